@@ -1,0 +1,180 @@
+/*
+ * smh_vision_hip.h -- C ABI of libsmh_vision_hip.so, the MI355X (gfx950) back-end for the
+ * squad-mortar-helper vision hot path.
+ *
+ * This is the drop-in boundary: one function per method of the reference's plugin trait
+ * `vision-common::Vision` (reference vision-common/src/lib.rs:30-61), i.e. exactly the table the
+ * reference resolves from its GPU plugin dylib (`{name}_init`, `{name}_shutdown`,
+ * `{name}_{load_frame,thread_ctx,crop_to_map,...}`; vision-common/src/dylib.rs:15-27,125-150).
+ * The reference's own table is `extern "Rust"` (unstable ABI), so a ~150-line Rust shim crate
+ * forwards each trait method to the function below (INTEGRATION.md shows it).  Plain pointers and
+ * sizes only; every function returns 0 on success or a negative SMHV_E_* code and never throws or
+ * aborts across the boundary (reference: Result<T, anyhow::Error>, vision-gpu/src/lib.rs:148).
+ *
+ * Parity target is the reference's CPU back-end (vision-cpu/src/lib.rs), NOT its CUDA back-end
+ * (the two differ: SURVEY.md Appendix A).
+ */
+#ifndef SMH_VISION_HIP_H
+#define SMH_VISION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMHV_API __attribute__((visibility("default")))
+
+/* error codes (negative).  smhv_last_error() returns the message of the calling thread's last failure. */
+#define SMHV_OK 0
+#define SMHV_E_INVALID (-1)  /* bad argument / call order (e.g. crop_to_map before load_frame)        */
+#define SMHV_E_GEOMETRY (-2) /* frame size for which the reference's bounds arithmetic would panic    */
+#define SMHV_E_HIP (-3)      /* HIP runtime error (message carries hipGetErrorString)                 */
+#define SMHV_E_NO_DEVICE (-4)/* no usable gfx950 device -- the caller falls back to its CPU back-end
+                                exactly as the reference does (src/vision/hardware.rs:73-76)          */
+#define SMHV_E_STATE (-5)    /* map closed / stage output not available                               */
+
+#define SMHV_MAX_LINES 32   /* find_lines::<32>, vision-common/src/lib.rs:58 */
+#define SMHV_MAX_SCALES 3   /* src/vision/mod.rs:131 */
+
+typedef struct smhv_ctx smhv_ctx;     /* one per device; ~ CudaInstance (vision-gpu/src/cuda.rs:15-94) */
+typedef struct smhv_batch smhv_batch; /* resident frame batch + its output buffers                    */
+
+/* == util::geometry::Line<f32> #[repr(C)] (util/src/geometry.rs:169-180): p0.x p0.y p1.x p1.y */
+typedef struct { float x0, y0, x1, y1; } smhv_line;
+
+/* log sink ~ the `&'static dyn log::Log` the reference passes to `{name}_init` (dylib.rs:79-83).
+ * level: 1=error 2=warn 3=info 4=debug. May be NULL. */
+typedef void (*smhv_log_fn)(int level, const char *msg);
+
+/* reference debug::DebugView (vision-common/src/debug.rs:31-40) */
+enum { SMHV_VIEW_NONE = 0, SMHV_VIEW_OCR_INPUT = 1, SMHV_VIEW_FIND_SCALES_INPUT = 2, SMHV_VIEW_LSD_PREPROCESS = 3,
+       SMHV_VIEW_LSD_INPUT = 4, SMHV_VIEW_CROPPED_BRQ = 5 };
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+/* replaces smh_vision_gpu_init (dylib.rs:77-88 -> CudaInstance::init, vision-gpu/src/cuda.rs:31-94) */
+SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out);
+/* replaces smh_vision_gpu_shutdown (dylib.rs:90-97); idempotent, NULL-safe */
+SMHV_API void smhv_shutdown(smhv_ctx *ctx);
+/* replaces Vision::thread_ctx (vision-gpu/src/lib.rs:154-165): binds the device to the calling thread */
+SMHV_API int smhv_thread_ctx(smhv_ctx *ctx);
+/* thread-local message of the last failing call on this thread ("" if none) */
+SMHV_API const char *smhv_last_error(void);
+
+/* ---- screen-relative bounds (vision-common/src/screen.rs:4-66, consts/mod.rs:7-19) ----------- */
+/* MAP_BOUNDS.into_absolute + "map fills remaining space" (vision-cpu/src/lib.rs:137-145) */
+SMHV_API int smhv_map_bounds(uint32_t frame_w, uint32_t frame_h, uint32_t xywh[4]);
+/* CLOSE_DEPLOYMENT_BUTTON_BOUNDS.into_absolute */
+SMHV_API int smhv_button_bounds(uint32_t frame_w, uint32_t frame_h, uint32_t xywh[4]);
+
+/* ---- per-frame trait surface ---------------------------------------------------------------- */
+/* Vision::load_frame (vision-gpu/src/lib.rs:167-193).  bgra: tightly packed BGRA8, w*h*4 bytes, host
+ * memory.  The bytes are copied; the caller keeps ownership (the Rust shim keeps the Arc<VisionFrame>
+ * for get_cpu_frame itself).  (Re)allocates device buffers when the dimensions change. */
+SMHV_API int smhv_load_frame(smhv_ctx *ctx, const uint8_t *bgra, uint32_t w, uint32_t h);
+/* Same, but the frame already lives in device memory (zero-copy path for device-side producers). */
+SMHV_API int smhv_load_frame_device(smhv_ctx *ctx, const void *d_bgra, uint32_t w, uint32_t h);
+
+/* Vision::crop_to_map (vision-cpu/src/lib.rs:110-171).  *map_open = 0 reproduces Ok(None) (red button
+ * fraction < 0.65): nothing else is written.  Otherwise roi = [x,y,w,h] and, if ui_rgba != NULL,
+ * w*h*4 bytes of RGBA (grayscale: luma,luma,luma,255) are written to it. */
+SMHV_API int smhv_crop_to_map(smhv_ctx *ctx, int grayscale, int *map_open, uint32_t roi[4], uint8_t *ui_rgba);
+/* number of "Close Deployment" red pixels counted by the last crop_to_map (diagnostic) */
+SMHV_API int smhv_red_pixels(smhv_ctx *ctx, uint32_t *count);
+
+/* Vision::ocr_preprocess (vision-cpu/src/lib.rs:173-231): *out is a borrowed host pointer to
+ * (w/2)*(h/2) bytes, valid until the next ocr_preprocess / load_frame on this context. */
+SMHV_API int smhv_ocr_preprocess(smhv_ctx *ctx, const uint8_t **out, size_t *len);
+/* Vision::find_scales_preprocess (vision-cpu/src/lib.rs:233-251): borrowed host image; rows above
+ * scales_start_y keep whatever the previous call left there (as in the reference). */
+SMHV_API int smhv_find_scales_preprocess(smhv_ctx *ctx, uint32_t scales_start_y, const uint8_t **out, uint32_t *w, uint32_t *h);
+
+/* Vision::isolate_map_markers (vision-cpu/src/lib.rs:253-280) */
+SMHV_API int smhv_isolate_map_markers(smhv_ctx *ctx);
+/* Vision::mask_marker_lines (vision-cpu/src/lib.rs:357-375): threshold + L1 radius-1 dilation */
+SMHV_API int smhv_mask_marker_lines(smhv_ctx *ctx);
+/* Host copy of the LSD mask (w*h bytes, values {0,255}) == "detected marker pixel coords". */
+SMHV_API int smhv_get_lsd_image(smhv_ctx *ctx, uint8_t *out, uint32_t *w, uint32_t *h);
+/* Vision::find_longest_line (vision-cpu/src/lib.rs:387-449) on the context's LSD image */
+SMHV_API int smhv_find_longest_line(smhv_ctx *ctx, float px, float py, float max_gap, smhv_line *line, float *len_sq);
+/* Vision::find_marker_lines (vision-cpu/src/lib.rs:377-385 -> lsd::find_lines::<32>, lsd.rs:60-107) */
+SMHV_API int smhv_find_marker_lines(smhv_ctx *ctx, uint32_t max_gap, smhv_line out[SMHV_MAX_LINES], uint32_t *n);
+/* calc_meters_to_px_ratio (src/vision/mpx_ratio.rs:3-134) on the image of the last
+ * find_scales_preprocess.  scales = n x {meters, x, y} (OCR label anchors, BRQ coordinates), n <= 3.
+ * *has = 0 reproduces None.  bars (optional) = n x {left, y, right, found} (the scales_debug lines). */
+SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *ctx, const uint32_t *scales, uint32_t n, double *ratio, int *has, uint32_t *bars);
+/* Vision::get_debug_view (vision-cpu/src/lib.rs:451-460): RGBA copy; rgba may be NULL to query w,h. */
+SMHV_API int smhv_get_debug_view(smhv_ctx *ctx, int which, uint8_t *rgba, uint32_t *w, uint32_t *h);
+
+/* ---- batched pipeline (BASELINE configs 2-5): frames resident in HBM -------------------------- */
+#define SMHV_STAGE_MARKERS 0x1u /* button test + marker mask + dilation + LSD                  */
+#define SMHV_STAGE_UI_MAP 0x2u  /* ui_map RGBA                                                   */
+#define SMHV_STAGE_OCR 0x4u     /* ocr_preprocess                                                */
+#define SMHV_STAGE_SCALES 0x8u  /* find_scales_preprocess + calc_meters_to_px_ratio (needs anchors) */
+#define SMHV_STAGE_ALL 0xFu
+
+/* One record per frame (what a node-level gather moves between GPUs).  mpx/derived fields follow
+ * src/ui/mod.rs:131-140 (length_px, meters in f64) and src/ui/markers.rs:98 (angle = atan2f). */
+typedef struct {
+	uint32_t map_open;              /* 0 = Ok(None): every other field is 0                        */
+	uint32_t n_lines;
+	smhv_line lines[SMHV_MAX_LINES];
+	double mpx;                     /* meters per pixel, valid iff has_mpx                         */
+	uint32_t has_mpx;
+	uint32_t n_mask_px;             /* 255-pixels in the dilated marker mask                       */
+	uint32_t red_pixels;            /* close-deployment button count                               */
+	uint32_t rounds;                /* find_longest_line invocations (workload statistic)          */
+	uint64_t ray_steps;             /* mask samples taken by all rays (workload statistic)         */
+	double length_px[SMHV_MAX_LINES];
+	double meters[SMHV_MAX_LINES];  /* length_px * mpx (0 when !has_mpx)                           */
+	float angle[SMHV_MAX_LINES];
+} smhv_frame_result;
+
+/* per-frame OCR anchors for SMHV_STAGE_SCALES: OCR (Tesseract) is outside this library */
+typedef struct {
+	uint32_t n;                     /* 0..3                                                        */
+	uint32_t scales_start_y;        /* min(ocr.bottom), src/vision/mod.rs:182                      */
+	uint32_t scales[SMHV_MAX_SCALES][3]; /* {meters, x, y}                                         */
+} smhv_anchors;
+
+typedef struct {
+	uint32_t frame_w, frame_h;
+	uint32_t roi[4], button[4];     /* map / button rects in frame coordinates                     */
+	uint32_t brq_w, brq_h;
+	/* device output layouts: row pitches in bytes, per-frame strides in bytes, and the byte offset
+	 * of pixel (0,0) inside a frame's slab (rows are padded so 16-byte stores stay aligned)        */
+	uint64_t ui_pitch, ui_stride, ui_offset;         /* RGBA8                                       */
+	uint64_t mask_pitch, mask_stride, mask_offset;   /* u8 {0,255}                                  */
+	uint64_t ocr_pitch, ocr_stride, ocr_offset;      /* u8                                          */
+	uint64_t scales_pitch, scales_stride, scales_offset; /* u8 {0,255}                              */
+	uint64_t bits_pitch_words, bits_stride, bits_xoff;   /* bit-packed mask: bit (x+xoff) of row y */
+} smhv_batch_layout;
+
+SMHV_API int smhv_batch_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, smhv_batch **out);
+SMHV_API void smhv_batch_destroy(smhv_batch *b);
+SMHV_API int smhv_batch_layout_get(smhv_batch *b, smhv_batch_layout *out);
+/* Runs the selected stages over n resident frames (d_frames: n * frame_w*frame_h*4 bytes of BGRA8 in
+ * device memory) on `stream` (a hipStream_t, NULL = default stream).  Asynchronous: results are in
+ * device memory when the stream reaches this point.  anchors: host array of n smhv_anchors or NULL. */
+SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                            const smhv_anchors *anchors, void *stream);
+/* device pointers of the batch outputs (valid for the life of the batch) */
+SMHV_API int smhv_batch_device_ptrs(smhv_batch *b, void **d_results, void **d_ui, void **d_mask, void **d_ocr, void **d_scales, void **d_bits);
+/* synchronising host copies (tightly packed) */
+SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, uint32_t n, smhv_frame_result *out);
+SMHV_API int smhv_batch_read_image(smhv_batch *b, int which /* SMHV_VIEW_* or 100 = ui_map RGBA */, uint32_t frame, uint8_t *out);
+/* Per-stage device time of the LAST smhv_batch_run with timing enabled, measured with hipEvents on
+ * the run's stream (the analogue of the reference's Timeshares, vision-common/src/debug.rs:3-30).
+ * ms[0]=button ms[1]=map pass ms[2]=brq pass ms[3]=lsd ms[4]=scale ratio.  Synchronises. */
+SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
+SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
+
+/* exhaustive colour-predicate check support: writes 2^24/32 words, bit (r<<16|g<<8|b) = device
+ * is_any_map_marker_color(r,g,b) (vision-common/src/markers/mod.rs:40-54) */
+SMHV_API int smhv_debug_marker_table(smhv_ctx *ctx, uint32_t *bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

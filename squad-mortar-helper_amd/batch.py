@@ -1,0 +1,102 @@
+"""Resident-batch pipeline (BASELINE configs 2-5): N frames stay in HBM, one result record per frame.
+
+torch is used only as plumbing (device memory for the frame batch, the current HIP stream and
+torch.distributed); every kernel is in libsmh_vision_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+STAGE_NAMES = ("button", "map_pass", "brq_pass", "lsd", "scale_ratio")
+
+
+def make_anchors(per_frame):
+    """per_frame: list (len n) of (scales_start_y, [(meters, x, y), ...]) -> ctypes array of smhv_anchors."""
+    arr = (L.Anchors * len(per_frame))()
+    for i, (start_y, scales) in enumerate(per_frame):
+        arr[i].n = len(scales)
+        arr[i].scales_start_y = start_y
+        for j, (m, x, y) in enumerate(scales[:L.MAX_SCALES]):
+            arr[i].scales[j][0], arr[i].scales[j][1], arr[i].scales[j][2] = m, x, y
+    return arr
+
+
+def results_to_dicts(recs):
+    out = []
+    for r in recs:
+        n = r.n_lines
+        out.append(dict(
+            map_open=int(r.map_open), n_lines=int(n),
+            lines=np.array([[r.lines[i].x0, r.lines[i].y0, r.lines[i].x1, r.lines[i].y1] for i in range(n)], np.float32).reshape(-1, 4),
+            mpx=(r.mpx if r.has_mpx else None), n_mask_px=int(r.n_mask_px), red_pixels=int(r.red_pixels),
+            rounds=int(r.rounds), ray_steps=int(r.ray_steps),
+            length_px=np.array(r.length_px[:n], np.float64), meters=np.array(r.meters[:n], np.float64),
+            angle=np.array(r.angle[:n], np.float32)))
+    return out
+
+
+class FrameBatch:
+    """Owns the output buffers for up to `max_frames` frames of one size on one device."""
+
+    def __init__(self, vision, frame_w, frame_h, max_frames):
+        self._lib = L.load()
+        self._vision = vision            # keeps the context alive
+        b = C.c_void_p()
+        L.check(self._lib.smhv_batch_create(vision._ctx, frame_w, frame_h, max_frames, C.byref(b)))
+        self._b = b
+        self.max_frames = max_frames
+        self.frame_w, self.frame_h = frame_w, frame_h
+        self.layout = L.BatchLayout()
+        L.check(self._lib.smhv_batch_layout_get(self._b, C.byref(self.layout)))
+
+    def close(self):
+        if self._b:
+            self._lib.smhv_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def roi(self):
+        return tuple(self.layout.roi)
+
+    def enable_timing(self, on=True):
+        L.check(self._lib.smhv_batch_enable_timing(self._b, int(on)))
+
+    def run(self, frames_ptr, n, stages=L.STAGE_ALL, grayscale=True, max_gap=15, anchors=None, stream=0):
+        """frames_ptr: device address of n tightly packed BGRA8 frames.  Asynchronous on `stream`."""
+        a = C.cast(anchors, C.c_void_p) if anchors is not None else None
+        L.check(self._lib.smhv_batch_run(self._b, C.c_void_p(frames_ptr), n, stages, int(bool(grayscale)), max_gap, a, C.c_void_p(stream)))
+
+    def stage_ms(self):
+        ms = (C.c_float * 5)()
+        L.check(self._lib.smhv_batch_stage_ms(self._b, ms))
+        return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
+
+    def device_ptrs(self):
+        p = [C.c_void_p() for _ in range(6)]
+        L.check(self._lib.smhv_batch_device_ptrs(self._b, *[C.byref(x) for x in p]))
+        return dict(zip(("results", "ui", "mask", "ocr", "scales", "bits"), [x.value for x in p]))
+
+    def read_results(self, first=0, n=None):
+        n = self.max_frames - first if n is None else n
+        recs = (L.FrameResult * n)()
+        L.check(self._lib.smhv_batch_read_results(self._b, first, n, recs))
+        return recs
+
+    def read_image(self, which, frame):
+        x, y, w, h = self.roi
+        if which == L.IMAGE_UI_MAP:
+            out = np.empty((h, w, 4), np.uint8)
+        elif which == L.VIEW_LSD_INPUT:
+            out = np.empty((h, w), np.uint8)
+        else:
+            out = np.empty((h // 2, w // 2), np.uint8)
+        L.check(self._lib.smhv_batch_read_image(self._b, which, frame, out.ctypes.data))
+        return out

@@ -1,0 +1,65 @@
+// smh_kernels.h -- launch interface between the host runtime (smh_runtime.cpp) and the gfx950
+// kernels (smh_kernels.hip).  Internal; the public boundary is include/smh_vision_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/smh_vision_hip.h"
+
+namespace smh {
+
+// Geometry + device buffer layout of one frame size.  All buffers are per-batch slabs indexed by
+// frame; rows are padded so that the 16-byte-per-lane accesses of the streaming passes are
+// aligned: a "quad" is 4 horizontally adjacent pixels whose frame x is a multiple of 4, and the
+// padded output rows start at the ROI's quad-aligned x (ROI pixel 0 sits `xoff` pixels in).
+struct Geom {
+	uint32_t W, H;                 // frame
+	uint32_t rx, ry, rw, rh;       // map ROI (reference "cropped_map")
+	uint32_t bx, by, bw, bh;       // close-deployment button
+	uint32_t qx, qy, qw, qh;       // bottom-right quadrant in FRAME coordinates / size
+	// map pass
+	uint32_t m_ax, m_xoff, m_quads, m_block;   // aligned x, rx - ax, quads per row, threads per block
+	// brq pass
+	uint32_t q_ax, q_xoff, q_quads, q_block;
+	// layouts (bytes unless noted)
+	uint64_t frame_bytes;
+	uint64_t ui_pitch, ui_stride;
+	uint64_t mask_pitch, mask_stride;
+	uint32_t bits_pitch_w; uint64_t bits_stride_w;  // words
+	uint64_t ocr_pitch, ocr_stride;                // also used for the scales image
+};
+
+// per-frame scratch written by k_button / k_map_pass, read by k_lsd
+struct FrameAux {
+	uint32_t open;        // button test passed
+	uint32_t red;         // red pixel count
+	uint32_t n_mask_px;   // popcount of the dilated mask
+	uint32_t y_min, y_max, w_min, w_max;  // bounding box of set bits: rows, and words of the bit-packed rows
+	uint32_t pad;
+};
+
+struct Buffers {
+	const uint8_t *frames;   // n * frame_bytes
+	uint8_t *ui, *mask, *ocr, *scales;
+	uint32_t *bits;
+	FrameAux *aux;
+	smhv_frame_result *results;
+	const smhv_anchors *anchors;   // device copy, may be null
+};
+
+enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u };
+enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
+
+hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
+hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s);
+hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
+// mode 0: find_lines (whole frame); mode 1: one find_longest_line round from (px,py), result in results[f].lines[0], len^2 in length_px[0]
+hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s);
+hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
+hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s);
+// which: SMHV_VIEW_*; isolated: LSDPreprocess shows the marker-isolated crop (after isolate_map_markers)
+hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s);
+hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
+size_t lsd_lds_bytes();
+
+}  // namespace smh

@@ -1,0 +1,898 @@
+// smh_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the squad-mortar-helper vision
+// hot path.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
+// structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
+//
+// Build with -ffp-contract=off and correctly rounded f32 division: several results are
+// truncated to integers right at a threshold, so the reference's scalar f32 operation order
+// (no FMA contraction, IEEE divide) is part of the contract.
+//
+// Kernels
+//   k_button      red "Close Deployment" pixel count -> map_open           (lib.rs:116-133)
+//   k_map_pass    one streaming pass over the map ROI: ui_map RGBA + marker colour predicate +
+//                 L1 radius-1 dilation -> u8 mask + bit-packed mask + bbox   (lib.rs:137-171,253-280,357-375)
+//   k_brq_pass    bottom-right quadrant: ocr_preprocess + find_scales_preprocess (lib.rs:173-251)
+//   k_lsd         lsd::find_lines::<32> incl. find_longest_line, one workgroup per frame,
+//                 mask window resident in LDS                                (lsd.rs:5-107, lib.rs:387-449)
+//   k_scale_ratio calc_meters_to_px_ratio / find_scale_width                 (src/vision/mpx_ratio.rs:3-134)
+//   k_finalize    derived marker outputs                                     (src/ui/mod.rs:131-140, markers.rs:98)
+#include "smh_kernels.h"
+#include "smh_consts.h"
+
+namespace smh {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+// Rust `f32 as u32`: truncate toward zero, saturate, NaN -> 0.
+__device__ __forceinline__ uint32_t f2u(float v) {
+	return (v >= 0.0f) ? ((v >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)v) : 0u;
+}
+
+// image 0.23.14 rgb_to_luma: (0.2126 r + 0.7152 g) + 0.0722 b in f32, truncated to u8.
+__device__ __forceinline__ uint32_t luma8(uint32_t r, uint32_t g, uint32_t b) {
+	float l = SMH_LUMA_R * (float)r + SMH_LUMA_G * (float)g + SMH_LUMA_B * (float)b;
+	uint32_t u = (uint32_t)l;   // l is in [0, 255.0001]
+	return u > 255u ? 255u : u;
+}
+
+__device__ __forceinline__ uint32_t absdiff(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
+
+// util/src/image.rs:159-187 hsv() + vision-common/src/markers/mod.rs:17-19,40-54, evaluated exactly
+// as the reference does (f32, same operation order).  Two identities remove the fmodf calls:
+//   ((g-b)/delta) % 6.0   : |(g-b)/delta| <= 1 < 6, so fmodf returns its argument unchanged;
+//   modulo(h, 360.0)      : h is in [-60, 300], so fmodf(h,360) == h and only the `+ 360` applies.
+// tests/test_gpu_parity.py checks the device predicate against the oracle on all 2^24 colours.
+__device__ __forceinline__ bool marker_exact(uint32_t r8, uint32_t g8, uint32_t b8) {
+	const float r = (float)r8 / 255.0f, g = (float)g8 / 255.0f, b = (float)b8 / 255.0f;
+	const float mx = fmaxf(r, fmaxf(g, b));
+	const float mn = fminf(r, fminf(g, b));
+	const float delta = mx - mn;
+	float h;
+	if (mx == mn) h = 0.0f;
+	else if (mx == r) h = 60.0f * ((g - b) / delta);
+	else if (mx == g) h = 60.0f * (((b - r) / delta) + 2.0f);
+	else h = 60.0f * (((r - g) / delta) + 4.0f);
+	if (h < 0.0f) h = h + 360.0f;
+	const float sf = (100.0f * delta) / mx;     // NaN when mx == 0 -> 0
+	const float vf = 100.0f * mx;
+	const uint32_t hu = f2u(h);
+	uint32_t su = f2u(sf); su = su > 255u ? 255u : su;
+	uint32_t vu = f2u(vf); vu = vu > 255u ? 255u : vu;
+	if (su < SMH_HSV_MIN_SAT) return false;
+	bool any = false;
+#define SMH_TEAM(MH, MS, MV)                                                                              \
+	any = any || (absdiff(MH, hu) <= SMH_HSV_HUE_TOLERANCE &&                                             \
+	              (absdiff(MS, su) <= SMH_HSV_SAT_TOLERANCE ||                                            \
+	               (uint32_t)abs((int)su - ((int)(MS) - SMH_PLAYER_DIR_ARC_SAT)) <= SMH_HSV_SAT_TOLERANCE) && \
+	              absdiff(MV, vu) <= SMH_HSV_VIB_TOLERANCE)
+	SMH_TEAM(SMH_ALPHA_H, SMH_ALPHA_S, SMH_ALPHA_V);
+	SMH_TEAM(SMH_BRAVO_H, SMH_BRAVO_S, SMH_BRAVO_V);
+	SMH_TEAM(SMH_CHARLIE_H, SMH_CHARLIE_S, SMH_CHARLIE_V);
+#undef SMH_TEAM
+	return any;
+}
+
+// Cheap integer necessary condition in front of the exact float path (most map terrain fails it,
+// so whole waves skip the divisions):  s >= 35 needs 100*d/m >= 34.99 (the f32 result is within
+// 1e-4 of the rational), and every team window needs v >= 70, i.e. max channel >= 178.
+__device__ __forceinline__ bool is_marker(uint32_t r8, uint32_t g8, uint32_t b8) {
+	const uint32_t m = max(r8, max(g8, b8)), n = min(r8, min(g8, b8)), d = m - n;
+	bool res = false;
+	if (m >= 178u && d * 10000u >= 3499u * m) res = marker_exact(r8, g8, b8);
+	return res;
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+	for (int o = 32; o; o >>= 1) v |= __shfl_xor(v, o);
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+	for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+__device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
+	for (int o = 32; o; o >>= 1) { uint64_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+	return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_button: one workgroup per frame.  Also resets the per-frame scratch for the later passes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_open) {
+	const uint32_t f = blockIdx.x;
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes;
+	__shared__ uint32_t s_cnt;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
+	uint32_t cnt = 0;
+	const uint32_t npx = g.bw * g.bh;
+	for (uint32_t i = threadIdx.x; i < npx; i += blockDim.x) {
+		const uint32_t y = i / g.bw, x = i - y * g.bw;
+		const uint32_t p = *(const uint32_t *)(fp + ((size_t)(g.by + y) * g.W + g.bx + x) * 4);   // B | G<<8 | R<<16 | A<<24
+		const uint32_t bb = p & 255u, gg = (p >> 8) & 255u, rr = (p >> 16) & 255u;
+		cnt += (absdiff(SMH_BUTTON_R, rr) <= SMH_BUTTON_TOLERANCE && absdiff(SMH_BUTTON_G, gg) <= SMH_BUTTON_TOLERANCE &&
+		        absdiff(SMH_BUTTON_B, bb) <= SMH_BUTTON_TOLERANCE) ? 1u : 0u;
+	}
+	cnt = wave_sum32(cnt);
+	if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, cnt);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const uint32_t red = s_cnt;
+		// `red_pixels as f32 / (w * h) as f32 < 0.65` => Ok(None)   (vision-cpu/src/lib.rs:130-133)
+		const float ratio = (float)red / (float)npx;
+		FrameAux a;
+		a.open = (force_open || !(ratio < SMH_BUTTON_RED_PIXEL_THRESHOLD)) ? 1u : 0u;
+		a.red = red; a.n_mask_px = 0;
+		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.pad = 0;
+		b.aux[f] = a;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_map_pass
+//
+// grid = (row bands, frames); block = one thread per quad (4 pixels, 16-byte BGRA load) across the
+// whole ROI width, so the waves of a workgroup sit side by side on the same rows.
+// Each thread marches down its quad column over the band's rows (+1 halo row above and below) and
+// keeps the marker predicate as four 64-bit column masks (bit = row).  In that form
+//   vertical dilation   = p | p<<1 | p>>1            (all rows of the band at once)
+//   horizontal dilation = neighbouring column masks  (own registers, lane+-1 via DPP shuffles,
+//                                                      wave edges via 16 B of LDS per wave)
+// so the 3x3-cross dilation of the reference (imageproc dilate_mut(L1,1)) costs a dozen
+// instructions per band instead of a second pass over an intermediate image.  ui_map is written
+// straight from the loaded registers; the frame is read exactly once (+2 halo rows per band).
+// ------------------------------------------------------------------------------------------------
+#define MAP_RB_MAX 62
+
+template <bool GRAY>
+__global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t flags, uint32_t RB) {
+	const uint32_t f = blockIdx.y;
+	if (!b.aux[f].open) return;
+	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
+	const int r0 = (int)(blockIdx.x * RB);
+	const int r1 = min(r0 + (int)RB, (int)g.rh);
+	const bool qact = q < g.m_quads;
+	uint32_t vmask = 0;
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		if ((uint32_t)(4 * q + c - g.m_xoff) < g.rw) vmask |= 1u << c;
+	if (!qact) vmask = 0;
+
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax + 4 * q) * 4;
+	uint8_t *uip = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
+	const size_t row_bytes = (size_t)g.W * 4;
+
+	uint64_t P[4] = {0, 0, 0, 0};
+	const int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
+	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
+
+	for (int r = rs; r <= re; r += 4) {
+		uint4 px[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int rr = min(r + k, re);
+			px[k] = qact ? *(const uint4 *)(fp + (size_t)rr * row_bytes) : make_uint4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int row = r + k;
+			if (row > re) break;
+			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+			if (do_ui && row >= r0 && row < r1 && qact) {
+				uint4 o;
+				uint32_t ov[4];
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+					if (GRAY) ov[c] = luma8(rr8, gg, bb) * 0x00010101u | 0xFF000000u;   // Bgra::to_luma -> (l,l,l,255)
+					else ov[c] = rr8 | (gg << 8) | (bb << 16) | 0xFF000000u;           // (r,g,b,255)
+				}
+				o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
+				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
+			}
+			if (do_mask) {
+				const int bit = row - (r0 - 1);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const uint32_t p = pv[c];
+					const bool m = ((vmask >> c) & 1u) && is_marker((p >> 16) & 255u, (p >> 8) & 255u, p & 255u);
+					P[c] |= (uint64_t)(m ? 1u : 0u) << bit;
+				}
+			}
+		}
+	}
+	if (!do_mask) return;
+
+	// ---- dilation on the column masks ----
+	__shared__ uint64_t s_edge_first[16], s_edge_last[16];
+	if (lane == 0) s_edge_first[wave] = P[0];
+	if (lane == 63) s_edge_last[wave] = P[3];
+	__syncthreads();
+	uint64_t left = __shfl_up(P[3], 1), right = __shfl_down(P[0], 1);
+	if (lane == 0) left = wave > 0 ? s_edge_last[wave - 1] : 0ull;
+	if (lane == 63) right = wave + 1 < nwave ? s_edge_first[wave + 1] : 0ull;
+	const int nrows = r1 - r0;
+	const uint64_t rowmask = ((nrows >= 63 ? ~0ull : ((1ull << nrows) - 1ull)) << 1);   // bits 1..nrows
+	uint64_t D[4];
+#define SMH_VERT(p) ((p) | ((p) << 1) | ((p) >> 1))
+	D[0] = SMH_VERT(P[0]) | left | P[1];
+	D[1] = SMH_VERT(P[1]) | P[0] | P[2];
+	D[2] = SMH_VERT(P[2]) | P[1] | P[3];
+	D[3] = SMH_VERT(P[3]) | P[2] | right;
+#undef SMH_VERT
+#pragma unroll
+	for (int c = 0; c < 4; ++c) D[c] = ((vmask >> c) & 1u) ? (D[c] & rowmask) : 0ull;
+
+	// ---- outputs: u8 mask rows and bit-packed rows ----
+	const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
+	if (q < quads_padded) {
+		uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
+		uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
+		for (int row = r0; row < r1; ++row) {
+			const int bit = row - r0 + 1;
+			const uint32_t nib = (uint32_t)((D[0] >> bit) & 1ull) | ((uint32_t)((D[1] >> bit) & 1ull) << 1) |
+			                     ((uint32_t)((D[2] >> bit) & 1ull) << 2) | ((uint32_t)((D[3] >> bit) & 1ull) << 3);
+			*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;
+			// gather 8 lanes' nibbles into one dword of the bit-packed row (lane l supplies bits 4(l%8)..)
+			uint32_t v = nib;
+			v |= __shfl_down(v, 1) << 4;
+			v |= __shfl_down(v, 2) << 8;
+			v |= __shfl_down(v, 4) << 16;
+			if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
+		}
+	}
+	// ---- bounding box + population count of the set bits (drives the LDS window of k_lsd) ----
+	const uint64_t any = D[0] | D[1] | D[2] | D[3];
+	const uint64_t lanes_set = __ballot(any != 0ull);
+	if (lanes_set) {
+		const uint64_t rows_set = wave_or64(any);
+		const uint32_t cnt = wave_sum32(__popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]));
+		if (lane == 0) {
+			FrameAux *a = &b.aux[f];
+			atomicMin(&a->y_min, (uint32_t)(r0 - 1 + __builtin_ctzll(rows_set)));
+			atomicMax(&a->y_max, (uint32_t)(r0 - 1 + 63 - __builtin_clzll(rows_set)));
+			atomicMin(&a->w_min, (wave * 64u + (uint32_t)__builtin_ctzll(lanes_set)) >> 3);
+			atomicMax(&a->w_max, (wave * 64u + 63u - (uint32_t)__builtin_clzll(lanes_set)) >> 3);
+			atomicAdd(&a->n_mask_px, cnt);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_brq_pass: ocr_preprocess (lib.rs:173-231) + find_scales_preprocess (lib.rs:233-251) over the
+// bottom-right quadrant, same column-mask technique with a 3-row halo.
+//   monochromaticy = sum over ordered pairs |ci-cj| = 4*(max-min)
+//     "<= 3"  <=> r == g == b            "<= 48" <=> max-min <= 12
+//   keep(x,y) = W(x,y) || (E(x,y) && exists W in [x-3, min(x+3, w-3)] x [y-3, min(y+3, h-3)])
+//     W = r==g==b && all >= 200,  E = max-min <= 12 && all >= 130
+// ------------------------------------------------------------------------------------------------
+#define BRQ_RB 58
+
+__global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start) {
+	const uint32_t f = blockIdx.y;
+	if (!b.aux[f].open) return;
+	uint32_t start_y = fixed_start_y;
+	bool do_scales = (flags & BRQ_SCALES) != 0;
+	if (use_anchor_start) {
+		const smhv_anchors an = b.anchors[f];
+		start_y = an.scales_start_y;
+		// src/vision/mod.rs:196-198: no labels => the scales branch returns before find_scales_preprocess
+		if (an.n == 0 || start_y > g.qh) do_scales = false;
+	}
+	const bool do_ocr = (flags & BRQ_OCR) != 0;
+	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
+	const int r0 = (int)(blockIdx.x * BRQ_RB);
+	const int r1 = min(r0 + BRQ_RB, (int)g.qh);
+	const bool qact = q < g.q_quads;
+	uint32_t vmask = 0, wmask = 0;   // valid pixel / pixel allowed as a "white neighbour" (x <= w-3)
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint32_t x = 4 * q + c - g.q_xoff;
+		if (x < g.qw) vmask |= 1u << c;
+		if (x + SMH_OCR_DILATE_RADIUS <= g.qw) wmask |= 1u << c;   // x <= w - 3
+	}
+	if (!qact) { vmask = 0; wmask = 0; }
+	wmask &= vmask;
+
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.qy * g.W + g.q_ax + 4 * q) * 4;
+	const size_t row_bytes = (size_t)g.W * 4;
+	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride + (size_t)q * 4;
+	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride + (size_t)q * 4;
+
+	uint64_t Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
+	const int rs = max(r0 - 3, 0), re = min(r1 + 2, (int)g.qh - 1);
+	for (int r = rs; r <= re; r += 4) {
+		uint4 px[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int rr = min(r + k, re);
+			px[k] = qact ? *(const uint4 *)(fp + (size_t)rr * row_bytes) : make_uint4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int row = r + k;
+			if (row > re) break;
+			const int bit = row - (r0 - 3);
+			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+			const bool out_row = row >= r0 && row < r1;
+			const bool nb_row = (uint32_t)row + SMH_OCR_DILATE_RADIUS <= g.qh;   // y <= h - 3
+			uint32_t ocr_w = 0, sc_w = 0;
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+				const uint32_t mx = max(rr8, max(gg, bb)), mn = min(rr8, min(gg, bb));
+				const bool w = (mx == mn) && mn >= SMH_OCR_BRIGHTNESS_THRESHOLD;
+				const bool e = (4u * (mx - mn) <= SMH_OCR_SIMILARITY_EDGE_THRESHOLD) && mn >= SMH_OCR_BRIGHTNESS_EDGE_THRESHOLD && !w;
+				const bool valid = (vmask >> c) & 1u;
+				Wb[c] |= (uint64_t)((w && nb_row && ((wmask >> c) & 1u)) ? 1u : 0u) << bit;
+				Eb[c] |= (uint64_t)((e && valid && out_row) ? 1u : 0u) << bit;
+				const uint32_t l = luma8(rr8, gg, bb);
+				ocr_w |= ((w && valid) ? (255u - l) : 255u) << (8 * c);
+				sc_w |= (l != 0u ? 255u : 0u) << (8 * c);
+			}
+			if (out_row && qact) {
+				if (do_ocr) *(uint32_t *)(op + (size_t)row * g.ocr_pitch) = ocr_w;
+				if (do_scales && (uint32_t)row >= start_y) *(uint32_t *)(sp + (size_t)row * g.ocr_pitch) = sc_w;
+			}
+		}
+	}
+	if (!do_ocr) return;
+
+	// ---- 7x7 "white neighbour" dilation on the column masks ----
+	uint64_t V[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint64_t w = Wb[c];
+		V[c] = w | (w << 1) | (w << 2) | (w << 3) | (w >> 1) | (w >> 2) | (w >> 3);
+	}
+	__shared__ uint64_t s_first[16][4], s_last[16][4];
+	if (lane == 0) { s_first[wave][0] = V[0]; s_first[wave][1] = V[1]; s_first[wave][2] = V[2]; s_first[wave][3] = V[3]; }
+	if (lane == 63) { s_last[wave][0] = V[0]; s_last[wave][1] = V[1]; s_last[wave][2] = V[2]; s_last[wave][3] = V[3]; }
+	__syncthreads();
+	uint64_t X[12];   // columns -4..7 relative to this quad
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		uint64_t l = __shfl_up(V[c], 1), r = __shfl_down(V[c], 1);
+		if (lane == 0) l = wave > 0 ? s_last[wave - 1][c] : 0ull;
+		if (lane == 63) r = wave + 1 < nwave ? s_first[wave + 1][c] : 0ull;
+		X[c] = l; X[4 + c] = V[c]; X[8 + c] = r;
+	}
+	bool any_patch = false;
+	uint64_t K[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		uint64_t d = 0;
+#pragma unroll
+		for (int k = -3; k <= 3; ++k) d |= X[4 + c + k];
+		K[c] = Eb[c] & d;
+		any_patch = any_patch || K[c] != 0ull;
+	}
+	// Pixels kept only because of a white neighbour are rare (anti-aliased glyph edges): re-read
+	// just those pixels for their luma and patch the byte written above (same thread => ordered).
+	if (any_patch) {
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			uint64_t k = K[c];
+			while (k) {
+				const int bit = __builtin_ctzll(k);
+				k &= k - 1;
+				const int row = r0 - 3 + bit;
+				const uint32_t p = *(const uint32_t *)(fp + (size_t)row * row_bytes + 4 * c);
+				const uint32_t l = luma8((p >> 16) & 255u, (p >> 8) & 255u, p & 255u);
+				op[(size_t)row * g.ocr_pitch + c] = (uint8_t)(255u - l);
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_lsd: lsd::find_lines::<32> with find_longest_line inlined; one workgroup per frame.
+// ------------------------------------------------------------------------------------------------
+struct RayDir { uint32_t dx, dy; };
+__device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
+#include "ray_table.inc"
+};
+
+#define LSD_BS 1024
+#define LSD_NW (LSD_BS / 64)
+#define LSD_RPT ((SMH_LSD_RAYS + LSD_BS - 1) / LSD_BS)
+#define LSD_LIST_CAP 4096u
+#define LSD_WIN_WORDS_CAP 35840u                       // 140 KiB window + 16 KiB list + static < 160 KiB
+#define LSD_DYN_LDS_BYTES ((LSD_WIN_WORDS_CAP + LSD_LIST_CAP) * 4u)
+
+// Window of the bit-packed mask: rows [wy0, wy0+wrows), words [ww0, ww0+wwords) of each row.
+// Every set bit of the mask lies inside the window (it is the bounding box of the set bits), so a
+// read outside it is 0.  `p` points at LDS (window copy) or at global memory (whole mask).
+struct MaskView {
+	const uint32_t *p;
+	uint32_t pitch, wy0, ww0, wrows, wwords, xoff, w, h;
+	__device__ __forceinline__ uint32_t at(uint32_t xi, uint32_t yi) const {   // 0 <= xi < w, 0 <= yi < h
+		const uint32_t X = xi + xoff, ry = yi - wy0, rc = (X >> 5) - ww0;
+		uint32_t v = 0;
+		if (ry < wrows && rc < wwords) v = (p[ry * pitch + rc] >> (X & 31u)) & 1u;
+		return v;
+	}
+};
+
+// find_line_in_image closure, vision-cpu/src/lib.rs:388-432 (literal).
+__device__ __forceinline__ void cast_ray(const MaskView &m, float xs, float ys, float max_gap, float dx, float dy, float &xe, float &ye,
+                                         uint32_t &steps) {
+	float x = xs, y = ys, xo = 0.0f, yo = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+	const float wf = (float)m.w, hf = (float)m.h;
+	while (x >= 0.0f && y >= 0.0f && x < wf && y < hf) {
+		++steps;
+		if (m.at((uint32_t)x, (uint32_t)y)) {
+			g0 = 0.0f; g1 = 0.0f; g2 = 0.0f;
+		} else if (g0 >= max_gap) {
+			x = g1; y = g2;
+			break;
+		} else if (g0 == 0.0f) {
+			g0 = 1.0f; g1 = x; g2 = y;
+		} else {
+			g0 += 1.0f;
+		}
+		xo += dx; yo += dy;
+		x = xo + xs; y = yo + ys;
+	}
+	xe = xs; ye = ys;
+	const uint32_t xi = f2u(x), yi = f2u(y);
+	if (xi < m.w && yi < m.h && m.at(xi, yi) == 0u) { xe = x - dx; ye = y - dy; }
+}
+
+// get_centre, vision-common/src/lsd.rs:5-44 (coordinates clamped like the oracle).
+__device__ __forceinline__ uint32_t white_at(const MaskView &m, float fx, float fy) {
+	uint32_t xi = f2u(fx), yi = f2u(fy);
+	xi = min(xi, m.w - 1u); yi = min(yi, m.h - 1u);
+	return m.at(xi, yi);
+}
+__device__ void get_centre(const MaskView &m, float px, float py, float &ox, float &oy) {
+	float left = px;
+	while (left > 0.0f && fabsf(left - px) < SMH_LSD_CENTRE_REACH && white_at(m, left, py)) left -= 1.0f;
+	float right = px;
+	while (right < (float)(m.w - 1u) && fabsf(right - px) < SMH_LSD_CENTRE_REACH && white_at(m, right, py)) right += 1.0f;
+	float up = py;
+	while (up > 0.0f && fabsf(up - py) < SMH_LSD_CENTRE_REACH && white_at(m, px, up)) up -= 1.0f;
+	float down = py;
+	while (down < (float)(m.h - 1u) && fabsf(down - py) < SMH_LSD_CENTRE_REACH && white_at(m, px, down)) down += 1.0f;
+	ox = (left + right) / 2.0f;
+	oy = (up + down) / 2.0f;
+}
+
+// lsd.rs:47-58 + the `< 50.0` test of lsd.rs:84-89 (u is not clamped: infinite line).
+__device__ __forceinline__ bool near_line(float x, float y, float x0, float y0, float x1, float y1) {
+	const float dx = x1 - x0, dy = y1 - y0;
+	float nx = x0, ny = y0;
+	if (!(dx == 0.0f && dy == 0.0f)) {
+		const float u = ((x - x0) * dx + (y - y0) * dy) / (dx * dx + dy * dy);
+		nx = x0 + u * dx; ny = y0 + u * dy;
+	}
+	const float ex = x - nx, ey = y - ny;
+	return ex * ex + ey * ey < SMH_LSD_PROXIMITY_SQ;
+}
+
+struct LsdShared {
+	uint64_t red[LSD_NW];
+	uint32_t cand[LSD_NW];
+	uint32_t scan[LSD_NW];
+	float best[2];
+	uint32_t segnext;
+	unsigned long long steps;
+	float lines[SMH_LSD_MAX_LINES][4];
+};
+
+// One find_longest_line round over all 3600 rays (vision-cpu/src/lib.rs:434-446): max len^2,
+// ties -> highest ray index.  Returns the packed key (len^2 bits << 32 | index); the end point
+// goes through sh.best.  Block-uniform result.
+__device__ __forceinline__ uint64_t ray_round(const MaskView &m, LsdShared &sh, float ptx, float pty, float max_gap, const float *rdx,
+                                              const float *rdy, uint32_t &steps) {
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	uint64_t best = 0;
+	float bxe = ptx, bye = pty;
+#pragma unroll
+	for (int j = 0; j < LSD_RPT; ++j) {
+		const uint32_t i = tid + LSD_BS * j;
+		if (i < SMH_LSD_RAYS) {
+			float xe, ye;
+			cast_ray(m, ptx, pty, max_gap, rdx[j], rdy[j], xe, ye, steps);
+			const float ddx = ptx - xe, ddy = pty - ye;
+			const float len = ddx * ddx + ddy * ddy;
+			const uint64_t key = ((uint64_t)__float_as_uint(len) << 32) | i;
+			if (key > best) { best = key; bxe = xe; bye = ye; }
+		}
+	}
+	const uint64_t wbest = wave_max64(best);
+	if (lane == 0) sh.red[wave] = wbest;
+	__syncthreads();
+	uint64_t gbest = 0;
+#pragma unroll
+	for (int k = 0; k < LSD_NW; ++k) gbest = max(gbest, sh.red[k]);
+	if (best == gbest && (gbest != 0ull || tid == 0)) { sh.best[0] = bxe; sh.best[1] = bye; }
+	__syncthreads();
+	return gbest;
+}
+
+template <bool LDSWIN>
+__device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max_gap, int mode, float spx, float spy, const FrameAux &aux,
+                          uint32_t *smem, LsdShared &sh) {
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	smhv_frame_result *res = &b.results[f];
+	const uint32_t *gbits = b.bits + (size_t)f * g.bits_stride_w;
+
+	MaskView m;
+	m.xoff = g.m_xoff; m.w = g.rw; m.h = g.rh;
+	uint32_t *list;
+	if (LDSWIN) {
+		m.wy0 = aux.y_min; m.ww0 = aux.w_min;
+		m.wrows = aux.y_max - aux.y_min + 1u; m.wwords = aux.w_max - aux.w_min + 1u;
+		m.pitch = m.wwords;
+		m.p = smem;
+		list = smem + LSD_WIN_WORDS_CAP;
+		const uint32_t wt = m.wrows * m.wwords;
+		for (uint32_t idx = tid; idx < wt; idx += LSD_BS) {
+			const uint32_t r = idx / m.wwords, c = idx - r * m.wwords;
+			smem[idx] = gbits[(size_t)(m.wy0 + r) * g.bits_pitch_w + m.ww0 + c];
+		}
+	} else {
+		m.wy0 = 0; m.ww0 = 0; m.wrows = g.rh; m.wwords = g.bits_pitch_w; m.pitch = g.bits_pitch_w;
+		m.p = gbits;
+		list = smem;
+	}
+	const uint32_t WT = m.wrows * m.wwords;
+	if (tid == 0) sh.steps = 0ull;
+
+	float rdx[LSD_RPT], rdy[LSD_RPT];
+#pragma unroll
+	for (int j = 0; j < LSD_RPT; ++j) {
+		const uint32_t i = min(tid + LSD_BS * j, (uint32_t)SMH_LSD_RAYS - 1u);
+		rdx[j] = __uint_as_float(g_ray_table[i].dx);
+		rdy[j] = __uint_as_float(g_ray_table[i].dy);
+	}
+	__syncthreads();
+
+	uint32_t steps = 0, rounds = 0, n_lines = 0;
+
+	if (mode == 1) {   // Vision::find_longest_line on an arbitrary point
+		const uint64_t key = ray_round(m, sh, spx, spy, max_gap, rdx, rdy, steps);
+		if (tid == 0) {
+			res->lines[0].x0 = spx; res->lines[0].y0 = spy; res->lines[0].x1 = sh.best[0]; res->lines[0].y1 = sh.best[1];
+			res->length_px[0] = (double)__uint_as_float((uint32_t)(key >> 32));
+			res->n_lines = 1; res->rounds = 1;
+		}
+		return;
+	}
+
+	uint32_t seg_start = 0;
+	bool done = false;
+	while (!done) {
+		// ---- ordered compaction of the non-zero mask words in [seg_start, WT) into `list` ----
+		const uint32_t range = WT - seg_start;
+		const uint32_t per = (range + LSD_BS - 1u) / LSD_BS;
+		const uint32_t my0 = min(seg_start + tid * per, WT), my1 = min(my0 + per, WT);
+		uint32_t cnt = 0;
+		for (uint32_t wi = my0; wi < my1; ++wi) cnt += m.p[wi] != 0u ? 1u : 0u;
+		uint32_t incl = cnt;
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
+		if (lane == 63) sh.scan[wave] = incl;
+		if (tid == 0) sh.segnext = WT;
+		__syncthreads();
+		uint32_t wprefix = 0, total = 0;
+#pragma unroll
+		for (int k = 0; k < LSD_NW; ++k) { const uint32_t s = sh.scan[k]; if ((uint32_t)k < wave) wprefix += s; total += s; }
+		uint32_t o = wprefix + incl - cnt;
+		for (uint32_t wi = my0; wi < my1; ++wi)
+			if (m.p[wi] != 0u) {
+				if (o < LSD_LIST_CAP) list[o] = wi;
+				else if (o == LSD_LIST_CAP) sh.segnext = wi;
+				++o;
+			}
+		__syncthreads();
+		const uint32_t T = min(total, LSD_LIST_CAP);
+		const uint32_t segnext = sh.segnext;
+
+		for (uint32_t cbase = 0; cbase < T && !done; cbase += LSD_BS) {
+			const uint32_t e = cbase + tid;
+			uint32_t surv = 0;
+			float py = 0.0f, px0 = 0.0f;
+			if (e < T) {
+				const uint32_t wi = list[e];
+				surv = m.p[wi];
+				const uint32_t r = wi / m.pitch, c = wi - r * m.pitch;
+				py = (float)(m.wy0 + r);
+				px0 = (float)(int)((m.ww0 + c) * 32u - m.xoff);
+				for (uint32_t l = 0; l < n_lines && surv; ++l) {
+					const float x0 = sh.lines[l][0], y0 = sh.lines[l][1], x1 = sh.lines[l][2], y1 = sh.lines[l][3];
+					uint32_t s = surv;
+					while (s) {
+						const uint32_t bit = __builtin_ctz(s);
+						s &= s - 1u;
+						if (near_line(px0 + (float)bit, py, x0, y0, x1, y1)) surv &= ~(1u << bit);
+					}
+				}
+			}
+			while (true) {
+				// ---- first surviving white pixel in raster order ----
+				const uint64_t bal = __ballot(surv != 0u);
+				uint32_t key = 0xFFFFFFFFu;
+				if (bal) {
+					const uint32_t src = (uint32_t)__builtin_ctzll(bal);
+					const uint32_t mine = (tid << 5) | (surv ? (uint32_t)__builtin_ctz(surv) : 0u);
+					key = __shfl(mine, src);
+				}
+				if (lane == 0) sh.cand[wave] = key;
+				__syncthreads();
+				uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+				for (int k = 0; k < LSD_NW; ++k) first = min(first, sh.cand[k]);
+				if (first == 0xFFFFFFFFu) break;
+				const uint32_t otid = first >> 5, obit = first & 31u;
+				if (tid == otid) surv &= ~(1u << obit);
+				const uint32_t cwi = list[cbase + otid];
+				const uint32_t cr = cwi / m.pitch, cc = cwi - cr * m.pitch;
+				const float cy = (float)(m.wy0 + cr);
+				const float cx = (float)(int)((m.ww0 + cc) * 32u - m.xoff + obit);
+
+				float ptx, pty;
+				get_centre(m, cx, cy, ptx, pty);
+				const uint64_t gk = ray_round(m, sh, ptx, pty, max_gap, rdx, rdy, steps);
+				++rounds;
+				const float len = __uint_as_float((uint32_t)(gk >> 32));
+				if (len > SMH_LSD_ACCEPT_LEN_SQ) {
+					float ex, ey;
+					get_centre(m, sh.best[0], sh.best[1], ex, ey);
+					if (tid == 0) { sh.lines[n_lines][0] = ptx; sh.lines[n_lines][1] = pty; sh.lines[n_lines][2] = ex; sh.lines[n_lines][3] = ey; }
+					++n_lines;
+					if (n_lines == SMH_LSD_MAX_LINES) { done = true; break; }
+					uint32_t s = surv;
+					while (s) {
+						const uint32_t bit = __builtin_ctz(s);
+						s &= s - 1u;
+						if (near_line(px0 + (float)bit, py, ptx, pty, ex, ey)) surv &= ~(1u << bit);
+					}
+				}
+			}
+			__syncthreads();   // sh.cand is rewritten by the next chunk's first search
+		}
+		if (segnext >= WT) break;
+		seg_start = segnext;
+		__syncthreads();
+	}
+	atomicAdd(&sh.steps, (unsigned long long)steps);
+	__syncthreads();
+	if (tid < n_lines) {
+		res->lines[tid].x0 = sh.lines[tid][0]; res->lines[tid].y0 = sh.lines[tid][1];
+		res->lines[tid].x1 = sh.lines[tid][2]; res->lines[tid].y1 = sh.lines[tid][3];
+	}
+	if (tid == 0) { res->n_lines = n_lines; res->rounds = rounds; res->ray_steps = sh.steps; }
+}
+
+__global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	__shared__ LsdShared sh;
+	const uint32_t f = blockIdx.x;
+	const FrameAux aux = b.aux[f];
+	if (mode == 0) {
+		if (threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
+		if (!aux.open || aux.n_mask_px == 0) return;
+	}
+	bool lds = false;
+	if (aux.n_mask_px != 0) {
+		const uint32_t wrows = aux.y_max - aux.y_min + 1u, wwords = aux.w_max - aux.w_min + 1u;
+		lds = wrows * wwords <= LSD_WIN_WORDS_CAP;
+	}
+	if (mode == 1 && aux.n_mask_px == 0) {
+		// empty mask: window degenerates; use the global view (all zeros) for the single round
+		lsd_frame<false>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+		return;
+	}
+	if (lds) lsd_frame<true>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+	else lsd_frame<false>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scale_ratio: src/vision/mpx_ratio.rs.  One lane per OCR label anchor (<= 3), sequential scan as
+// in the reference.  Reads below the image count as non-zero (reference: unchecked read).
+// ------------------------------------------------------------------------------------------------
+__device__ bool find_scale_width(const uint8_t *img, size_t pitch, uint32_t w, uint32_t h, uint32_t meters, uint32_t x, uint32_t y, double *ratio,
+                                 uint32_t bar[3]) {
+	if (y < SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT || x >= w) return false;
+	// ((20.0 / 640.0) * w as f64).round(): 0.03125*w has at most 5 fractional bits, so t + 0.5 is exact
+	// and floor(t + 0.5) is round-half-away-from-zero for t >= 0
+	const double t = (20.0 / 640.0) * (double)w;
+	const uint32_t max_off = (uint32_t)floor(t + 0.5);
+	const uint32_t y_end = min(h, y + max_off);
+	for (uint32_t yy = y; yy < y_end; ++yy) {
+		if (img[(size_t)yy * pitch + x] != 0) continue;
+		uint32_t right = 0;
+		for (uint32_t xx = x; xx < w; ++xx) {
+			bool all0 = true;
+			for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty)
+				if (ty >= h || img[(size_t)ty * pitch + xx] != 0) { all0 = false; break; }
+			if (all0) { right = xx; break; }
+		}
+		if (right == 0) continue;
+		right -= 1;
+		uint32_t left = 0;
+		for (uint32_t xx = x; xx-- > 0;) {
+			bool all0 = true;
+			for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty)
+				if (ty >= h || img[(size_t)ty * pitch + xx] != 0) { all0 = false; break; }
+			if (all0) { left = xx; break; }
+		}
+		if (left == 0) continue;
+		left += 1;
+		const uint32_t width = right - left;   // wraps like release Rust (mpx_ratio.rs:58)
+		if (width < SMH_MIN_SCALE_WIDTH) continue;
+		bar[0] = left; bar[1] = yy; bar[2] = right;
+		*ratio = (double)meters / (double)width;
+		return true;
+	}
+	return false;
+}
+
+__global__ void __launch_bounds__(64) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) {
+	const uint32_t f = blockIdx.x, lane = threadIdx.x;
+	__shared__ double s_ratio[SMHV_MAX_SCALES];
+	__shared__ uint32_t s_ok[SMHV_MAX_SCALES];
+	smhv_frame_result *res = &b.results[f];
+	const bool open = b.aux[f].open != 0;
+	const smhv_anchors an = b.anchors[f];
+	const uint32_t n = open ? min(an.n, (uint32_t)SMHV_MAX_SCALES) : 0u;
+	const bool valid = an.scales_start_y <= g.qh;
+	if (lane < SMHV_MAX_SCALES) {
+		double r = 0.0;
+		uint32_t bar[3] = {0, 0, 0};
+		bool ok = false;
+		if (lane < n && valid) {
+			const uint8_t *img = b.scales + (size_t)f * g.ocr_stride + g.q_xoff;
+			ok = find_scale_width(img, g.ocr_pitch, g.qw, g.qh, an.scales[lane][0], an.scales[lane][1], an.scales[lane][2], &r, bar);
+		}
+		s_ratio[lane] = r; s_ok[lane] = ok ? 1u : 0u;
+		if (bars) {
+			uint32_t *o = bars + ((size_t)f * SMHV_MAX_SCALES + lane) * 4;
+			o[0] = bar[0]; o[1] = bar[1]; o[2] = bar[2]; o[3] = ok ? 1u : 0u;
+		}
+	}
+	__syncthreads();
+	if (lane == 0) {
+		// the "Rayon ladder" (mpx_ratio.rs:93-125): mean of the successes, summed in index order
+		double sum = 0.0; uint32_t k = 0;
+		for (uint32_t i = 0; i < SMHV_MAX_SCALES; ++i)
+			if (s_ok[i]) { sum = k ? sum + s_ratio[i] : s_ratio[i]; ++k; }
+		res->has_mpx = k ? 1u : 0u;
+		res->mpx = k == 0 ? 0.0 : (k == 1 ? sum : sum / (double)k);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finalize: per-frame record header + ui::Marker::new / angle (src/ui/mod.rs:131-140, markers.rs:98)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t stages) {
+	const uint32_t f = blockIdx.x, l = threadIdx.x;
+	smhv_frame_result *res = &b.results[f];
+	const FrameAux aux = b.aux[f];
+	const bool open = aux.open != 0;
+	const bool markers = (stages & SMHV_STAGE_MARKERS) != 0;
+	const uint32_t n = (open && markers) ? res->n_lines : 0u;
+	const bool has_mpx = open && (stages & SMHV_STAGE_SCALES) && res->has_mpx;
+	const double mpx = has_mpx ? res->mpx : 0.0;
+	if (l < SMHV_MAX_LINES) {
+		double len = 0.0, met = 0.0;
+		float ang = 0.0f;
+		smhv_line ln = {0.0f, 0.0f, 0.0f, 0.0f};
+		if (l < n) {
+			ln = res->lines[l];
+			const double ax = (double)ln.x0 - (double)ln.x1, ay = (double)ln.y0 - (double)ln.y1;
+			len = sqrt(ax * ax + ay * ay);
+			met = has_mpx ? len * mpx : 0.0;
+			ang = atan2f(ln.y0 - ln.y1, ln.x0 - ln.x1);
+		}
+		res->lines[l] = ln;
+		res->length_px[l] = len; res->meters[l] = met; res->angle[l] = ang;
+	}
+	if (l == 0) {
+		res->map_open = open ? 1u : 0u;
+		res->n_lines = n;
+		res->mpx = mpx; res->has_mpx = has_mpx ? 1u : 0u;
+		res->n_mask_px = (open && markers) ? aux.n_mask_px : 0u;
+		res->red_pixels = aux.red;
+		if (!(open && markers)) { res->rounds = 0; res->ray_steps = 0; }
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug views (vision-cpu/src/lib.rs:451-460) and the exhaustive colour table
+// ------------------------------------------------------------------------------------------------
+__global__ void k_debug_view(Geom g, Buffers b, uint32_t f, int which, int isolated, uint8_t *out) {
+	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
+	const uint32_t w = brq ? g.qw : g.rw, h = brq ? g.qh : g.rh;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= w * h) return;
+	const uint32_t y = i / w, x = i - y * w;
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes;
+	uint32_t o;
+	if (which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT) {
+		const uint8_t *img = (which == SMHV_VIEW_OCR_INPUT ? b.ocr : b.scales) + (size_t)f * g.ocr_stride + g.q_xoff;
+		o = (uint32_t)img[(size_t)y * g.ocr_pitch + x] * 0x00010101u | 0xFF000000u;
+	} else if (which == SMHV_VIEW_LSD_INPUT) {
+		o = (uint32_t)b.mask[(size_t)f * g.mask_stride + (size_t)y * g.mask_pitch + g.m_xoff + x] * 0x00010101u | 0xFF000000u;
+	} else {
+		const uint32_t fx = brq ? g.qx + x : g.rx + x, fy = brq ? g.qy + y : g.ry + y;
+		const uint32_t p = *(const uint32_t *)(fp + ((size_t)fy * g.W + fx) * 4);
+		uint32_t bb = p & 255u, gg = (p >> 8) & 255u, rr = (p >> 16) & 255u;
+		if (which == SMHV_VIEW_LSD_PREPROCESS && isolated && !is_marker(rr, gg, bb)) { rr = 0; gg = 0; bb = 0; }
+		o = rr | (gg << 8) | (bb << 16) | 0xFF000000u;
+	}
+	((uint32_t *)out)[i] = o;
+}
+
+__global__ void k_marker_table(uint32_t *bits) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= (1u << 24) / 32u) return;
+	uint32_t acc = 0;
+	for (uint32_t k = 0; k < 32; ++k) {
+		const uint32_t c = w * 32u + k;
+		if (is_marker((c >> 16) & 255u, (c >> 8) & 255u, c & 255u)) acc |= 1u << k;
+	}
+	bits[w] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s) {
+	hipLaunchKernelGGL(k_button, dim3(n), dim3(256), 0, s, g, b, force_open);
+	return hipGetLastError();
+}
+
+hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s) {
+	// Few frames: shorter bands so a single frame still spreads over the chip.
+	uint32_t RB = MAP_RB_MAX;
+	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
+	const dim3 grid((g.rh + RB - 1) / RB, n);
+	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
+	else hipLaunchKernelGGL(k_map_pass<false>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
+	return hipGetLastError();
+}
+
+hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s) {
+	const dim3 grid((g.qh + BRQ_RB - 1) / BRQ_RB, n);
+	hipLaunchKernelGGL(k_brq_pass, grid, dim3(g.q_block), 0, s, g, b, flags, fixed_start_y, use_anchor_start);
+	return hipGetLastError();
+}
+
+size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
+
+hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s) {
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute((const void *)k_lsd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSD_DYN_LDS_BYTES);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(k_lsd, dim3(n), dim3(LSD_BS), LSD_DYN_LDS_BYTES, s, g, b, max_gap, mode, px, py);
+	return hipGetLastError();
+}
+
+hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s) {
+	hipLaunchKernelGGL(k_scale_ratio, dim3(n), dim3(64), 0, s, g, b, d_bars);
+	return hipGetLastError();
+}
+
+hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s) {
+	hipLaunchKernelGGL(k_finalize, dim3(n), dim3(64), 0, s, g, b, stages);
+	return hipGetLastError();
+}
+
+hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s) {
+	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
+	const uint32_t npx = brq ? g.qw * g.qh : g.rw * g.rh;
+	hipLaunchKernelGGL(k_debug_view, dim3((npx + 255) / 256), dim3(256), 0, s, g, b, frame, which, isolated, d_rgba);
+	return hipGetLastError();
+}
+
+hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s) {
+	hipLaunchKernelGGL(k_marker_table, dim3(((1u << 24) / 32u + 255) / 256), dim3(256), 0, s, d_bits);
+	return hipGetLastError();
+}
+
+}  // namespace smh

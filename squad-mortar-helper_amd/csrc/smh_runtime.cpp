@@ -1,0 +1,663 @@
+// smh_runtime.cpp -- host runtime behind the C ABI of include/smh_vision_hip.h.
+//
+// Plays the role of the reference's Rust-CUDA host side (vision-gpu/src/{lib,cuda,gpuimage}.rs):
+// device context, per-frame-size buffer set (GpuMemory, vision-gpu/src/lib.rs:33-104), streams for
+// the two concurrent branches of VisionState::process (src/vision/mod.rs:219-223), pinned staging
+// for the images the host-side OCR / scale scan consume, and error reporting as status codes.
+// It is written directly on the HIP runtime API; there is no CPU fallback in this library: if the
+// device or the gfx950 code object is missing every entry point fails with an error code and the
+// caller does what the reference does on plugin failure (falls back to its own CPU back-end,
+// src/vision/hardware.rs:73-76).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "smh_consts.h"
+#include "smh_kernels.h"
+
+using namespace smh;
+
+// ------------------------------------------------------------------------------------------------
+// errors / logging
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string t_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	t_last_error = buf;
+	return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+	do {                                                                                                      \
+		hipError_t _e = (expr);                                                                               \
+		if (_e != hipSuccess) return fail(SMHV_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+	} while (0)
+
+extern "C" SMHV_API const char *smhv_last_error(void) { return t_last_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// geometry: vision-common/src/screen.rs + consts/mod.rs + vision-cpu/src/lib.rs:137-145
+// ------------------------------------------------------------------------------------------------
+static uint32_t screen_h(double frac, uint32_t H) {
+	// RelativeBound::ScreenH(h) => (h * screen_size[1] as f64).round() as u32   (screen.rs:58-65)
+	double r = std::round(frac * (double)H);
+	if (!(r > 0.0)) return 0u;
+	if (r >= 4294967296.0) return 0xFFFFFFFFu;
+	return (uint32_t)r;
+}
+
+extern "C" SMHV_API int smhv_map_bounds(uint32_t W, uint32_t H, uint32_t out[4]) {
+	if (!out) return fail(SMHV_E_INVALID, "null output");
+	const uint32_t w = screen_h(SMH_MAP_W, H), h = screen_h(SMH_MAP_H, H);
+	const uint32_t x = screen_h(SMH_MAP_X, H), yb = screen_h(SMH_MAP_Y_BOTTOM, H);
+	if ((uint64_t)yb + h > H || w > W) return fail(SMHV_E_GEOMETRY, "frame %ux%u: map bounds underflow", W, H);
+	const uint32_t y = H - yb - h;
+	const uint32_t w2 = W - w;          // "Map fills remaining space"
+	if ((uint64_t)x + w2 > W) return fail(SMHV_E_GEOMETRY, "frame %ux%u: map bounds underflow", W, H);
+	const uint32_t x2 = W - x - w2;
+	// par_crop_into panics when x + w >= width || y + h >= height (util/src/image.rs:71-77)
+	if ((uint64_t)x2 + w2 >= W || (uint64_t)y + h >= H || w2 < 8 || h < 8)
+		return fail(SMHV_E_GEOMETRY, "frame %ux%u: map crop (%u,%u,%u,%u) is outside the frame", W, H, x2, y, w2, h);
+	out[0] = x2; out[1] = y; out[2] = w2; out[3] = h;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_button_bounds(uint32_t W, uint32_t H, uint32_t out[4]) {
+	if (!out) return fail(SMHV_E_INVALID, "null output");
+	const uint32_t w = screen_h(SMH_BTN_W, H), h = screen_h(SMH_BTN_H, H);
+	const uint32_t xr = screen_h(SMH_BTN_X_RIGHT, H), yb = screen_h(SMH_BTN_Y_BOTTOM, H);
+	if ((uint64_t)xr + w > W || (uint64_t)yb + h > H || w == 0 || h == 0)
+		return fail(SMHV_E_GEOMETRY, "frame %ux%u: button bounds underflow", W, H);
+	out[0] = W - xr - w; out[1] = H - yb - h; out[2] = w; out[3] = h;
+	return SMHV_OK;
+}
+
+static int compute_geom(uint32_t W, uint32_t H, Geom *g) {
+	uint32_t m[4], bt[4];
+	int rc = smhv_map_bounds(W, H, m);
+	if (rc) return rc;
+	rc = smhv_button_bounds(W, H, bt);
+	if (rc) return rc;
+	memset(g, 0, sizeof *g);
+	g->W = W; g->H = H;
+	g->rx = m[0]; g->ry = m[1]; g->rw = m[2]; g->rh = m[3];
+	g->bx = bt[0]; g->by = bt[1]; g->bw = bt[2]; g->bh = bt[3];
+	g->qw = g->rw / 2; g->qh = g->rh / 2;            // brq = bottom right quadrant (lib.rs:143-145)
+	g->qx = g->rx + g->qw; g->qy = g->ry + g->qh;
+	if (g->qw < SMH_OCR_DILATE_RADIUS || g->qh < SMH_OCR_DILATE_RADIUS) return fail(SMHV_E_GEOMETRY, "frame %ux%u too small", W, H);
+	g->m_ax = g->rx & ~3u; g->m_xoff = g->rx - g->m_ax;
+	g->m_quads = (g->rw + g->m_xoff + 3u) / 4u;
+	g->m_block = (g->m_quads + 63u) & ~63u;
+	g->q_ax = g->qx & ~3u; g->q_xoff = g->qx - g->q_ax;
+	g->q_quads = (g->qw + g->q_xoff + 3u) / 4u;
+	g->q_block = (g->q_quads + 63u) & ~63u;
+	if (g->m_block > 1024u) return fail(SMHV_E_GEOMETRY, "frame %ux%u: map ROI wider than 4096 px is not supported", W, H);
+	const uint32_t mq = (g->m_quads + 15u) & ~15u, qq = (g->q_quads + 15u) & ~15u;
+	g->frame_bytes = (uint64_t)W * H * 4;
+	g->ui_pitch = (uint64_t)mq * 16; g->ui_stride = g->ui_pitch * g->rh;
+	g->mask_pitch = (uint64_t)mq * 4; g->mask_stride = g->mask_pitch * g->rh;
+	g->bits_pitch_w = mq / 8; g->bits_stride_w = (uint64_t)g->bits_pitch_w * g->rh;
+	g->ocr_pitch = (uint64_t)qq * 4; g->ocr_stride = g->ocr_pitch * g->qh;
+	return SMHV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------------------------------------
+struct smhv_batch {
+	smhv_ctx *ctx = nullptr;
+	Geom g{};
+	uint32_t max_frames = 0;
+	uint8_t *d_ui = nullptr, *d_mask = nullptr, *d_ocr = nullptr, *d_scales = nullptr;
+	uint32_t *d_bits = nullptr, *d_bars = nullptr;
+	FrameAux *d_aux = nullptr;
+	smhv_frame_result *d_results = nullptr;   // max_frames (+2 spare records for the per-frame trait path)
+	smhv_anchors *d_anchors = nullptr;
+	bool timing = false, timed_run = false;
+	hipEvent_t ev[6] = {};
+	bool ev_ok = false;
+};
+
+struct smhv_ctx {
+	int device = 0;
+	smhv_log_fn log = nullptr;
+	hipStream_t s_main = nullptr, s_markers = nullptr, s_scales = nullptr;
+	// current frame (per-call trait path); ~ GpuMemory
+	uint32_t W = 0, H = 0;
+	bool have_frame = false;
+	uint8_t *d_frame = nullptr;        // owned copy of the uploaded frame
+	size_t d_frame_cap = 0;
+	const uint8_t *frame_ptr = nullptr; // d_frame or the caller's device pointer
+	smhv_batch *fb = nullptr;          // single-frame buffer set
+	// pinned staging
+	uint8_t *h_ocr = nullptr, *h_scales = nullptr;
+	smhv_frame_result *h_res = nullptr;
+	FrameAux *h_aux = nullptr;
+	uint32_t *h_bars = nullptr;
+	// per-frame state
+	bool cropped = false, map_open = false, isolated = false, mask_valid = false, scales_valid = false;
+	std::mutex mu;                      // serialises (re)allocation only
+};
+
+static void logf(smhv_ctx *c, int lvl, const char *fmt, ...) {
+	if (!c || !c->log) return;
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	c->log(lvl, buf);
+}
+
+static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
+	Buffers bf;
+	bf.frames = frames;
+	bf.ui = b->d_ui; bf.mask = b->d_mask; bf.ocr = b->d_ocr; bf.scales = b->d_scales;
+	bf.bits = b->d_bits; bf.aux = b->d_aux;
+	bf.results = b->d_results + result_slot;
+	bf.anchors = b->d_anchors;
+	return bf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out) {
+	if (!out) return fail(SMHV_E_INVALID, "null output");
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) return fail(SMHV_E_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+	if (device < 0 || device >= count) return fail(SMHV_E_NO_DEVICE, "device %d out of range (%d devices)", device, count);
+	HIPCHK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(SMHV_E_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+	smhv_ctx *c = new (std::nothrow) smhv_ctx();
+	if (!c) return fail(SMHV_E_INVALID, "out of host memory");
+	c->device = device; c->log = log;
+	HIPCHK(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&c->s_markers, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&c->s_scales, hipStreamNonBlocking));
+	HIPCHK(hipHostMalloc((void **)&c->h_res, sizeof(smhv_frame_result) * 4));
+	HIPCHK(hipHostMalloc((void **)&c->h_aux, sizeof(FrameAux)));
+	HIPCHK(hipHostMalloc((void **)&c->h_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4));
+	logf(c, 3, "smh_vision_hip ready on device %d (%s, %d CUs)", device, prop.gcnArchName, prop.multiProcessorCount);
+	*out = c;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize();
+	if (c->fb) { smhv_batch_destroy(c->fb); c->fb = nullptr; }
+	if (c->d_frame) (void)hipFree(c->d_frame);
+	if (c->h_ocr) (void)hipHostFree(c->h_ocr);
+	if (c->h_scales) (void)hipHostFree(c->h_scales);
+	if (c->h_res) (void)hipHostFree(c->h_res);
+	if (c->h_aux) (void)hipHostFree(c->h_aux);
+	if (c->h_bars) (void)hipHostFree(c->h_bars);
+	if (c->s_main) (void)hipStreamDestroy(c->s_main);
+	if (c->s_markers) (void)hipStreamDestroy(c->s_markers);
+	if (c->s_scales) (void)hipStreamDestroy(c->s_scales);
+	logf(c, 3, "smh_vision_hip shut down");
+	delete c;
+}
+
+extern "C" SMHV_API int smhv_thread_ctx(smhv_ctx *c) {
+	if (!c) return fail(SMHV_E_INVALID, "null context");
+	HIPCHK(hipSetDevice(c->device));
+	return SMHV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch objects
+// ------------------------------------------------------------------------------------------------
+extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, smhv_batch **out) {
+	if (!c || !out || max_frames == 0) return fail(SMHV_E_INVALID, "bad arguments");
+	*out = nullptr;
+	Geom g;
+	int rc = compute_geom(W, H, &g);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = new (std::nothrow) smhv_batch();
+	if (!b) return fail(SMHV_E_INVALID, "out of host memory");
+	b->ctx = c; b->g = g; b->max_frames = max_frames;
+	const size_t n = max_frames;
+#define ALLOC0(ptr, bytes)                                          \
+	do {                                                            \
+		hipError_t _e = hipMalloc((void **)&(ptr), (bytes));        \
+		if (_e == hipSuccess) _e = hipMemset((ptr), 0, (bytes));    \
+		if (_e != hipSuccess) { smhv_batch_destroy(b); return fail(SMHV_E_HIP, "allocating %zu bytes: %s", (size_t)(bytes), hipGetErrorString(_e)); } \
+	} while (0)
+	ALLOC0(b->d_ui, g.ui_stride * n);
+	ALLOC0(b->d_mask, g.mask_stride * n);
+	ALLOC0(b->d_bits, g.bits_stride_w * 4 * n);
+	ALLOC0(b->d_ocr, g.ocr_stride * n);
+	ALLOC0(b->d_scales, g.ocr_stride * n);      // zero-initialised like GrayImage::new (lib.rs:86)
+	ALLOC0(b->d_aux, sizeof(FrameAux) * n);
+	ALLOC0(b->d_results, sizeof(smhv_frame_result) * (n + 2));
+	ALLOC0(b->d_anchors, sizeof(smhv_anchors) * n);
+	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
+#undef ALLOC0
+	*out = b;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
+	if (!b) return;
+	if (b->ctx) (void)hipSetDevice(b->ctx->device);
+	(void)hipDeviceSynchronize();
+	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars};
+	for (void *p : ptrs)
+		if (p) (void)hipFree(p);
+	if (b->ev_ok)
+		for (auto &e : b->ev) (void)hipEventDestroy(e);
+	delete b;
+}
+
+extern "C" SMHV_API int smhv_batch_layout_get(smhv_batch *b, smhv_batch_layout *o) {
+	if (!b || !o) return fail(SMHV_E_INVALID, "bad arguments");
+	const Geom &g = b->g;
+	memset(o, 0, sizeof *o);
+	o->frame_w = g.W; o->frame_h = g.H;
+	o->roi[0] = g.rx; o->roi[1] = g.ry; o->roi[2] = g.rw; o->roi[3] = g.rh;
+	o->button[0] = g.bx; o->button[1] = g.by; o->button[2] = g.bw; o->button[3] = g.bh;
+	o->brq_w = g.qw; o->brq_h = g.qh;
+	o->ui_pitch = g.ui_pitch; o->ui_stride = g.ui_stride; o->ui_offset = (uint64_t)g.m_xoff * 4;
+	o->mask_pitch = g.mask_pitch; o->mask_stride = g.mask_stride; o->mask_offset = g.m_xoff;
+	o->ocr_pitch = g.ocr_pitch; o->ocr_stride = g.ocr_stride; o->ocr_offset = g.q_xoff;
+	o->scales_pitch = g.ocr_pitch; o->scales_stride = g.ocr_stride; o->scales_offset = g.q_xoff;
+	o->bits_pitch_words = g.bits_pitch_w; o->bits_stride = g.bits_stride_w * 4; o->bits_xoff = g.m_xoff;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
+	if (!b) return fail(SMHV_E_INVALID, "null batch");
+	if (enable && !b->ev_ok) {
+		HIPCHK(hipSetDevice(b->ctx->device));
+		for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
+		b->ev_ok = true;
+	}
+	b->timing = enable != 0;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                                       const smhv_anchors *anchors, void *stream) {
+	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
+	if ((stages & SMHV_STAGE_ALL) == 0) return fail(SMHV_E_INVALID, "no stage selected");
+	hipStream_t s = (hipStream_t)stream;
+	const Geom &g = b->g;
+	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
+	const bool scales = (stages & SMHV_STAGE_SCALES) && anchors;
+	if (scales) HIPCHK(hipMemcpyAsync(b->d_anchors, anchors, sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, s));
+	const bool t = b->timing;
+	b->timed_run = t;
+	if (t) HIPCHK(hipEventRecord(b->ev[0], s));
+	HIPCHK(launch_button(g, bf, n, 0, s));
+	if (t) HIPCHK(hipEventRecord(b->ev[1], s));
+	uint32_t mflags = 0;
+	if (stages & SMHV_STAGE_MARKERS) mflags |= MAP_MASK;
+	if (stages & SMHV_STAGE_UI_MAP) mflags |= MAP_UI;
+	if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
+	if (t) HIPCHK(hipEventRecord(b->ev[2], s));
+	uint32_t qflags = 0;
+	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
+	if (scales) qflags |= BRQ_SCALES;
+	if (qflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
+	if (t) HIPCHK(hipEventRecord(b->ev[3], s));
+	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, s));
+	if (t) HIPCHK(hipEventRecord(b->ev[4], s));
+	if (scales) HIPCHK(launch_scale_ratio(g, bf, n, b->d_bars, s));
+	HIPCHK(launch_finalize(g, bf, n, scales ? stages : (stages & ~SMHV_STAGE_SCALES), s));
+	if (t) HIPCHK(hipEventRecord(b->ev[5], s));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]) {
+	if (!b || !ms) return fail(SMHV_E_INVALID, "bad arguments");
+	if (!b->timed_run) return fail(SMHV_E_STATE, "the last smhv_batch_run was not timed");
+	HIPCHK(hipEventSynchronize(b->ev[5]));
+	for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_device_ptrs(smhv_batch *b, void **r, void **ui, void **mask, void **ocr, void **scales, void **bits) {
+	if (!b) return fail(SMHV_E_INVALID, "null batch");
+	if (r) *r = b->d_results;
+	if (ui) *ui = b->d_ui;
+	if (mask) *mask = b->d_mask;
+	if (ocr) *ocr = b->d_ocr;
+	if (scales) *scales = b->d_scales;
+	if (bits) *bits = b->d_bits;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, uint32_t n, smhv_frame_result *out) {
+	if (!b || !out || first + n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+	HIPCHK(hipSetDevice(b->ctx->device));
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(out, b->d_results + first, sizeof(smhv_frame_result) * n, hipMemcpyDeviceToHost));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t frame, uint8_t *out) {
+	if (!b || !out || frame >= b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+	const Geom &g = b->g;
+	HIPCHK(hipSetDevice(b->ctx->device));
+	HIPCHK(hipDeviceSynchronize());
+	switch (which) {
+	case 100:
+		HIPCHK(hipMemcpy2D(out, (size_t)g.rw * 4, b->d_ui + frame * g.ui_stride + (size_t)g.m_xoff * 4, g.ui_pitch, (size_t)g.rw * 4, g.rh, hipMemcpyDeviceToHost));
+		break;
+	case SMHV_VIEW_LSD_INPUT:
+		HIPCHK(hipMemcpy2D(out, g.rw, b->d_mask + frame * g.mask_stride + g.m_xoff, g.mask_pitch, g.rw, g.rh, hipMemcpyDeviceToHost));
+		break;
+	case SMHV_VIEW_OCR_INPUT:
+		HIPCHK(hipMemcpy2D(out, g.qw, b->d_ocr + frame * g.ocr_stride + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost));
+		break;
+	case SMHV_VIEW_FIND_SCALES_INPUT:
+		HIPCHK(hipMemcpy2D(out, g.qw, b->d_scales + frame * g.ocr_stride + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost));
+		break;
+	default:
+		return fail(SMHV_E_INVALID, "unsupported image id %d", which);
+	}
+	return SMHV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-frame trait surface
+// ------------------------------------------------------------------------------------------------
+static int ensure_frame_buffers(smhv_ctx *c, uint32_t w, uint32_t h) {
+	if (c->fb && c->W == w && c->H == h) return SMHV_OK;
+	// dimensions changed: (re)allocate, like GpuMemory::update (vision-gpu/src/lib.rs:106-138)
+	std::lock_guard<std::mutex> lk(c->mu);
+	Geom g;
+	int rc = compute_geom(w, h, &g);
+	if (rc) return rc;
+	HIPCHK(hipDeviceSynchronize());
+	if (c->fb) { smhv_batch_destroy(c->fb); c->fb = nullptr; }
+	if (c->h_ocr) { (void)hipHostFree(c->h_ocr); c->h_ocr = nullptr; }
+	if (c->h_scales) { (void)hipHostFree(c->h_scales); c->h_scales = nullptr; }
+	rc = smhv_batch_create(c, w, h, 1, &c->fb);
+	if (rc) return rc;
+	HIPCHK(hipHostMalloc((void **)&c->h_ocr, (size_t)g.qw * g.qh));
+	HIPCHK(hipHostMalloc((void **)&c->h_scales, (size_t)g.qw * g.qh));
+	memset(c->h_scales, 0, (size_t)g.qw * g.qh);
+	memset(c->h_ocr, 0, (size_t)g.qw * g.qh);
+	c->W = w; c->H = h;
+	logf(c, 3, "allocated buffers for %ux%u frames (map ROI %u,%u %ux%u)", w, h, g.rx, g.ry, g.rw, g.rh);
+	return SMHV_OK;
+}
+
+static void reset_frame_state(smhv_ctx *c) {
+	c->have_frame = true; c->cropped = false; c->map_open = false; c->isolated = false; c->mask_valid = false;
+}
+
+extern "C" SMHV_API int smhv_load_frame(smhv_ctx *c, const uint8_t *bgra, uint32_t w, uint32_t h) {
+	if (!c || !bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = ensure_frame_buffers(c, w, h);
+	if (rc) return rc;
+	const size_t bytes = (size_t)w * h * 4;
+	if (c->d_frame_cap < bytes) {
+		HIPCHK(hipDeviceSynchronize());
+		if (c->d_frame) (void)hipFree(c->d_frame);
+		c->d_frame = nullptr; c->d_frame_cap = 0;
+		HIPCHK(hipMalloc((void **)&c->d_frame, bytes));
+		c->d_frame_cap = bytes;
+	}
+	// Only the rows the pipeline reads are uploaded: the map ROI rows and the button rows below
+	// them (the reference uploads the whole frame although 61 % of it is never inspected).
+	const Geom &g = c->fb->g;
+	const uint32_t y0 = g.ry < g.by ? g.ry : g.by;
+	const uint32_t y1 = (g.ry + g.rh > g.by + g.bh) ? g.ry + g.rh : g.by + g.bh;
+	const size_t off = (size_t)y0 * w * 4, len = (size_t)(y1 - y0) * w * 4;
+	HIPCHK(hipMemcpyAsync(c->d_frame + off, bgra + off, len, hipMemcpyHostToDevice, c->s_main));
+	HIPCHK(hipStreamSynchronize(c->s_main));
+	c->frame_ptr = c->d_frame;
+	reset_frame_state(c);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_load_frame_device(smhv_ctx *c, const void *d_bgra, uint32_t w, uint32_t h) {
+	if (!c || !d_bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = ensure_frame_buffers(c, w, h);
+	if (rc) return rc;
+	c->frame_ptr = (const uint8_t *)d_bgra;
+	reset_frame_state(c);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_crop_to_map(smhv_ctx *c, int grayscale, int *map_open, uint32_t roi[4], uint8_t *ui_rgba) {
+	if (!c || !map_open) return fail(SMHV_E_INVALID, "bad arguments");
+	if (!c->have_frame) return fail(SMHV_E_INVALID, "crop_to_map called before load_frame");
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	const Geom &g = b->g;
+	Buffers bf = make_buffers(b, c->frame_ptr, 0);
+	hipStream_t s = c->s_main;
+	HIPCHK(launch_button(g, bf, 1, 0, s));
+	HIPCHK(hipMemcpyAsync(c->h_aux, b->d_aux, sizeof(FrameAux), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	c->cropped = true; c->isolated = false; c->mask_valid = false;
+	c->map_open = c->h_aux->open != 0;
+	*map_open = c->map_open ? 1 : 0;
+	if (!c->map_open) return SMHV_OK;          // Ok(None)
+	if (roi) { roi[0] = g.rx; roi[1] = g.ry; roi[2] = g.rw; roi[3] = g.rh; }
+	// One pass over the ROI produces ui_map and, speculatively, the marker mask (the reference's
+	// cropped_map / isolate / mask sequence re-reads the crop three times); mask_marker_lines then
+	// only has to publish it.
+	HIPCHK(launch_map_pass(g, bf, 1, MAP_UI | MAP_MASK, grayscale, s));
+	c->mask_valid = true;
+	if (ui_rgba)
+		HIPCHK(hipMemcpy2DAsync(ui_rgba, (size_t)g.rw * 4, b->d_ui + (size_t)g.m_xoff * 4, g.ui_pitch, (size_t)g.rw * 4, g.rh, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_red_pixels(smhv_ctx *c, uint32_t *count) {
+	if (!c || !count) return fail(SMHV_E_INVALID, "bad arguments");
+	if (!c->cropped) return fail(SMHV_E_STATE, "crop_to_map has not run for this frame");
+	*count = c->h_aux->red;
+	return SMHV_OK;
+}
+
+static int require_open(smhv_ctx *c, const char *what) {
+	if (!c) return fail(SMHV_E_INVALID, "null context");
+	if (!c->have_frame || !c->cropped) return fail(SMHV_E_INVALID, "%s called before load_frame/crop_to_map", what);
+	if (!c->map_open) return fail(SMHV_E_STATE, "%s: the map is closed for this frame (crop_to_map returned None)", what);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_ocr_preprocess(smhv_ctx *c, const uint8_t **out, size_t *len) {
+	int rc = require_open(c, "ocr_preprocess");
+	if (rc) return rc;
+	if (!out || !len) return fail(SMHV_E_INVALID, "null output");
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	const Geom &g = b->g;
+	Buffers bf = make_buffers(b, c->frame_ptr, 1);
+	hipStream_t s = c->s_scales;
+	HIPCHK(launch_brq_pass(g, bf, 1, BRQ_OCR, 0, 0, s));
+	HIPCHK(hipMemcpy2DAsync(c->h_ocr, g.qw, b->d_ocr + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	*out = c->h_ocr; *len = (size_t)g.qw * g.qh;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_find_scales_preprocess(smhv_ctx *c, uint32_t scales_start_y, const uint8_t **out, uint32_t *w, uint32_t *h) {
+	int rc = require_open(c, "find_scales_preprocess");
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	const Geom &g = b->g;
+	if (scales_start_y > g.qh) return fail(SMHV_E_INVALID, "scales_start_y %u is below the %u-row quadrant", scales_start_y, g.qh);
+	Buffers bf = make_buffers(b, c->frame_ptr, 1);
+	hipStream_t s = c->s_scales;
+	HIPCHK(launch_brq_pass(g, bf, 1, BRQ_SCALES, scales_start_y, 0, s));
+	HIPCHK(hipMemcpy2DAsync(c->h_scales, g.qw, b->d_scales + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	c->scales_valid = true;
+	if (out) *out = c->h_scales;
+	if (w) *w = g.qw;
+	if (h) *h = g.qh;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_isolate_map_markers(smhv_ctx *c) {
+	int rc = require_open(c, "isolate_map_markers");
+	if (rc) return rc;
+	// The isolated crop is only observable through DebugView::LSDPreprocess; it is materialised
+	// there on demand.  The marker predicate is idempotent under isolation, so the mask is the same.
+	c->isolated = true;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_mask_marker_lines(smhv_ctx *c) {
+	int rc = require_open(c, "mask_marker_lines");
+	if (rc) return rc;
+	if (c->mask_valid) return SMHV_OK;
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	Buffers bf = make_buffers(b, c->frame_ptr, 0);
+	HIPCHK(launch_map_pass(b->g, bf, 1, MAP_MASK, 1, c->s_markers));
+	HIPCHK(hipStreamSynchronize(c->s_markers));
+	c->mask_valid = true;
+	return SMHV_OK;
+}
+
+static int require_mask(smhv_ctx *c, const char *what) {
+	int rc = require_open(c, what);
+	if (rc) return rc;
+	if (!c->mask_valid) return fail(SMHV_E_INVALID, "%s called before mask_marker_lines", what);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_get_lsd_image(smhv_ctx *c, uint8_t *out, uint32_t *w, uint32_t *h) {
+	int rc = require_mask(c, "get_lsd_image");
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(c->device));
+	const Geom &g = c->fb->g;
+	if (w) *w = g.rw;
+	if (h) *h = g.rh;
+	if (out) {
+		HIPCHK(hipMemcpy2DAsync(out, g.rw, c->fb->d_mask + g.m_xoff, g.mask_pitch, g.rw, g.rh, hipMemcpyDeviceToHost, c->s_markers));
+		HIPCHK(hipStreamSynchronize(c->s_markers));
+	}
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_find_longest_line(smhv_ctx *c, float px, float py, float max_gap, smhv_line *line, float *len_sq) {
+	int rc = require_mask(c, "find_longest_line");
+	if (rc) return rc;
+	if (!line || !len_sq) return fail(SMHV_E_INVALID, "null output");
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	Buffers bf = make_buffers(b, c->frame_ptr, 2);
+	hipStream_t s = c->s_markers;
+	HIPCHK(launch_lsd(b->g, bf, 1, max_gap, 1, px, py, s));
+	HIPCHK(hipMemcpyAsync(&c->h_res[2], b->d_results + 2, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	*line = c->h_res[2].lines[0];
+	*len_sq = (float)c->h_res[2].length_px[0];
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_find_marker_lines(smhv_ctx *c, uint32_t max_gap, smhv_line out[SMHV_MAX_LINES], uint32_t *n) {
+	int rc = require_mask(c, "find_marker_lines");
+	if (rc) return rc;
+	if (!out || !n) return fail(SMHV_E_INVALID, "null output");
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	Buffers bf = make_buffers(b, c->frame_ptr, 0);
+	hipStream_t s = c->s_markers;
+	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s));
+	HIPCHK(launch_finalize(b->g, bf, 1, SMHV_STAGE_MARKERS, s));
+	HIPCHK(hipMemcpyAsync(&c->h_res[0], b->d_results, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	*n = c->h_res[0].n_lines;
+	memcpy(out, c->h_res[0].lines, sizeof(smhv_line) * SMHV_MAX_LINES);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *c, const uint32_t *scales, uint32_t n, double *ratio, int *has, uint32_t *bars) {
+	int rc = require_open(c, "calc_meters_to_px_ratio");
+	if (rc) return rc;
+	if (!ratio || !has || (n && !scales)) return fail(SMHV_E_INVALID, "null argument");
+	if (n > SMHV_MAX_SCALES) return fail(SMHV_E_INVALID, "at most %d scales", SMHV_MAX_SCALES);
+	if (!c->scales_valid) return fail(SMHV_E_INVALID, "calc_meters_to_px_ratio called before find_scales_preprocess");
+	*has = 0; *ratio = 0.0;
+	if (n == 0) return SMHV_OK;                 // scales.is_empty() => None (mpx_ratio.rs:80-82)
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	smhv_anchors an;
+	memset(&an, 0, sizeof an);
+	an.n = n; an.scales_start_y = 0;
+	memcpy(an.scales, scales, sizeof(uint32_t) * 3 * n);
+	Buffers bf = make_buffers(b, c->frame_ptr, 1);
+	hipStream_t s = c->s_scales;
+	HIPCHK(hipMemcpyAsync(b->d_anchors, &an, sizeof an, hipMemcpyHostToDevice, s));
+	HIPCHK(hipStreamSynchronize(s));            // `an` is a stack object
+	HIPCHK(launch_scale_ratio(b->g, bf, 1, b->d_bars, s));
+	HIPCHK(hipMemcpyAsync(&c->h_res[1], b->d_results + 1, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(c->h_bars, b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	*has = c->h_res[1].has_mpx ? 1 : 0;
+	*ratio = c->h_res[1].mpx;
+	if (bars) memcpy(bars, c->h_bars, sizeof(uint32_t) * 4 * n);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_get_debug_view(smhv_ctx *c, int which, uint8_t *rgba, uint32_t *w, uint32_t *h) {
+	if (!c) return fail(SMHV_E_INVALID, "null context");
+	if (which == SMHV_VIEW_NONE) { if (w) *w = 0; if (h) *h = 0; return SMHV_OK; }
+	if (which < 0 || which > SMHV_VIEW_CROPPED_BRQ) return fail(SMHV_E_INVALID, "unknown debug view %d", which);
+	if (!c->have_frame || !c->fb) return fail(SMHV_E_INVALID, "get_debug_view called before load_frame");
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	const Geom &g = b->g;
+	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
+	const uint32_t vw = brq ? g.qw : g.rw, vh = brq ? g.qh : g.rh;
+	if (w) *w = vw;
+	if (h) *h = vh;
+	if (!rgba) return SMHV_OK;
+	uint8_t *d_tmp = nullptr;
+	HIPCHK(hipMalloc((void **)&d_tmp, (size_t)vw * vh * 4));
+	Buffers bf = make_buffers(b, c->frame_ptr, 0);
+	hipError_t e = launch_debug_view(g, bf, 0, which, c->isolated ? 1 : 0, d_tmp, c->s_main);
+	if (e == hipSuccess) e = hipMemcpyAsync(rgba, d_tmp, (size_t)vw * vh * 4, hipMemcpyDeviceToHost, c->s_main);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->s_main);
+	(void)hipFree(d_tmp);
+	if (e != hipSuccess) return fail(SMHV_E_HIP, "debug view: %s", hipGetErrorString(e));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_debug_marker_table(smhv_ctx *c, uint32_t *bits) {
+	if (!c || !bits) return fail(SMHV_E_INVALID, "bad arguments");
+	HIPCHK(hipSetDevice(c->device));
+	uint32_t *d = nullptr;
+	const size_t bytes = ((size_t)1 << 24) / 8;
+	HIPCHK(hipMalloc((void **)&d, bytes));
+	hipError_t e = launch_marker_table(d, c->s_main);
+	if (e == hipSuccess) e = hipMemcpyAsync(bits, d, bytes, hipMemcpyDeviceToHost, c->s_main);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->s_main);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(SMHV_E_HIP, "marker table: %s", hipGetErrorString(e));
+	return SMHV_OK;
+}

@@ -1,0 +1,51 @@
+"""Multi-GPU: frames are independent, so a batch is block-sharded over ranks (one process per GPU)
+with no data-path collective; the only exchange is a gather of the fixed-size per-frame result
+records to rank 0 (RCCL over xGMI when the backend is "nccl"; gloo on CPU for tests).
+
+Nothing like this exists in the reference (device 0 only, vision-gpu/src/cuda.rs:34); see DESIGN.md.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+RECORD_BYTES = C.sizeof(L.FrameResult)
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block shard: rank r owns frames [r*n/world, (r+1)*n/world)."""
+    lo = (n_total * rank) // world
+    hi = (n_total * (rank + 1)) // world
+    return lo, hi
+
+
+def gather_records(local_records, dist, device=None, dst=0):
+    """local_records: uint8 torch tensor [n_local * RECORD_BYTES] (on `device` for nccl).
+    Returns on dst a list of per-rank uint8 tensors, elsewhere None.  Shards may differ by one
+    frame, so sizes are exchanged first and the payload is padded to the maximum."""
+    import torch
+
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    n = torch.tensor([local_records.numel()], dtype=torch.int64, device=local_records.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    padded = torch.zeros(mx, dtype=torch.uint8, device=local_records.device)
+    padded[:local_records.numel()] = local_records
+    bufs = [torch.zeros(mx, dtype=torch.uint8, device=local_records.device) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+def records_from_bytes(buf):
+    """uint8 numpy array -> ctypes array of FrameResult."""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    n = buf.size // RECORD_BYTES
+    arr = (L.FrameResult * n)()
+    C.memmove(arr, buf.ctypes.data, n * RECORD_BYTES)
+    return arr
