@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- map frames/s through the full CV pipeline on N MI355X GPUs (one process per GPU).
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a batch of
+1920x1080 synthetic map frames RESIDENT IN HBM per GPU, full pipeline per step: close-deployment
+button test, ui_map, marker threshold + dilation, ocr_preprocess, find_scales_preprocess + m/px,
+ray-cast line-segment detection, derived marker lengths/angles; with N > 1 the per-frame result
+records are gathered to rank 0 over RCCL inside the timed step.  Frames are independent, so the
+batch is block-sharded over ranks (weak scaling: --frames-per-gpu is fixed as N grows).
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
+  roofline     -- the dominant HBM streaming kernel (k_map_pass): algorithmic bytes / hipEvent time
+  stages_ms    -- average per-stage device time over the timed steps (hipEvents on the run's stream)
+  lsd          -- workload statistics of the (non-HBM-bound) ray-cast stage
+  cpu_baseline -- the C oracle (a port of the reference's vision-cpu; the Rust original cannot be
+                  built here) timed on this box's host cores on a bounded sample of the same frames
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes(roi_w, roi_h, btn_w, btn_h):
+    """each input ROI pixel read once as BGRA, each API-visible output written once."""
+    qw, qh = roi_w // 2, roi_h // 2
+    map_pass = roi_w * roi_h * 4 + roi_w * roi_h * 4 + roi_w * roi_h          # read BGRA, write ui RGBA, write u8 mask
+    full = btn_w * btn_h * 4 + map_pass + 2 * qw * qh + 516                    # + button, ocr_out, scales, <=32 lines
+    return map_pass, full
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=256)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
+    ap.add_argument("--stages", type=lambda s: int(s, 0), default=0xF)
+    ap.add_argument("--cpu-sample", type=int, default=64, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import dist as sdist
+    from squad_mortar_helper_amd import synth
+
+    W, H, n = args.width, args.height, args.frames_per_gpu
+    first = rank * n                                   # block shard of the global batch
+    frames_host = torch.empty((n, H, W, 4), dtype=torch.uint8, pin_memory=True)
+    _, infos = synth.make_batch(W, H, n, first_idx=first, n_lines=args.lines, out=frames_host.numpy())
+    t0 = time.perf_counter()
+    frames = frames_host.cuda(non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_s = time.perf_counter() - t0
+
+    vision = smh.HipVision.init(local_rank)
+    fb = smh.FrameBatch(vision, W, H, n)
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+    ptrs = fb.device_ptrs()
+
+    class _Rec:   # torch view over the library's device result records (for the RCCL gather)
+        __cuda_array_interface__ = {"shape": (n * sdist.RECORD_BYTES,), "typestr": "|u1", "data": (ptrs["results"], False), "version": 2}
+    rec_tensor = torch.as_tensor(_Rec(), device="cuda")
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        fb.run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=stream)
+        if world > 1:
+            return sdist.gather_records(rec_tensor, dist, sizes=[n * sdist.RECORD_BYTES] * world)
+        return None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_stage_timing:
+        fb.enable_timing(True)
+    t0 = time.perf_counter()
+    gathered = None
+    for _ in range(args.steps):
+        gathered = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages_ms = fb.stage_ms() if not args.no_stage_timing else None
+    fb.enable_timing(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- result sanity + workload statistics (outside the timed region) ----
+    recs = smh.results_to_dicts(fb.read_results(0, n))
+    rounds = float(np.mean([r["rounds"] for r in recs]))
+    ray_steps = float(np.mean([r["ray_steps"] for r in recs]))
+    n_lines = float(np.mean([r["n_lines"] for r in recs]))
+    all_open = all(r["map_open"] for r in recs)
+    if world > 1 and rank == 0:
+        total = sum(g.numel() for g in gathered) // sdist.RECORD_BYTES
+        assert total == n * world, "gather returned %d records, expected %d" % (total, n * world)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    x, y, rw, rh = fb.roi
+    bw, bh = fb.layout.button[2], fb.layout.button[3]
+    map_bytes, full_bytes = algorithmic_bytes(rw, rh, bw, bh)
+    total_frames = n * world * args.steps
+    value = total_frames / dt
+    out = {
+        "metric": "map frames/sec (1080p full CV pipeline)" if (W, H) == (1920, 1080) else "map frames/sec (%dx%d full CV pipeline)" % (W, H),
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %d x %dx%d BGRA frames resident in HBM per GPU, full pipeline "
+                               "(button, ui_map, marker mask+dilate, LSD, ocr_preprocess, scales+m/px)%s" % (
+                                   n, W, H, ", RCCL gather of result records" if world > 1 else ""),
+                   "frames_per_gpu": n, "global_batch": n * world, "frame": [W, H], "stages": args.stages,
+                   "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world},
+        "per_gpu_frames_per_s": value / world,
+        "h2d_seconds_for_batch": h2d_s,
+        "all_map_open": bool(all_open),
+    }
+    if stages_ms is not None:
+        t_map = stages_ms["map_pass"] * 1e-3
+        ach = n * map_bytes / t_map / 1e9 if t_map > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "k_map_pass", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_frame": map_bytes, "launch_ms": stages_ms["map_pass"]}
+        out["stages_ms"] = stages_ms
+        out["pipeline_algorithmic_GBps"] = value / world * full_bytes / 1e9
+        out["pipeline_hbm_frac"] = value / world * full_bytes / 1e9 / HBM_PEAK_GBS
+        t_lsd = stages_ms["lsd"] * 1e-3
+        out["lsd"] = {"rounds_per_frame": rounds, "ray_steps_per_frame": ray_steps, "lines_per_frame": n_lines,
+                      "ray_steps_per_s": (n * ray_steps / t_lsd) if t_lsd > 0 else None,
+                      "time_share": stages_ms["lsd"] / max(sum(stages_ms.values()), 1e-9)}
+
+    if args.cpu_sample > 0:
+        from oracle import oracle as orc   # CPU baseline leg only (checker, never the product path)
+        k = min(args.cpu_sample, n)
+        cores = os.cpu_count() or 1
+        a = np.zeros((k, 3, 3), np.uint32)
+        for i in range(k):
+            for j, s in enumerate(infos[i]["anchors"][:3]):
+                a[i, j] = s
+        sub = frames_host.numpy()[:k]
+        orc.process_batch(sub[:min(k, cores)], cores, stages=args.stages, anchors=a[:min(k, cores)], n_anchors=len(infos[0]["anchors"]),
+                          scales_start_y=infos[0]["scales_start_y"])          # warm-up
+        t0 = time.perf_counter()
+        res = orc.process_batch(sub, cores, stages=args.stages, anchors=a, n_anchors=len(infos[0]["anchors"]), scales_start_y=infos[0]["scales_start_y"])
+        cdt = time.perf_counter() - t0
+        same = all(res[i].n_lines == recs[i]["n_lines"] and res[i].rounds == recs[i]["rounds"] for i in range(k))
+        out["cpu_baseline"] = {"value": k / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": "first %d frames of rank 0's batch, same stages, C oracle (gcc -O2), frames parallel across %d threads; "
+                                         "line/round counts match GPU: %s" % (k, cores, same)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,7 +164,8 @@ SMHV_API int smhv_batch_device_ptrs(smhv_batch *b, void **d_results, void **d_ui
 /* synchronising host copies (tightly packed) */
 SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, uint32_t n, smhv_frame_result *out);
 SMHV_API int smhv_batch_read_image(smhv_batch *b, int which /* SMHV_VIEW_* or 100 = ui_map RGBA */, uint32_t frame, uint8_t *out);
-/* Per-stage device time of the LAST smhv_batch_run with timing enabled, measured with hipEvents on
+/* Per-stage device time, AVERAGED over the timed smhv_batch_run calls since the last read (at most the
+ * 64 most recent), measured with hipEvents on
  * the run's stream (the analogue of the reference's Timeshares, vision-common/src/debug.rs:3-30).
  * ms[0]=button ms[1]=map pass ms[2]=brq pass ms[3]=lsd ms[4]=scale ratio.  Synchronises. */
 SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);

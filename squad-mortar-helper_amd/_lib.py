@@ -105,6 +105,13 @@ def load():
             raise ImportError(
                 "%s not found: the HIP extension is not built (run __graft_entry__.build() or "
                 "`make -C squad-mortar-helper_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in
+        # one process do not work ("No HIP GPUs are available"), so when torch is installed it is
+        # imported first and this library binds to the runtime torch loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the symbol is not exported

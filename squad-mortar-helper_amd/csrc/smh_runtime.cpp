@@ -124,9 +124,12 @@ struct smhv_batch {
 	FrameAux *d_aux = nullptr;
 	smhv_frame_result *d_results = nullptr;   // max_frames (+2 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
-	bool timing = false, timed_run = false;
-	hipEvent_t ev[6] = {};
-	bool ev_ok = false;
+	// per-stage hipEvent ring: up to TIMING_RING timed runs are kept so a benchmark loop can read the
+	// average stage durations afterwards without synchronising between steps
+	static constexpr int TIMING_RING = 64;
+	bool timing = false;
+	hipEvent_t (*ev)[6] = nullptr;
+	uint64_t timed_runs = 0;
 };
 
 struct smhv_ctx {
@@ -264,8 +267,11 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
-	if (b->ev_ok)
-		for (auto &e : b->ev) (void)hipEventDestroy(e);
+	if (b->ev) {
+		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
+			for (int i = 0; i < 6; ++i) (void)hipEventDestroy(b->ev[r][i]);
+		delete[] b->ev;
+	}
 	delete b;
 }
 
@@ -287,12 +293,14 @@ extern "C" SMHV_API int smhv_batch_layout_get(smhv_batch *b, smhv_batch_layout *
 
 extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 	if (!b) return fail(SMHV_E_INVALID, "null batch");
-	if (enable && !b->ev_ok) {
+	if (enable && !b->ev) {
 		HIPCHK(hipSetDevice(b->ctx->device));
-		for (auto &e : b->ev) HIPCHK(hipEventCreate(&e));
-		b->ev_ok = true;
+		b->ev = new hipEvent_t[smhv_batch::TIMING_RING][6];
+		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
+			for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&b->ev[r][i]));
 	}
 	b->timing = enable != 0;
+	b->timed_runs = 0;
 	return SMHV_OK;
 }
 
@@ -306,33 +314,40 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	const bool scales = (stages & SMHV_STAGE_SCALES) && anchors;
 	if (scales) HIPCHK(hipMemcpyAsync(b->d_anchors, anchors, sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, s));
 	const bool t = b->timing;
-	b->timed_run = t;
-	if (t) HIPCHK(hipEventRecord(b->ev[0], s));
+	hipEvent_t *ev = t ? b->ev[b->timed_runs % smhv_batch::TIMING_RING] : nullptr;
+	if (t) HIPCHK(hipEventRecord(ev[0], s));
 	HIPCHK(launch_button(g, bf, n, 0, s));
-	if (t) HIPCHK(hipEventRecord(b->ev[1], s));
+	if (t) HIPCHK(hipEventRecord(ev[1], s));
 	uint32_t mflags = 0;
 	if (stages & SMHV_STAGE_MARKERS) mflags |= MAP_MASK;
 	if (stages & SMHV_STAGE_UI_MAP) mflags |= MAP_UI;
 	if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
-	if (t) HIPCHK(hipEventRecord(b->ev[2], s));
+	if (t) HIPCHK(hipEventRecord(ev[2], s));
 	uint32_t qflags = 0;
 	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
 	if (scales) qflags |= BRQ_SCALES;
 	if (qflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
-	if (t) HIPCHK(hipEventRecord(b->ev[3], s));
+	if (t) HIPCHK(hipEventRecord(ev[3], s));
 	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, s));
-	if (t) HIPCHK(hipEventRecord(b->ev[4], s));
+	if (t) HIPCHK(hipEventRecord(ev[4], s));
 	if (scales) HIPCHK(launch_scale_ratio(g, bf, n, b->d_bars, s));
 	HIPCHK(launch_finalize(g, bf, n, scales ? stages : (stages & ~SMHV_STAGE_SCALES), s));
-	if (t) HIPCHK(hipEventRecord(b->ev[5], s));
+	if (t) { HIPCHK(hipEventRecord(ev[5], s)); b->timed_runs++; }
 	return SMHV_OK;
 }
 
 extern "C" SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]) {
 	if (!b || !ms) return fail(SMHV_E_INVALID, "bad arguments");
-	if (!b->timed_run) return fail(SMHV_E_STATE, "the last smhv_batch_run was not timed");
-	HIPCHK(hipEventSynchronize(b->ev[5]));
-	for (int i = 0; i < 5; ++i) HIPCHK(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+	if (!b->ev || b->timed_runs == 0) return fail(SMHV_E_STATE, "no timed smhv_batch_run since timing was enabled");
+	const uint64_t runs = b->timed_runs < (uint64_t)smhv_batch::TIMING_RING ? b->timed_runs : (uint64_t)smhv_batch::TIMING_RING;
+	double acc[5] = {0, 0, 0, 0, 0};
+	for (uint64_t r = 0; r < runs; ++r) {
+		hipEvent_t *ev = b->ev[(b->timed_runs - 1 - r) % smhv_batch::TIMING_RING];
+		HIPCHK(hipEventSynchronize(ev[5]));
+		for (int i = 0; i < 5; ++i) { float m = 0; HIPCHK(hipEventElapsedTime(&m, ev[i], ev[i + 1])); acc[i] += m; }
+	}
+	for (int i = 0; i < 5; ++i) ms[i] = (float)(acc[i] / (double)runs);
+	b->timed_runs = 0;
 	return SMHV_OK;
 }
 

@@ -20,21 +20,26 @@ def shard_range(n_total, rank, world):
     return lo, hi
 
 
-def gather_records(local_records, dist, device=None, dst=0):
-    """local_records: uint8 torch tensor [n_local * RECORD_BYTES] (on `device` for nccl).
+def gather_records(local_records, dist, dst=0, sizes=None):
+    """local_records: uint8 torch tensor [n_local * RECORD_BYTES] (a CUDA tensor for nccl/RCCL).
     Returns on dst a list of per-rank uint8 tensors, elsewhere None.  Shards may differ by one
-    frame, so sizes are exchanged first and the payload is padded to the maximum."""
+    frame: unless the caller passes the per-rank byte `sizes` (known for equal shards), they are
+    exchanged first; the payload is padded to the maximum so a single gather moves it."""
     import torch
 
     world = dist.get_world_size()
     rank = dist.get_rank()
-    n = torch.tensor([local_records.numel()], dtype=torch.int64, device=local_records.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n = torch.tensor([local_records.numel()], dtype=torch.int64, device=local_records.device)
+        got = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(got, n)
+        sizes = [int(s.item()) for s in got]
     mx = max(sizes)
-    padded = torch.zeros(mx, dtype=torch.uint8, device=local_records.device)
-    padded[:local_records.numel()] = local_records
+    if local_records.numel() == mx:
+        padded = local_records
+    else:
+        padded = torch.zeros(mx, dtype=torch.uint8, device=local_records.device)
+        padded[:local_records.numel()] = local_records
     bufs = [torch.zeros(mx, dtype=torch.uint8, device=local_records.device) for _ in range(world)] if rank == dst else None
     dist.gather(padded, bufs, dst=dst)
     if rank != dst:

@@ -1,0 +1,345 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the
+committed goldens.  Integer outputs (pixels, masks, counts) must be bit-exact; the float line
+endpoints are compared bit-exactly too (same f32 operation order); derived f64/f32 lengths, meters
+and angles within the north star's 1e-4."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run_trait_sequence(v, frame, max_gap=15, anchors=None, grayscale=True):
+    """The call order of the reference's own GPU test (vision-gpu/src/lib.rs:562-622)."""
+    import squad_mortar_helper_amd as smh
+    st = smh.VisionState(grayscale_map=grayscale, max_gap=max_gap)
+    return st.process(v, frame, ocr_labels=anchors)
+
+
+def test_native_library_is_loaded_and_device_is_gfx950(vision):
+    import torch
+    assert torch.cuda.is_available()
+    maps = open("/proc/self/maps").read()
+    assert "libsmh_vision_hip.so" in maps
+
+
+def test_colour_predicate_exhaustive_2_pow_24(vision):
+    """is_any_map_marker_color on the device == oracle for every RGB colour (hsv f32 rounding,
+    division, the fmod identities and the integer pre-filter are all covered)."""
+    dev = vision.debug_marker_table()
+    ref = o.marker_table()
+    assert np.array_equal(dev, ref)
+    assert int(np.unpackbits(ref.view(np.uint8)).sum()) == 888998
+
+
+@pytest.mark.parametrize("stem", fx.OPEN_STEMS)
+def test_samples_match_goldens_and_oracle(vision, stem):
+    frame, e, g = fx.load_fixture(stem)
+    anchors = e.get("anchors") or None
+    res = run_trait_sequence(vision, frame, anchors=anchors)
+    assert res is not None and list(res.roi) == e["map_rect"]
+    assert vision.red_pixels() == e["red_pixels"]
+    lsd = vision.lsd_image()
+    assert np.array_equal(np.flatnonzero(lsd.reshape(-1) == 255).astype(np.uint32), g["mask_idx"])   # marker pixel coords
+    assert set(np.unique(lsd)) <= {0, 255} and sha(lsd) == e["sha_lsd"]
+    assert res.markers.shape == g["lines"].shape and np.array_equal(res.markers, g["lines"])
+    assert sha(res.map) == e["sha_ui_gray"]
+    assert sha(vision.ocr_preprocess()) == e["sha_ocr"]
+    assert sha(vision.find_scales_preprocess(0)) == e["sha_scales0"]
+    # the reference's GPU test calls find_marker_lines(22)
+    assert np.array_equal(vision.find_marker_lines(22), g["lines_gap22"])
+    # debug views (vision-cpu/src/lib.rs:451-460)
+    import squad_mortar_helper_amd as smh
+    iso = vision.get_debug_view(smh.DebugView.LSD_PREPROCESS)
+    assert sha(iso[..., :3]) == e["sha_isolated"] and (iso[..., 3] == 255).all()
+    assert sha(vision.get_debug_view(smh.DebugView.CROPPED_BRQ)[..., :3]) == e["sha_brq"]
+    assert np.array_equal(vision.get_debug_view(smh.DebugView.LSD_INPUT)[..., 0], lsd)
+    if anchors:
+        assert res.meters_to_px_ratio == e["mpx"]
+
+
+@pytest.mark.parametrize("stem", fx.FULL_STEMS)
+def test_colour_ui_map(vision, stem):
+    frame, e, _ = fx.load_fixture(stem)
+    vision.load_frame(frame)
+    ui, roi = vision.crop_to_map(False)
+    assert sha(ui) == e["sha_ui_color"]
+
+
+def test_closed_map_returns_none_and_later_calls_error(vision):
+    import squad_mortar_helper_amd as smh
+    for stem in ("a_point_png", "line_angle_png"):
+        frame, e, _ = fx.load_fixture(stem)
+        vision.load_frame(frame)
+        assert vision.crop_to_map(True) is None
+        assert vision.red_pixels() == e["red_pixels"]
+        with pytest.raises(smh.VisionError) as ei:
+            vision.find_marker_lines(15)
+        assert ei.value.code == -5
+    with pytest.raises(smh.VisionError):
+        vision.load_frame(np.zeros((44, 43, 4), np.uint8))          # convolution.png geometry
+
+
+def test_button_threshold_edge(vision):
+    """ratio < 0.65 => None; the count is compared as f32 exactly like the reference."""
+    from squad_mortar_helper_amd import synth
+    import squad_mortar_helper_amd as smh
+    W, H = 1024, 768
+    frame, _ = synth.make_frame(W, H, 1, n_lines=0)
+    bx, by, bw, bh = smh.button_bounds(W, H)
+    n = bw * bh
+    k_open = int(np.ceil(0.65 * n))
+    for k in (k_open - 1, k_open, k_open + 1):
+        f = frame.copy()
+        flat = f[by:by + bh, bx:bx + bw].reshape(-1, 4)
+        flat[:, :3] = (49, 67, 217)
+        flat[k:, :3] = (0, 0, 0)
+        f[by:by + bh, bx:bx + bw] = flat.reshape(bh, bw, 4)
+        vision.load_frame(f)
+        got = vision.crop_to_map(True)
+        want = o.crop_to_map(f, True)
+        assert (got is None) == (want is None)
+        assert vision.red_pixels() == k == o.button_red_pixels(f)
+    # per-channel tolerance is inclusive at 25
+    f = frame.copy()
+    f[by:by + bh, bx:bx + bw, :3] = (49 + 25, 67 - 25, 217 + 25)
+    vision.load_frame(f)
+    assert vision.crop_to_map(True) is not None and vision.red_pixels() == n
+    f[by:by + bh, bx:bx + bw, 2] = 217 + 26
+    vision.load_frame(f)
+    assert vision.crop_to_map(True) is None and vision.red_pixels() == 0
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (2560, 1440), (1024, 768), (1280, 1024), (1600, 1024), (3840, 2160)])
+def test_synthetic_frames_all_stages(vision, size):
+    from squad_mortar_helper_amd import synth
+    W, H = size
+    for idx in (0, 1):
+        frame, info = synth.make_frame(W, H, idx, n_lines=2 + idx)
+        ref = o.process_frame(frame, stages=0xF, anchors=info["anchors"], scales_start_y=info["scales_start_y"], want_images=True)
+        res = run_trait_sequence(vision, frame, anchors=info["anchors"])
+        assert np.array_equal(res.map, ref["ui_map"])
+        assert np.array_equal(vision.lsd_image(), ref["lsd"])
+        assert np.array_equal(res.markers, ref["lines"])
+        assert np.array_equal(vision.ocr_preprocess(), ref["ocr"])
+        sc = vision.find_scales_preprocess(info["scales_start_y"])
+        assert np.array_equal(sc[info["scales_start_y"]:], ref["scales"][info["scales_start_y"]:])
+        assert res.meters_to_px_ratio == ref["mpx"]
+
+
+def test_find_longest_line_random_points(vision):
+    """Vision::find_longest_line on arbitrary (also fractional / off-mask / border) points."""
+    frame, e, g = fx.load_fixture("points_intersect_png")
+    run_trait_sequence(vision, frame)
+    lsd = vision.lsd_image()
+    h, w = lsd.shape
+    rng = np.random.default_rng(3)
+    ys, xs = np.nonzero(lsd == 255)
+    pts = [(float(xs[i]), float(ys[i])) for i in rng.integers(0, len(xs), 12)]
+    pts += [(float(xs[i]) + 0.5, float(ys[i]) + 0.25) for i in rng.integers(0, len(xs), 6)]
+    pts += [(0.0, 0.0), (w - 1.0, h - 1.0), (w / 2.0, 0.0), (0.0, h / 2.0), (float(rng.uniform(0, w - 1)), float(rng.uniform(0, h - 1)))]
+    for gap in (15.0, 22.0, 0.0, 3.5):
+        for (x, y) in pts[:: (1 if gap == 15.0 else 4)]:
+            line, ln = vision.find_longest_line((x, y), gap)
+            rl, rn = o.find_longest_line(lsd, x, y, gap)
+            assert np.array_equal(line, rl) and ln == rn, (x, y, gap, line, rl)
+
+
+def test_ocr_neighbourhood_and_scales_semantics(vision):
+    """Hand-made BRQ content: white glyph pixels, grey edge pixels inside/outside the 7x7 reach, the
+    asymmetric `min(x+3, w-3)` clamp at the right/bottom border, near-black luma (scales)."""
+    from squad_mortar_helper_amd import synth
+    import squad_mortar_helper_amd as smh
+    W, H = 1280, 1024
+    frame, info = synth.make_frame(W, H, 2, n_lines=0)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    qw, qh = rw // 2, rh // 2
+    ox, oy = x + qw, y + qh
+    rng = np.random.default_rng(11)
+    brq = frame[oy:oy + qh, ox:ox + qw]
+    brq[..., :3] = rng.integers(100, 200, (qh, qw, 1))            # grey field: many edge candidates (>=130), none white
+    for _ in range(60):
+        cx, cy = int(rng.integers(0, qw)), int(rng.integers(0, qh))
+        brq[cy, cx, :3] = int(rng.integers(200, 256))             # white glyph pixels (r==g==b>=200)
+    brq[qh - 1, qw - 1, :3] = 255                                 # white pixels the clamp makes unreachable as neighbours
+    brq[qh - 2, qw - 2, :3] = 255
+    brq[5, qw - 1, :3] = 230
+    brq[0, 0, :3] = 210
+    brq[10:14, 10:30, :3] = (3, 0, 4)                             # luma 0.9 -> 0  => scales 0
+    brq[20:24, 10:30, :3] = (0, 2, 0)                             # luma 1.43 -> 1 => scales 255
+    tint = brq[40:60, 40:90, :3].astype(np.int16)
+    tint[..., 0] += rng.integers(0, 14, tint.shape[:2])           # max-min up to 13 straddles the similarity threshold (12)
+    brq[40:60, 40:90, :3] = np.clip(tint, 0, 255).astype(np.uint8)
+    ref = o.process_frame(frame, stages=0xC, want_images=True, scales_start_y=7)
+    vision.load_frame(frame)
+    assert vision.crop_to_map(True) is not None
+    assert np.array_equal(vision.ocr_preprocess(), ref["ocr"])
+    assert int((ref["ocr"] != 255).sum()) > 100
+    sc = vision.find_scales_preprocess(7)
+    assert np.array_equal(sc[7:], ref["scales"][7:])
+    assert (sc[10:14, 10:30] == 0).all() and (sc[20:24, 10:30] == 255).all()
+    # rows above scales_start_y stay stale: a second call with a larger start leaves rows 7.. untouched
+    sc2 = vision.find_scales_preprocess(qh // 2)
+    assert np.array_equal(sc2, sc)
+    with pytest.raises(smh.VisionError):
+        vision.find_scales_preprocess(qh + 1)
+
+
+def test_mask_edges_and_dilation_clipping(vision):
+    """Marker pixels on all four ROI borders and corners: dilation must clip at the image edge and
+    must not leak across the ROI boundary (pixels just outside the ROI are marker-coloured too)."""
+    from squad_mortar_helper_amd import synth
+    import squad_mortar_helper_amd as smh
+    W, H = 1600, 1024
+    frame, _ = synth.make_frame(W, H, 4, n_lines=0)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    green = (0, 255, 64, 255)      # BGRA of RGB(64,255,0)
+    frame[y - 1, x:x + rw] = green           # just outside (above)
+    frame[y + rh, x:x + rw] = green          # just outside (below)
+    frame[y:y + rh, x - 1] = green           # just outside (left)
+    frame[y:y + rh, x + rw] = green          # just outside (right)
+    for (px, py) in [(0, 0), (rw - 1, 0), (0, rh - 1), (rw - 1, rh - 1), (rw // 2, 0), (0, rh // 2), (rw - 1, rh // 3), (rw // 3, rh - 1),
+                     (61, 61), (62, 62), (63, 63), (64, 64), (255, 61), (256, 62), (257, 123), (3, 124)]:
+        frame[y + py, x + px] = green
+    ref = o.process_frame(frame, stages=0x1, want_images=True)
+    res = run_trait_sequence(vision, frame)
+    lsd = vision.lsd_image()
+    assert np.array_equal(lsd, ref["lsd"]) and ref["n_mask_px"] > 40
+    assert np.array_equal(res.markers, ref["lines"])
+
+
+def test_line_cap_of_32_and_many_rounds(vision):
+    """A frame with far more than 32 acceptable segments stops at 32 exactly like lsd.rs:100-102."""
+    from squad_mortar_helper_amd import synth
+    import squad_mortar_helper_amd as smh
+    W, H = 1920, 1080
+    frame, _ = synth.make_frame(W, H, 9, n_lines=0)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    for k in range(45):
+        yy = y + 12 + 17 * k
+        frame[yy:yy + 2, x + 30 + (k % 5) * 7: x + 30 + (k % 5) * 7 + 90 + 3 * k] = (217, 117, 192, 255)   # RGB(192,117,217)
+    ref = o.process_frame(frame, stages=0x1, want_images=True)
+    res = run_trait_sequence(vision, frame)
+    assert ref["n_lines"] == 32 and res.markers.shape == (32, 4)
+    assert np.array_equal(res.markers, ref["lines"])
+
+
+def test_batch_matches_oracle_including_derived_outputs(vision):
+    """Resident-batch entry point: mixed open/closed frames, per-frame anchors, every record field."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N = 1920, 1080, 12
+    frames, infos = synth.make_batch(W, H, N, first_idx=100)
+    frames[3], _ = synth.make_frame(W, H, 103, map_open=False)
+    frames[7], _ = synth.make_frame(W, H, 107, n_lines=0)
+    per = [(i["scales_start_y"], i["anchors"]) for i in infos]
+    per[5] = (per[5][0], [])                                       # no OCR labels for frame 5 => no m/px
+    per[6] = (per[6][0], per[6][1] + [(50, 20, 20)])               # a third, bogus label
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    fb.run(d.data_ptr(), N, anchors=smh.make_anchors(per), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    recs = smh.results_to_dicts(fb.read_results(0, N))
+    for i in range(N):
+        start_y, anc = per[i]
+        ref = o.process_frame(frames[i], stages=0xF if anc else 0x7, anchors=anc, scales_start_y=start_y, want_images=True)
+        r = recs[i]
+        assert r["map_open"] == ref["map_open"]
+        if not ref["map_open"]:
+            assert r["n_lines"] == 0 and r["mpx"] is None and r["n_mask_px"] == 0
+            continue
+        assert r["red_pixels"] == o.button_red_pixels(frames[i])
+        assert np.array_equal(r["lines"], ref["lines"]) and r["n_mask_px"] == ref["n_mask_px"]
+        assert (r["rounds"], r["ray_steps"]) == (ref["rounds"], ref["steps"])       # identical ray trajectories
+        assert r["mpx"] == ref["mpx"]
+        assert np.array_equal(fb.read_image(smh._lib.IMAGE_UI_MAP, i), ref["ui_map"])
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_LSD_INPUT, i), ref["lsd"])
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_OCR_INPUT, i), ref["ocr"])
+        if anc:
+            assert np.array_equal(fb.read_image(smh._lib.VIEW_FIND_SCALES_INPUT, i)[start_y:], ref["scales"][start_y:])
+        for k, ln in enumerate(ref["lines"]):
+            length, meters = o.marker_new(ln, ref["mpx"] if ref["mpx"] is not None else 0.0)
+            assert abs(r["length_px"][k] - length) <= TOL
+            assert abs(r["meters"][k] - (meters if ref["mpx"] is not None else 0.0)) <= TOL
+            assert abs(float(r["angle"][k]) - o.marker_angle(ln)) <= TOL
+    fb.close()
+
+
+def test_full_size_batch_properties(vision):
+    """BASELINE configs[2] size (256 x 1080p): size-independent properties instead of a full oracle run:
+    idempotence (a second run gives identical bytes), permutation equivariance (reversing the batch
+    reverses the records), n_mask_px == popcount of the mask image, and a sample of frames against
+    the oracle."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N = 1920, 1080, 256
+    host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
+    _, infos = synth.make_batch(W, H, N, out=host.numpy())
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+    d = host.cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    s = torch.cuda.current_stream().cuda_stream
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
+    a = bytes(fb.read_results(0, N))
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
+    b = bytes(fb.read_results(0, N))
+    assert a == b
+    recs = smh.results_to_dicts(fb.read_results(0, N))
+    assert all(r["map_open"] == 1 and r["mpx"] == recs[0]["mpx"] for r in recs)
+    for i in (0, 17, 101, 255):
+        ref = o.process_frame(host.numpy()[i], stages=0xF, anchors=infos[i]["anchors"], scales_start_y=infos[i]["scales_start_y"], want_images=True)
+        assert np.array_equal(recs[i]["lines"], ref["lines"]) and recs[i]["mpx"] == ref["mpx"]
+        assert (recs[i]["rounds"], recs[i]["ray_steps"], recs[i]["n_mask_px"]) == (ref["rounds"], ref["steps"], ref["n_mask_px"])
+        m = fb.read_image(smh._lib.VIEW_LSD_INPUT, i)
+        assert int((m == 255).sum()) == recs[i]["n_mask_px"] and np.array_equal(m, ref["lsd"])
+    rev = torch.flip(d, dims=[0]).contiguous()
+    anchors_rev = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in reversed(infos)])
+    fb.run(rev.data_ptr(), N, anchors=anchors_rev, stream=s)
+    recs_rev = smh.results_to_dicts(fb.read_results(0, N))
+    for i in range(N):
+        r, q = recs[i], recs_rev[N - 1 - i]
+        assert np.array_equal(r["lines"], q["lines"]) and r["rounds"] == q["rounds"] and r["n_mask_px"] == q["n_mask_px"]
+    fb.close()
+
+
+def test_1440p_batch_window_and_global_mask_paths(vision):
+    """BASELINE configs[3] geometry: the bit-packed mask (176 KiB) does not fit LDS.  Frame 0 has
+    markers spread over the whole ROI (bounding box > LDS window => global-memory mask path), the
+    others use the LDS window path."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N = 2560, 1440, 6
+    frames, infos = synth.make_batch(W, H, N, first_idx=40, n_lines=3)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    green = (0, 255, 64, 255)
+    frames[0, y + 2:y + 5, x + 2:x + 80] = green
+    frames[0, y + rh - 6:y + rh - 3, x + rw - 90:x + rw - 3] = green
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    per = [(i["scales_start_y"], i["anchors"]) for i in infos]
+    fb.run(d.data_ptr(), N, anchors=smh.make_anchors(per), stream=torch.cuda.current_stream().cuda_stream)
+    recs = smh.results_to_dicts(fb.read_results(0, N))
+    for i in range(N):
+        ref = o.process_frame(frames[i], stages=0xF, anchors=per[i][1], scales_start_y=per[i][0], want_images=True)
+        assert np.array_equal(recs[i]["lines"], ref["lines"]) and recs[i]["mpx"] == ref["mpx"]
+        assert (recs[i]["rounds"], recs[i]["ray_steps"]) == (ref["rounds"], ref["steps"])
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_LSD_INPUT, i), ref["lsd"])
+        assert np.array_equal(fb.read_image(smh._lib.IMAGE_UI_MAP, i), ref["ui_map"])
+    fb.close()
+
+
+def test_smoke_entry_point(vision):
+    import __graft_entry__ as g
+    g.smoke()

@@ -1,0 +1,137 @@
+"""CPU tests (no GPU): the C-ABI library loads, exports every symbol include/smh_vision_hip.h declares,
+its host-side logic (bounds arithmetic, error reporting, record layout) is right, and the
+multi-process gather path works (gloo, world_size 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "smh_vision_hip.h")).read()
+    return sorted(set(re.findall(r"SMHV_API\s+[\w\s\*]+?\b(smhv_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from squad_mortar_helper_amd import _lib
+    names = header_symbols()
+    assert len(names) >= 29 and set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (\w+)", out))
+    assert set(names) <= exported
+    # nothing but the C ABI leaks out of the library (visibility=hidden), and no oracle symbol is linked in
+    assert not [s for s in exported if s.startswith("orc_")]
+    assert "libsmh_oracle" not in subprocess.check_output(["ldd", _lib.LIB_PATH], text=True)
+
+
+def test_product_package_does_not_import_the_oracle(built):
+    pkg = os.path.join(ROOT, "squad-mortar-helper_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "smh_oracle" not in src, f
+
+
+def test_bounds_match_oracle_for_many_sizes(built):
+    import squad_mortar_helper_amd as smh
+    from oracle import oracle as o
+    sizes = [(1920, 1080), (2560, 1440), (1024, 768), (1280, 1024), (1600, 1024), (3840, 2160), (1366, 768), (1280, 720),
+             (3440, 1440), (5120, 1440), (7680, 4320), (800, 600), (641, 479)]
+    for w, h in sizes:
+        om, ob = o.map_bounds(w, h), o.button_bounds(w, h)
+        if om is None or ob is None:
+            with pytest.raises(smh.VisionError) as ei:
+                smh.map_bounds(w, h)
+                smh.button_bounds(w, h)
+            assert ei.value.code == -2
+        else:
+            assert smh.map_bounds(w, h) == om and smh.button_bounds(w, h) == ob
+    for w, h in [(43, 44), (600, 1080), (1, 1)]:
+        with pytest.raises(smh.VisionError) as ei:
+            smh.map_bounds(w, h)
+        assert ei.value.code == -2 and "frame" in str(ei.value)
+
+
+def test_init_without_gpu_fails_loudly_not_silently(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import squad_mortar_helper_amd as smh
+    with pytest.raises(smh.VisionError) as ei:
+        smh.HipVision.init(0)
+    assert ei.value.code == -4          # SMHV_E_NO_DEVICE: the caller falls back, the library never does
+
+
+def test_record_layout_matches_header(built):
+    from squad_mortar_helper_amd import _lib
+    # smhv_frame_result: 8 + 32*16 + 8 + 4*4 + 8 + 32*8*2 + 32*4 = 1192
+    assert C.sizeof(_lib.FrameResult) == 1192
+    assert _lib.FrameResult.lines.offset == 8 and _lib.FrameResult.mpx.offset == 520
+    assert _lib.FrameResult.ray_steps.offset == 544 and _lib.FrameResult.length_px.offset == 552
+    assert C.sizeof(_lib.Anchors) == 44 and C.sizeof(_lib.Line) == 16
+
+
+def test_shard_range_partitions_exactly(built):
+    from squad_mortar_helper_amd.dist import shard_range
+    for n in (1, 7, 8, 255, 256, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    assert [shard_range(8192, r, 8) for r in range(8)] == [(1024 * r, 1024 * (r + 1)) for r in range(8)]
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import ctypes as C
+from squad_mortar_helper_amd import _lib
+from squad_mortar_helper_amd.dist import gather_records, records_from_bytes, shard_range, RECORD_BYTES
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+N = 7                                     # uneven shards: 3 + 4
+lo, hi = shard_range(N, rank, world)
+recs = (_lib.FrameResult * (hi - lo))()
+for i, f in enumerate(range(lo, hi)):
+    recs[i].map_open = 1; recs[i].n_lines = f % 5; recs[i].rounds = 100 + f; recs[i].mpx = 0.5 * f; recs[i].has_mpx = 1
+    recs[i].lines[0].x0 = float(f)
+buf = torch.from_numpy(np.frombuffer(bytes(recs), np.uint8).copy())
+out = gather_records(buf, dist)
+if rank == 0:
+    allrecs = []
+    for t in out:
+        allrecs += list(records_from_bytes(t.numpy()))
+    assert len(allrecs) == N
+    for f, r in enumerate(allrecs):
+        assert r.rounds == 100 + f and r.n_lines == f % 5 and r.mpx == 0.5 * f and r.lines[0].x0 == float(f)
+    # equal shards with known sizes: single collective
+out2 = gather_records(buf[:3 * RECORD_BYTES].contiguous(), dist, sizes=[3 * RECORD_BYTES] * world)
+if rank == 0:
+    assert [t.numel() for t in out2] == [3 * RECORD_BYTES] * world
+    print("GATHER_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_gather_of_result_records_gloo_world2(built, tmp_path):
+    """The N>1 path of bench.py (block shard + gather of per-frame records) on CPU with gloo."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", str(script), ROOT]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "GATHER_OK" in p.stdout

@@ -1,0 +1,228 @@
+"""CPU tests (no GPU): the oracle against the committed goldens and against known answers.
+
+The goldens under tests/golden/ were produced from the reference's own sample screenshots by
+tests/golden/make_goldens.py; the workload counts asserted in test_appendix_b_counts were
+recorded independently (numpy probe) before the C oracle existed.
+"""
+import re
+import os
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+from oracle import oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# SURVEY.md Appendix B (independent numpy restatement): ROI geometry per frame size
+GEOMETRY = {
+    (1920, 1080): ((1657, 1031, 255, 41), (914, 178, 986, 822)),
+    (2560, 1440): ((2209, 1374, 340, 55), (1219, 237, 1314, 1096)),
+    (1024, 768): ((837, 733, 181, 29), (650, 126, 360, 585)),
+    (1280, 1024): ((1030, 977, 242, 39), (867, 169, 394, 779)),
+    (1600, 1024): ((1350, 977, 242, 39), (867, 169, 714, 779)),
+}
+
+# (marker px, mask px, skipped by proximity, rounds, ray steps, lines)
+APPENDIX_B = {
+    "in_mortar_png": (114, 293, 292, 1, 74660, 1),
+    "point_png": (501, 1351, 1273, 78, 5326764, 1),
+    "point2_png": (543, 2091, 2090, 1, 75250, 1),
+    "lol_png": (437, 1574, 1500, 74, 5056614, 2),
+    "point_far_png": (1076, 2646, 2567, 79, 5405513, 2),
+    "point_intersect_png": (954, 2306, 2227, 79, 5405676, 2),
+    "point_opposite_h_png": (991, 1866, 1865, 1, 77920, 1),
+    "point_opposite_v_png": (1068, 2139, 2138, 1, 78263, 1),
+    "points_png": (1560, 4400, 4396, 4, 301640, 4),
+    "points_intersect_png": (2722, 6817, 6810, 7, 540087, 7),
+    "snowpoints_png": (1338, 4781, 4429, 352, 28069232, 24),
+    "vlcsnap-2022-05-11-06h03m39s483_png": (14, 61, 0, 61, 4057200, 0),
+    "full_1024x768_png": (68, 230, 0, 230, 17117542, 0),
+    "full_1280x1024_png": (92, 312, 0, 312, 23370451, 0),
+    "full_1600x1024_png": (303, 1098, 393, 705, 56020456, 6),
+}
+# Appendix B provisional lines (to ~7 significant digits)
+APPENDIX_B_LINES = {
+    "point_png": [[719, 558, 1092.0632, 876.6817]],
+    "in_mortar_png": [[669.5, 538, 673.18024, 646.93903]],
+    "point2_png": [[1077, 153, 305.15057, 618.91766]],
+    "point_opposite_h_png": [[618, 497.5, 227.76489, 916.48022]],
+    "point_opposite_v_png": [[1146.5, 82.5, 649.35065, 458.63406]],
+    "point_intersect_png": [[719, 558, 1092.0632, 876.6817], [971, 618.5, 720.685, 699.00909]],
+    "lol_png": [[721, 560, 1092.6296, 875.2829], [960, 621.5, 825.10394, 664.85156]],
+}
+
+
+@pytest.mark.parametrize("size", sorted(GEOMETRY))
+def test_geometry_matches_appendix_b(size):
+    btn, mp = GEOMETRY[size]
+    assert o.button_bounds(*size) == btn
+    assert o.map_bounds(*size) == mp
+
+
+def test_geometry_rejects_frames_the_reference_panics_on():
+    assert o.map_bounds(43, 44) is None          # convolution.png
+    assert o.map_bounds(600, 1080) is None       # portrait: map width underflows
+
+
+def test_hsv_known_answers():
+    # exact team colours (consts.toml:33-41) and corner cases of util/src/image.rs:159-187
+    assert o.hsv(64, 255, 0) == (104, 100, 100)
+    assert o.hsv(192, 117, 217) == (285, 46, 85)
+    assert o.hsv(93, 232, 181) == (157, 59, 90)
+    assert o.hsv(0, 0, 0) == (0, 0, 0)           # s = NaN -> 0
+    assert o.hsv(255, 255, 255) == (0, 0, 100)
+    assert o.hsv(255, 0, 0) == (0, 100, 100)
+    assert o.hsv(255, 0, 1)[0] == 359            # negative hue wraps through modulo(h, 360)
+    assert o.hsv(0, 0, 255) == (240, 100, 100)
+    for rgb in [(64, 255, 0), (192, 117, 217), (93, 232, 181)]:
+        assert o.is_any_map_marker_color(*rgb)
+    for rgb in [(0, 0, 0), (255, 255, 255), (128, 128, 128), (255, 0, 0), (200, 180, 150)]:
+        assert not o.is_any_map_marker_color(*rgb)
+
+
+def test_luma_matches_image_crate_formula():
+    rng = np.random.default_rng(1)
+    for r, g, b in rng.integers(0, 256, (2000, 3)):
+        l = np.float32(0.2126) * np.float32(r) + np.float32(0.7152) * np.float32(g) + np.float32(0.0722) * np.float32(b)
+        assert o.lib().orc_luma8(int(r), int(g), int(b)) == int(l)
+    assert o.lib().orc_luma8(255, 255, 255) == 255 and o.lib().orc_luma8(0, 0, 0) == 0
+
+
+def test_ray_table_is_glibc_and_matches_committed_include():
+    dx, dy = o.ray_table()
+    g = np.load(os.path.join(fx.GOLDEN, "ray_table_glibc.npz"))
+    assert np.array_equal(dx.view(np.uint32), g["dx"].view(np.uint32))
+    assert np.array_equal(dy.view(np.uint32), g["dy"].view(np.uint32))
+    txt = open(os.path.join(ROOT, "squad-mortar-helper_amd", "csrc", "ray_table.inc")).read()
+    v = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)], np.uint32).reshape(3600, 2)
+    assert np.array_equal(v[:, 0], dx.view(np.uint32)) and np.array_equal(v[:, 1], dy.view(np.uint32))
+    assert dx[0] == 1.0 and dy[0] == 0.0
+    assert dx[900] == np.float32(-4.371139e-08)    # cos(90 deg) in f32 is not 0
+
+
+def test_dilation_literal_imageproc_equals_cross():
+    rng = np.random.default_rng(7)
+    for shape, p in [((37, 53), 0.05), ((64, 64), 0.3), ((5, 9), 0.5), ((1, 17), 0.2), ((23, 1), 0.2), ((40, 40), 0.0)]:
+        img = (rng.random(shape) < p).astype(np.uint8) * 255
+        assert np.array_equal(o.dilate_l1_imageproc(img, 1), o.dilate_cross(img))
+    one = np.zeros((9, 9), np.uint8)
+    one[4, 4] = 255
+    d = o.dilate_l1_imageproc(one, 1)
+    assert int((d == 255).sum()) == 5 and d[4, 4] == d[3, 4] == d[5, 4] == d[4, 3] == d[4, 5] == 255
+    corner = np.zeros((4, 4), np.uint8)
+    corner[0, 0] = 7                                  # any non-zero value is foreground
+    assert int((o.dilate_l1_imageproc(corner, 1) == 255).sum()) == 3
+
+
+def test_find_longest_line_quirks():
+    # a ray leaving through the right/bottom edge while still white has len 0,
+    # one leaving through the left/top edge inspects column/row 0.
+    img = np.zeros((40, 200), np.uint8)
+    img[20, :] = 255                                  # full-width horizontal line
+    line, ln = o.find_longest_line(img, 100.0, 20.0, 15.0)
+    assert ln > 0 and line[2] < 100.0                 # the leftward ray wins; the rightward one is void
+    img2 = np.zeros((40, 200), np.uint8)
+    img2[20, 50:150] = 255
+    line2, ln2 = o.find_longest_line(img2, 100.0, 20.0, 15.0)
+    # both directions end on a black sample here (~50 px each way); the winner is a ray a fraction of a
+    # degree off the axis that stays inside row 20 and is therefore marginally longer than the axial one.
+    assert abs(np.sqrt(ln2) - 50.0) < 0.01 and int(line2[3]) == 20
+    # gap tolerance: 15 missing samples are bridged, 16 are not
+    img3 = np.zeros((9, 300), np.uint8)
+    img3[4, 10:100] = 255
+    img3[4, 115:200] = 255                            # 15-px gap
+    _, l15 = o.find_longest_line(img3, 10.0, 4.0, 15.0)
+    img3[4, 115] = 0                                  # 16-px gap
+    _, l16 = o.find_longest_line(img3, 10.0, 4.0, 15.0)
+    assert abs(np.sqrt(l15) - 190.0) < 0.01 and abs(np.sqrt(l16) - 90.0) < 0.01   # sub-pixel steps end just inside the last white pixel
+
+
+def test_get_centre_half_pixel_midpoints():
+    img = np.zeros((30, 30), np.uint8)
+    img[10:14, 10:15] = 255                           # 5 wide, 4 tall
+    cx, cy = o.get_centre(img, 10.0, 10.0)
+    assert (cx, cy) == (12.0, 11.5)
+    assert o.get_centre(img, 0.0, 0.0) == (0.0, 0.0)
+
+
+def test_find_scale_width_and_ladder():
+    img = np.full((60, 200), 255, np.uint8)
+    img[30, 40:161] = 0
+    img[30:37, 40] = 0
+    img[30:37, 160] = 0
+    r = o.find_scale_width(300, 100, 25, img)
+    assert r is not None and r[1] == (41, 30, 159, 30) and r[0] == 300 / 118
+    assert o.find_scale_width(300, 100, 3, img) is None            # y < MIN_SCALE_VERTICAL_BAR_HEIGHT
+    assert o.find_scale_width(300, 100, 24, img) is None           # bar row is not within round(20/640*w)=6 rows [y, y+6)
+    assert o.calc_meters_to_px_ratio([], img) is None
+    assert o.calc_meters_to_px_ratio([(300, 100, 25)], img) == 300 / 118
+    assert o.calc_meters_to_px_ratio([(300, 100, 25), (7, 5, 5)], img) == 300 / 118
+    assert o.calc_meters_to_px_ratio([(300, 100, 25), (100, 100, 26)], img) == (300 / 118 + 100 / 118) / 2.0
+    # ticks that reach below the image do not count (reference: unchecked read; oracle: non-zero)
+    img2 = np.full((33, 200), 255, np.uint8)
+    img2[30, 40:161] = 0
+    img2[30:33, 40] = 0
+    img2[30:33, 160] = 0
+    assert o.find_scale_width(300, 100, 25, img2) is None
+
+
+def test_closed_and_invalid_samples():
+    assert fx.MANIFEST["convolution_png"]["kind"] == "invalid_geometry"
+    for stem in ("a_point_png", "line_angle_png"):
+        frame, e, _ = fx.load_fixture(stem)
+        assert e["kind"] == "closed" and o.crop_to_map(frame) is None
+        assert o.button_red_pixels(frame) == e["red_pixels"]
+
+
+@pytest.mark.parametrize("stem", sorted(APPENDIX_B))
+def test_appendix_b_counts(stem):
+    frame, e, g = fx.load_fixture(stem)
+    n_marker, n_mask, skipped, rounds, steps, n_lines = APPENDIX_B[stem]
+    c = o.crop_to_map(frame, True)
+    assert c is not None and tuple(c["roi"]) == tuple(e["map_rect"])
+    iso = o.isolate_map_markers(c["cropped_map"])
+    assert int(iso.any(axis=2).sum()) == n_marker
+    mask = o.mask_marker_lines(iso)
+    assert int((mask == 255).sum()) == n_mask and set(np.unique(mask)) <= {0, 255}
+    lines, st = o.find_lines(mask, 15)
+    assert (st["skipped"], st["rounds"], st["steps"], len(lines)) == (skipped, rounds, steps, n_lines)
+    if stem in APPENDIX_B_LINES:
+        assert np.allclose(lines, np.array(APPENDIX_B_LINES[stem], np.float32), rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("stem", fx.OPEN_STEMS)
+def test_oracle_reproduces_committed_goldens(stem):
+    frame, e, g = fx.load_fixture(stem)
+    res = o.process_frame(frame, stages=0x1, want_images=True)
+    assert res["map_open"] == 1 and o.button_red_pixels(frame) == e["red_pixels"]
+    assert np.array_equal(np.flatnonzero(res["lsd"].reshape(-1) == 255).astype(np.uint32), g["mask_idx"])
+    assert np.array_equal(res["lines"], g["lines"])
+    assert (res["rounds"], res["steps"]) == (e["rounds"], e["steps"])
+    lines22, _ = o.find_lines(res["lsd"], 22)
+    assert np.array_equal(lines22, g["lines_gap22"])
+
+
+@pytest.mark.parametrize("stem", ["point_intersect_png", "points_intersect_png"])
+def test_real_scale_bars(stem):
+    frame, e, g = fx.load_fixture(stem)
+    res = o.process_frame(frame, stages=0xF, anchors=e["anchors"], scales_start_y=e["scales_start_y"], want_images=True)
+    assert res["mpx"] == e["mpx"] and 3.7 < res["mpx"] < 4.0       # 300 m over ~78 px, 900 m over ~237 px at 1440p
+    der = g["derived"]
+    for i, ln in enumerate(res["lines"]):
+        length, meters = o.marker_new(ln, res["mpx"])
+        assert abs(length - der[i, 0]) <= 1e-4 and abs(meters - der[i, 1]) <= 1e-4
+        assert abs(o.marker_angle(ln) - der[i, 2]) <= 1e-4
+
+
+def test_synthetic_frames_are_deterministic_and_marker_free_terrain(built):
+    from squad_mortar_helper_amd import synth
+    a, ia = synth.make_frame(1024, 768, 3)
+    b, ib = synth.make_frame(1024, 768, 3)
+    assert np.array_equal(a, b) and ia == ib
+    blank, _ = synth.make_frame(1024, 768, 5, n_lines=0)
+    res = o.process_frame(blank, stages=0x1)
+    assert res["map_open"] == 1 and res["n_mask_px"] == 0 and res["n_lines"] == 0
+    closed, _ = synth.make_frame(1024, 768, 5, map_open=False)
+    assert o.process_frame(closed)["map_open"] == 0
