@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
     ap.add_argument("--stages", type=lambda s: int(s, 0), default=0xF)
-    ap.add_argument("--cpu-sample", type=int, default=64, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     args = ap.parse_args()
 
@@ -171,7 +171,7 @@ def main():
     if args.cpu_sample > 0:
         from oracle import oracle as orc   # CPU baseline leg only (checker, never the product path)
         k = min(args.cpu_sample, n)
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, k)              # threads actually used: one frame per thread at a time
         a = np.zeros((k, 3, 3), np.uint32)
         for i in range(k):
             for j, s in enumerate(infos[i]["anchors"][:3]):

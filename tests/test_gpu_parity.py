@@ -174,8 +174,8 @@ def test_ocr_neighbourhood_and_scales_semantics(vision):
     brq[qh - 2, qw - 2, :3] = 255
     brq[5, qw - 1, :3] = 230
     brq[0, 0, :3] = 210
-    brq[10:14, 10:30, :3] = (3, 0, 4)                             # luma 0.9 -> 0  => scales 0
-    brq[20:24, 10:30, :3] = (0, 2, 0)                             # luma 1.43 -> 1 => scales 255
+    brq[10:14, 10:30, :3] = (4, 0, 3)                             # BGR: luma 0.2126*3 + 0.0722*4 = 0.93 -> 0 => scales 0
+    brq[20:24, 10:30, :3] = (0, 2, 0)                             # luma 0.7152*2 = 1.43 -> 1 => scales 255
     tint = brq[40:60, 40:90, :3].astype(np.int16)
     tint[..., 0] += rng.integers(0, 14, tint.shape[:2])           # max-min up to 13 straddles the similarity threshold (12)
     brq[40:60, 40:90, :3] = np.clip(tint, 0, 255).astype(np.uint8)
