@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmh_vision_hip.so")
+LIB_PATH = os.environ.get("SMH_VISION_HIP_LIB") or os.path.join(_HERE, "libsmh_vision_hip.so")   # env override: diagnostic builds only
 
 MAX_LINES = 32
 MAX_SCALES = 3

@@ -11,7 +11,8 @@
 //   k_map_pass    one streaming pass over the map ROI: ui_map RGBA + marker colour predicate +
 //                 L1 radius-1 dilation -> u8 mask + bit-packed mask + bbox   (lib.rs:137-171,253-280,357-375)
 //   k_brq_pass    bottom-right quadrant: ocr_preprocess + find_scales_preprocess (lib.rs:173-251)
-//   k_lsd         lsd::find_lines::<32> incl. find_longest_line, one workgroup per frame,
+//   k_lsd         lsd::find_lines::<32> incl. find_longest_line, one workgroup per frame, speculative
+//                 candidate groups, batched ray walking,
 //                 mask window resident in LDS                                (lsd.rs:5-107, lib.rs:387-449)
 //   k_scale_ratio calc_meters_to_px_ratio / find_scale_width                 (src/vision/mpx_ratio.rs:3-134)
 //   k_finalize    derived marker outputs                                     (src/ui/mod.rs:131-140, markers.rs:98)
@@ -386,7 +387,24 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_lsd: lsd::find_lines::<32> with find_longest_line inlined; one workgroup per frame.
+// k_lsd: lsd::find_lines::<32> (vision-common/src/lsd.rs:60-107) with find_longest_line
+// (vision-cpu/src/lib.rs:387-449) inlined; one 1024-thread workgroup per frame.
+//
+// The reference scans the mask in raster order and, per surviving white pixel, casts 3600 rays;
+// on its CUDA back-end that is one kernel launch + sync per pixel.  Here the whole scan runs
+// on-device against a window of the bit-packed mask held in LDS:
+//   * candidates: the non-zero mask words are compacted in raster order; each thread owns one word
+//     and keeps its "survivor" bits (white pixels not within sqrt(50) px of an accepted line);
+//     new lines only ever clear bits, so the proximity tests are done once per (pixel, line).
+//   * speculation: the next LSD_C survivors are ray-cast TOGETHER (a candidate's ray result does not
+//     depend on the lines accepted before it, only whether it is visited does), then resolved in
+//     raster order; a candidate invalidated by a line accepted earlier in the same group is dropped.
+//   * rays: phase A walks every ray for its first 32 samples with no divergence (positions by
+//     repeated f32 addition as in the reference, 32 LDS reads in flight, the gap state machine runs
+//     on the 32-bit whiteness mask); almost all rays end there.  Survivors (rays running along a
+//     marker line) are compacted into an LDS queue and finished in phase B with full lanes.
+// Results are bit-identical to the sequential reference, including the max-len^2 / highest-angle
+// tie rule and the sample counts.
 // ------------------------------------------------------------------------------------------------
 struct RayDir { uint32_t dx, dy; };
 __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
@@ -395,33 +413,49 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 
 #define LSD_BS 1024
 #define LSD_NW (LSD_BS / 64)
-#define LSD_RPT ((SMH_LSD_RAYS + LSD_BS - 1) / LSD_BS)
-#define LSD_LIST_CAP 4096u
-#define LSD_WIN_WORDS_CAP 35840u                       // 140 KiB window + 16 KiB list + static < 160 KiB
-#define LSD_DYN_LDS_BYTES ((LSD_WIN_WORDS_CAP + LSD_LIST_CAP) * 4u)
+#define LSD_C 8u                                   // candidates ray-cast per group
+#define LSD_GROUPS ((SMH_LSD_RAYS + 63) / 64)      // 64-ray units per candidate (57)
+#define LSD_UNITS (LSD_C * LSD_GROUPS)
+#define LSD_LIST_CAP 2048u
+#define LSD_QCAP 2048u
+#define LSD_A_BATCHES 2u                            // 32-sample batches walked in phase A before a ray is queued
+#define LSD_WIN_WORDS_CAP 30000u                   // 1080p whole-ROI padded window = 824 x 35 = 28840 words
+#define LSD_DYN_LDS_BYTES ((LSD_WIN_WORDS_CAP + LSD_LIST_CAP + 2u * LSD_QCAP) * 4u)
 
-// Window of the bit-packed mask: rows [wy0, wy0+wrows), words [ww0, ww0+wwords) of each row.
-// Every set bit of the mask lies inside the window (it is the bounding box of the set bits), so a
-// read outside it is 0.  `p` points at LDS (window copy) or at global memory (whole mask).
-struct MaskView {
+// Window of the bit-packed mask.  In LDS it is the bounding box of the set bits plus a one-word /
+// one-row border of zeros, and coordinates are clamped into it, so any read outside the box yields
+// 0 without a branch.  In the global-memory fallback (box larger than LDS) it is the whole mask.
+struct Win {
 	const uint32_t *p;
-	uint32_t pitch, wy0, ww0, wrows, wwords, xoff, w, h;
-	__device__ __forceinline__ uint32_t at(uint32_t xi, uint32_t yi) const {   // 0 <= xi < w, 0 <= yi < h
-		const uint32_t X = xi + xoff, ry = yi - wy0, rc = (X >> 5) - ww0;
-		uint32_t v = 0;
-		if (ry < wrows && rc < wwords) v = (p[ry * pitch + rc] >> (X & 31u)) & 1u;
-		return v;
-	}
+	uint32_t pitch4;                  // row pitch in BYTES
+	int y_lo, xbias;
+	uint32_t rows_hi, cols_hi;
+	uint32_t w, h;
+	float wf, hf;
 };
 
-// find_line_in_image closure, vision-cpu/src/lib.rs:388-432 (literal).
-__device__ __forceinline__ void cast_ray(const MaskView &m, float xs, float ys, float max_gap, float dx, float dy, float &xe, float &ye,
-                                         uint32_t &steps) {
+// One sample.  Coordinates below/left of the window wrap to huge unsigned values and clamp to the far
+// (zero) border just like coordinates beyond it, so each axis costs one v_min_u32.  24-bit multiply:
+// rows * pitch4 < 2^24 for any supported frame.
+__device__ __forceinline__ uint32_t win_raw(const Win &m, int xi, int yi) {   // bit 0 = the pixel, upper bits garbage
+	const uint32_t ry = min((uint32_t)(yi - m.y_lo), m.rows_hi);
+	const int X = xi + m.xbias;
+	const uint32_t rc = min((uint32_t)(X >> 5), m.cols_hi);
+	const char *row = (const char *)m.p + __umul24(ry, m.pitch4);
+	const uint32_t word = *(const uint32_t *)(row + (rc << 2));
+	return word >> ((uint32_t)X & 31u);
+}
+__device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) { return win_raw(m, xi, yi) & 1u; }
+
+__device__ __forceinline__ bool in_image(const Win &m, float x, float y) { return x >= 0.0f && y >= 0.0f && x < m.wf && y < m.hf; }
+
+// find_line_in_image closure, vision-cpu/src/lib.rs:388-432, literally.  Used for max_gap values the
+// batched walker does not cover (<= 0, NaN, huge) -- never in production (max_gap = 15).
+__device__ void cast_ray_literal(const Win &m, float xs, float ys, float max_gap, float dx, float dy, float &xe, float &ye, uint32_t &steps) {
 	float x = xs, y = ys, xo = 0.0f, yo = 0.0f, g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
-	const float wf = (float)m.w, hf = (float)m.h;
-	while (x >= 0.0f && y >= 0.0f && x < wf && y < hf) {
+	while (in_image(m, x, y)) {
 		++steps;
-		if (m.at((uint32_t)x, (uint32_t)y)) {
+		if (win_bit(m, (int)x, (int)y)) {
 			g0 = 0.0f; g1 = 0.0f; g2 = 0.0f;
 		} else if (g0 >= max_gap) {
 			x = g1; y = g2;
@@ -436,16 +470,134 @@ __device__ __forceinline__ void cast_ray(const MaskView &m, float xs, float ys, 
 	}
 	xe = xs; ye = ys;
 	const uint32_t xi = f2u(x), yi = f2u(y);
-	if (xi < m.w && yi < m.h && m.at(xi, yi) == 0u) { xe = x - dx; ye = y - dy; }
+	if (xi < m.w && yi < m.h && win_bit(m, (int)xi, (int)yi) == 0u) { xe = x - dx; ye = y - dy; }
+}
+
+// State of a ray between 32-sample batches.  The reference's gap tuple (count, saved_x, saved_y) is
+// kept as: g = consecutive non-white samples so far, and where that run started as (offsets at the
+// start of ITS batch, index in that batch, first step of that batch) -- the saved position is
+// re-derived by replaying the additions only for rays that can still win (see ray_engine).
+struct RayState {
+	float bxo, byo;        // x_offset / y_offset at the start of the current batch
+	uint32_t k0, g;        // samples taken before this batch; current non-white run length
+	float gxo, gyo;        // offsets at the start of the batch in which the current run began
+	uint32_t gj, gk0;      // ... its index in that batch, and that batch's first step
+	uint32_t nexit;        // status 2: number of in-image samples of the last batch
+};
+enum { RAY_CONTINUE = 0, RAY_ABORTED = 1, RAY_LEFT_IMAGE = 2 };
+
+// One batch of up to 32 samples.  T = smallest integer >= max_gap (>= 1): the reference aborts at a
+// non-white sample when the run count before it is >= max_gap, i.e. at the (T+1)-th consecutive
+// non-white sample, and restores the position where that run started.
+//   RAY_ABORTED    : the run started at global step s.gk0 + s.gj; samples taken = *steps
+//   RAY_LEFT_IMAGE : the first out-of-image position is step s.k0 + s.nexit
+__device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float dx, float dy, uint32_t T, RayState &s, uint32_t &steps) {
+	float xo = s.bxo, yo = s.byo, x = 0.0f, y = 0.0f;
+	uint32_t Wm = 0;
+	// 4 x 8 samples: eight LDS reads in flight per wave keep the register footprint small enough for
+	// 16 waves per CU; the whiteness bits are shifted in from the top (sample j ends up in bit j).
+	uint32_t taken = 0;
+#pragma unroll 1
+	for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			x = xo + xs; y = yo + ys;                   // x = x_offset + x_start
+			Wm = __builtin_amdgcn_alignbit(win_raw(m, (int)x, (int)y), Wm, 1);   // shifts in bit 0 of its first operand
+			xo += dx; yo += dy;                         // x_offset += dx
+		}
+		taken += 8u;
+		// Early out: when the most recent T+1 samples of EVERY lane of the wave are non-white, every
+		// ray of the wave has aborted inside this batch (most rays die T+1 samples after leaving the
+		// blob they start in), so the remaining samples of the batch cannot matter.
+		if (taken > T && taken < 32u && __all((Wm >> (31u - T)) == 0u)) break;
+	}
+	Wm >>= 32u - taken;                                 // sample j -> bit j
+	// x(j) and y(j) are monotonic in j, so the in-image samples are a prefix: test the last one.
+	uint32_t n = taken;
+	if (!in_image(m, x, y)) {
+		float rx = s.bxo, ry = s.byo;
+#pragma unroll 1
+		for (n = 0; n < taken; ++n) {
+			if (!in_image(m, rx + xs, ry + ys)) break;
+			rx += dx; ry += dy;
+		}
+	}
+	const uint32_t valid = n >= 32u ? 0xFFFFFFFFu : ((1u << n) - 1u);
+	const uint32_t Wv = Wm & valid, Z = ~Wm & valid;
+	const uint32_t g = s.g;
+	if (T <= 31u) {
+		// Branch-free gap state machine: prepend the g carried-in non-white samples, then find the first
+		// run of T+1 consecutive non-white samples by AND-ing shifted copies (run-length doubling).
+		const unsigned long long Z64 = ((unsigned long long)Z << g) | ((1ull << g) - 1ull);
+		unsigned long long R = Z64;
+		const uint32_t L = T + 1u;
+		uint32_t have = 1u;
+		while (have * 2u <= L) { R &= R >> have; have *= 2u; }
+		if (L > have) R &= R >> (L - have);
+		if (R) {
+			const uint32_t p = (uint32_t)__builtin_ctzll(R);    // start of that run (a run start, or 0 = carried in)
+			if (p >= g) { s.gxo = s.bxo; s.gyo = s.byo; s.gj = p - g; s.gk0 = s.k0; }
+			steps += s.k0 + (p + T - g) + 1u;
+			return RAY_ABORTED;
+		}
+		if (n < taken) { steps += s.k0 + n; s.nexit = n; return RAY_LEFT_IMAGE; }
+		// no abort in a full batch with T <= 31 implies at least one white sample (and taken == 32: the
+		// early out above is taken only when every lane aborts)
+		const uint32_t msb = 31u - (uint32_t)__builtin_clz(Wv);
+		s.g = 31u - msb;
+		if (s.g) { s.gxo = s.bxo; s.gyo = s.byo; s.gj = msb + 1u; s.gk0 = s.k0; }
+	} else {
+		uint32_t rem = valid, gg = g;
+		while (rem) {
+			const uint32_t pos = (uint32_t)__builtin_ctz(rem);
+			if ((Wv >> pos) & 1u) {                         // white run: the gap state resets
+				gg = 0;
+				const uint32_t z = Z & rem;
+				if (!z) break;
+				rem &= 0xFFFFFFFFu << __builtin_ctz(z);
+			} else {                                        // non-white run [pos, end)
+				const uint32_t wr = Wv & rem;
+				const uint32_t end = wr ? (uint32_t)__builtin_ctz(wr) : n;
+				const uint32_t len = end - pos;
+				if (gg == 0) { s.gxo = s.bxo; s.gyo = s.byo; s.gj = pos; s.gk0 = s.k0; }
+				if (gg + len > T) {                         // "gap didn't close, abort"
+					steps += s.k0 + pos + (T - gg) + 1u;
+					return RAY_ABORTED;
+				}
+				gg += len;
+				if (end >= 32u) break;
+				rem &= 0xFFFFFFFFu << end;
+			}
+		}
+		if (n < 32u) { steps += s.k0 + n; s.nexit = n; return RAY_LEFT_IMAGE; }
+		s.g = gg;
+	}
+	s.bxo = xo; s.byo = yo; s.k0 += 32u;
+	return RAY_CONTINUE;
+}
+
+// Exact end point of a finished ray (vision-cpu/src/lib.rs:415-429), by replaying the additions.
+__device__ __forceinline__ void ray_endpoint(const Win &m, int status, const RayState &s, float xs, float ys, float dx, float dy, float &xe, float &ye) {
+	if (status == RAY_ABORTED) {                            // restore the gap start; that pixel is in the image and 0
+		float gx = s.gxo, gy = s.gyo;
+		for (uint32_t k = 0; k < s.gj; ++k) { gx += dx; gy += dy; }
+		xe = (gx + xs) - dx; ye = (gy + ys) - dy;
+	} else {                                                // walked out of the image
+		float rx = s.bxo, ry = s.byo;
+		for (uint32_t k = 0; k < s.nexit; ++k) { rx += dx; ry += dy; }
+		const float px = rx + xs, py = ry + ys;
+		xe = xs; ye = ys;
+		const uint32_t xi = f2u(px), yi = f2u(py);          // get_pixel_checked(x as u32, y as u32) == Some(0)
+		if (xi < m.w && yi < m.h && win_bit(m, (int)xi, (int)yi) == 0u) { xe = px - dx; ye = py - dy; }
+	}
 }
 
 // get_centre, vision-common/src/lsd.rs:5-44 (coordinates clamped like the oracle).
-__device__ __forceinline__ uint32_t white_at(const MaskView &m, float fx, float fy) {
-	uint32_t xi = f2u(fx), yi = f2u(fy);
-	xi = min(xi, m.w - 1u); yi = min(yi, m.h - 1u);
-	return m.at(xi, yi);
+__device__ __forceinline__ uint32_t white_at(const Win &m, float fx, float fy) {
+	const uint32_t xi = min(f2u(fx), m.w - 1u), yi = min(f2u(fy), m.h - 1u);
+	return win_bit(m, (int)xi, (int)yi);
 }
-__device__ void get_centre(const MaskView &m, float px, float py, float &ox, float &oy) {
+__device__ void get_centre(const Win &m, float px, float py, float &ox, float &oy) {
 	float left = px;
 	while (left > 0.0f && fabsf(left - px) < SMH_LSD_CENTRE_REACH && white_at(m, left, py)) left -= 1.0f;
 	float right = px;
@@ -470,45 +622,227 @@ __device__ __forceinline__ bool near_line(float x, float y, float x0, float y0, 
 	return ex * ex + ey * ey < SMH_LSD_PROXIMITY_SQ;
 }
 
+// Diagnostic build only (-DSMH_LSD_PROFILE): thread 0 accumulates s_memtime deltas per phase and stores
+// them in the tail of the record's `meters` array (never read by product code in that build).
+#ifdef SMH_LSD_PROFILE
+#define PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = __builtin_amdgcn_s_memtime();
+#define PROF_MARK(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[i] += _n - prof_last; prof_last = _n; } while (0)
+#define PROF_STORE(res) do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) ((unsigned long long *)(res)->meters)[24 + _i] = prof_t[_i]; } while (0)
+#define PROF_ARG , prof_t
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_STORE(res)
+#define PROF_ARG
+#endif
+
 struct LsdShared {
-	uint64_t red[LSD_NW];
-	uint32_t cand[LSD_NW];
+	unsigned long long cand_best[LSD_C];   // max over rays of (len^2 bits << 32 | ray index): ties -> highest angle
+	unsigned long long unit_key[LSD_UNITS];
+	float unit_end[LSD_UNITS][2];
+	uint32_t unit_kmax[LSD_UNITS];
+	float cand_pt[LSD_C][2];
+	float cand_end[LSD_C][2];
+	uint32_t cand_steps[LSD_C];
+	uint32_t cand_kmax[LSD_C];
+	uint32_t cand_key[LSD_C];
 	uint32_t scan[LSD_NW];
-	float best[2];
-	uint32_t segnext;
-	unsigned long long steps;
+	uint32_t qtail, segnext, unit_next;
 	float lines[SMH_LSD_MAX_LINES][4];
 };
 
-// One find_longest_line round over all 3600 rays (vision-cpu/src/lib.rs:434-446): max len^2,
-// ties -> highest ray index.  Returns the packed key (len^2 bits << 32 | index); the end point
-// goes through sh.best.  Block-uniform result.
-__device__ __forceinline__ uint64_t ray_round(const MaskView &m, LsdShared &sh, float ptx, float pty, float max_gap, const float *rdx,
-                                              const float *rdy, uint32_t &steps) {
+// Wave-wide reductions on DPP lane permutes (no LDS round trips): butterflies inside each 16-lane row,
+// then the four row results are combined on the scalar unit.  All 64 lanes must be active.
+#define SMH_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ uint32_t wave_max32_dpp(uint32_t v) {
+	v = max(v, SMH_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
+	v = max(v, SMH_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
+	v = max(v, SMH_DPP(v, 0x141));   // row_half_mirror
+	v = max(v, SMH_DPP(v, 0x140));   // row_mirror
+	return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+	           max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_sum32_dpp(uint32_t v) {
+	v += SMH_DPP(v, 0xB1);
+	v += SMH_DPP(v, 0x4E);
+	v += SMH_DPP(v, 0x141);
+	v += SMH_DPP(v, 0x140);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+	       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// find_longest_line for nc candidates at once (start points in sh.cand_pt).  On return (after a
+// barrier) sh.cand_best / cand_end / cand_steps hold, per candidate, the winning key, its end point
+// and the number of mask samples all 3600 rays took.
+//
+// Only the max-len^2 ray matters.  A ray that aborted with its gap starting at step K ends K-1 unit
+// steps from the start (to within accumulated f32 rounding < 0.25 for the longest possible ray), so
+// pass 1 only records K per ray and the largest K per 64-ray unit; the exact end point (a replay of
+// the additions) is computed in pass 2, and only for the rays of units whose K comes within 2 of the
+// candidate's largest K.  Every ray that could win or tie is therefore still evaluated exactly, with
+// the reference's arithmetic; rays that left the image (which may legitimately end with length 0)
+// and the long rays of phase B are always evaluated exactly.
+__device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_t nc, float max_gap, unsigned long long *prof_t = nullptr) {
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	uint64_t best = 0;
-	float bxe = ptx, bye = pty;
+#ifdef SMH_LSD_PROFILE
+	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
+	const bool fast = max_gap > 0.0f && max_gap <= 60000.0f;
+	const uint32_t T = fast ? (uint32_t)ceilf(max_gap) : 0u;
+	const uint32_t nunits = nc * LSD_GROUPS;
+
+	// ---- pass 1: first LSD_A_BATCHES x 32 samples of every ray; unit = (candidate, 64 consecutive angles).
+	// Units cost one or two batches depending on the scene, so waves pull them from a shared counter
+	// (the next unit and its ray directions are fetched while the current one is walked).
+	uint32_t u = wave;                                     // first unit is static; sh.unit_next starts at LSD_NW
+	uint32_t un = 0;
+	if (lane == 0) un = atomicAdd(&sh.unit_next, 1u);
+	un = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
+	RayDir nd = g_ray_table[min((u % LSD_GROUPS) * 64u + lane, (uint32_t)SMH_LSD_RAYS - 1u)];
+	for (; u < nunits; ) {
+		const uint32_t c = u / LSD_GROUPS, i = (u - c * LSD_GROUPS) * 64u + lane;
+		const bool valid = i < SMH_LSD_RAYS;
+		const float dx = __uint_as_float(nd.dx), dy = __uint_as_float(nd.dy);
+		const uint32_t ucur = u;
+		u = un;
+		if (u < nunits) {
+			nd = g_ray_table[min((u % LSD_GROUPS) * 64u + lane, (uint32_t)SMH_LSD_RAYS - 1u)];
+			if (lane == 0) un = atomicAdd(&sh.unit_next, 1u);
+			un = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
+		}
+		const float xs = sh.cand_pt[c][0], ys = sh.cand_pt[c][1];
+		float xe = xs, ye = ys;
+		uint32_t steps = 0;
+		int status = RAY_ABORTED;                          // invalid lanes: "finished", K = 0
+		bool exact = false;                                // end point computed in this pass
+		RayState s = {0.0f, 0.0f, 0u, 0u, 0.0f, 0.0f, 0u, 0u, 0u};
+		if (valid) {
+			if (fast) {
+				status = RAY_CONTINUE;
+#pragma unroll 1
+				for (uint32_t bi = 0; bi < LSD_A_BATCHES && status == RAY_CONTINUE; ++bi) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+			} else {
+				cast_ray_literal(m, xs, ys, max_gap, dx, dy, xe, ye, steps);
+				exact = true;
+			}
+		}
+		const uint64_t sv = __ballot(status == RAY_CONTINUE);
+		if (sv) {
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(&sh.qtail, (uint32_t)__popcll(sv));
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			const uint32_t slot = base + (uint32_t)__popcll(sv & ((1ull << lane) - 1ull));
+			if (status == RAY_CONTINUE && slot >= LSD_QCAP) {      // queue full: finish this ray here, exactly
+				while (status == RAY_CONTINUE) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+				ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye);
+				exact = true;
+			} else if (status == RAY_CONTINUE) {
+				queue[2u * slot] = (c << 16) | i;
+				queue[2u * slot + 1u] = s.g | (s.gj << 16) | ((s.gk0 >> 5) << 24);
+			}
+		}
+		const bool fin = valid && status != RAY_CONTINUE;
+		if (fin && !exact && status == RAY_LEFT_IMAGE) { ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye); exact = true; }
+		// exactly evaluated rays (rare) compete right away
+		if (__any(fin && exact)) {
+			unsigned long long key = 0;
+			if (fin && exact) {
+				const float ddx = xs - xe, ddy = ys - ye;       // p0.distance_sqr(&p1)
+				key = ((unsigned long long)__float_as_uint(ddx * ddx + ddy * ddy) << 32) | i;
+			}
+			const unsigned long long wkey = wave_max64(key);
+			if (lane == 0) atomicMax(&sh.cand_best[c], wkey);
+			if (key != 0ull && key == wkey) { sh.unit_key[ucur] = key; sh.unit_end[ucur][0] = xe; sh.unit_end[ucur][1] = ye; }
+		}
+		const uint32_t Kw = wave_max32_dpp((fin && !exact) ? s.gk0 + s.gj : 0u);
+		const uint32_t wsteps = wave_sum32_dpp(steps);
+		if (lane == 0) { sh.unit_kmax[ucur] = Kw; atomicMax(&sh.cand_kmax[c], Kw); atomicAdd(&sh.cand_steps[c], wsteps); }
+	}
+	__syncthreads();
+	PROF_MARK(3);
+
+	// ---- phase B: the few long rays, packed 64 to a wave; always exact ----
+	const uint32_t Q = min(sh.qtail, LSD_QCAP);
+#ifdef SMH_LSD_PROFILE
+	if (prof_t) { prof_t[6] += sh.qtail; prof_t[7] += 1; }
+#endif
+	unsigned long long bkey[2] = {0ull, 0ull};
+	float bxe[2] = {0.0f, 0.0f}, bye[2] = {0.0f, 0.0f};
+	uint32_t bc[2] = {0u, 0u};
 #pragma unroll
-	for (int j = 0; j < LSD_RPT; ++j) {
-		const uint32_t i = tid + LSD_BS * j;
-		if (i < SMH_LSD_RAYS) {
-			float xe, ye;
-			cast_ray(m, ptx, pty, max_gap, rdx[j], rdy[j], xe, ye, steps);
-			const float ddx = ptx - xe, ddy = pty - ye;
-			const float len = ddx * ddx + ddy * ddy;
-			const uint64_t key = ((uint64_t)__float_as_uint(len) << 32) | i;
-			if (key > best) { best = key; bxe = xe; bye = ye; }
+	for (int r = 0; r < 2; ++r) {                          // LSD_QCAP == 2 * LSD_BS
+		const uint32_t e = tid + (uint32_t)r * LSD_BS;
+		if (e < Q) {
+			const uint32_t id = queue[2u * e], st = queue[2u * e + 1u];
+			const uint32_t c = id >> 16, i = id & 0xFFFFu;
+			const float dx = __uint_as_float(g_ray_table[i].dx), dy = __uint_as_float(g_ray_table[i].dy);
+			const float xs = sh.cand_pt[c][0], ys = sh.cand_pt[c][1];
+			RayState s;
+			s.g = st & 0xFFFFu; s.gj = (st >> 16) & 31u; s.gk0 = (st >> 24) << 5; s.k0 = 32u * LSD_A_BATCHES; s.nexit = 0u;
+			float xo = 0.0f, yo = 0.0f;
+			s.gxo = 0.0f; s.gyo = 0.0f;
+			for (uint32_t k = 0; k < 32u * LSD_A_BATCHES; ++k) {      // replay the additions of pass 1
+				if (k == s.gk0) { s.gxo = xo; s.gyo = yo; }
+				xo += dx; yo += dy;
+			}
+			s.bxo = xo; s.byo = yo;
+			float xe = xs, ye = ys;
+			uint32_t steps = 0;
+			int status = RAY_CONTINUE;
+			while (status == RAY_CONTINUE) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+			ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye);
+			const float ddx = xs - xe, ddy = ys - ye;
+			const unsigned long long key = ((unsigned long long)__float_as_uint(ddx * ddx + ddy * ddy) << 32) | i;
+			bkey[r] = key; bxe[r] = xe; bye[r] = ye; bc[r] = c;
+			atomicMax(&sh.cand_best[c], key);
+			atomicAdd(&sh.cand_steps[c], steps);
+			if (status == RAY_ABORTED) atomicMax(&sh.cand_kmax[c], s.gk0 + s.gj);   // raises the bar for pass 2
 		}
 	}
-	const uint64_t wbest = wave_max64(best);
-	if (lane == 0) sh.red[wave] = wbest;
 	__syncthreads();
-	uint64_t gbest = 0;
+	PROF_MARK(4);
+
+	// ---- pass 2: exact end points for the units that can still hold the winner ----
+	if (fast) {
+		for (uint32_t u2 = wave; u2 < nunits; u2 += LSD_NW) {
+			const uint32_t c = u2 / LSD_GROUPS;
+			const uint32_t kbar = sh.cand_kmax[c];
+			if (sh.unit_kmax[u2] + 2u < kbar) continue;        // wave-uniform
+			const uint32_t i = (u2 - c * LSD_GROUPS) * 64u + lane;
+			const bool valid = i < SMH_LSD_RAYS;
+			const RayDir d = g_ray_table[min(i, (uint32_t)SMH_LSD_RAYS - 1u)];
+			const float dx = __uint_as_float(d.dx), dy = __uint_as_float(d.dy);
+			const float xs = sh.cand_pt[c][0], ys = sh.cand_pt[c][1];
+			float xe = xs, ye = ys;
+			uint32_t steps = 0;
+			int status = RAY_CONTINUE;
+			RayState s = {0.0f, 0.0f, 0u, 0u, 0.0f, 0.0f, 0u, 0u, 0u};
+			if (valid) {
+#pragma unroll 1
+				for (uint32_t bi = 0; bi < LSD_A_BATCHES && status == RAY_CONTINUE; ++bi) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+			}
+			unsigned long long key = 0;
+			if (valid && status == RAY_ABORTED && s.gk0 + s.gj + 2u >= kbar) {
+				ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye);
+				const float ddx = xs - xe, ddy = ys - ye;
+				key = ((unsigned long long)__float_as_uint(ddx * ddx + ddy * ddy) << 32) | i;
+			}
+			const unsigned long long wkey = wave_max64(key);
+			// a unit may already hold an exact (left-the-image) winner from pass 1: keep the larger
+			if (key != 0ull && key == wkey && key > sh.unit_key[u2]) { sh.unit_key[u2] = key; sh.unit_end[u2][0] = xe; sh.unit_end[u2][1] = ye; }
+			if (lane == 0) atomicMax(&sh.cand_best[c], wkey);
+		}
+	}
+	__syncthreads();
+	// ---- the winning ray of each candidate publishes its end point (keys are unique per ray) ----
 #pragma unroll
-	for (int k = 0; k < LSD_NW; ++k) gbest = max(gbest, sh.red[k]);
-	if (best == gbest && (gbest != 0ull || tid == 0)) { sh.best[0] = bxe; sh.best[1] = bye; }
+	for (int r = 0; r < 2; ++r)
+		if (bkey[r] != 0ull && bkey[r] == sh.cand_best[bc[r]]) { sh.cand_end[bc[r]][0] = bxe[r]; sh.cand_end[bc[r]][1] = bye[r]; }
+	if (tid < nunits) {
+		const uint32_t c = tid / LSD_GROUPS;
+		if (sh.unit_key[tid] != 0ull && sh.unit_key[tid] == sh.cand_best[c]) { sh.cand_end[c][0] = sh.unit_end[tid][0]; sh.cand_end[c][1] = sh.unit_end[tid][1]; }
+	}
 	__syncthreads();
-	return gbest;
 }
 
 template <bool LDSWIN>
@@ -518,58 +852,66 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	smhv_frame_result *res = &b.results[f];
 	const uint32_t *gbits = b.bits + (size_t)f * g.bits_stride_w;
 
-	MaskView m;
-	m.xoff = g.m_xoff; m.w = g.rw; m.h = g.rh;
-	uint32_t *list;
+	Win m;
+	m.w = g.rw; m.h = g.rh; m.wf = (float)g.rw; m.hf = (float)g.rh;
+	uint32_t *list, *queue;
+	uint32_t wy0, ww0, wrows, wwords;   // geometry of the compaction domain (unpadded window)
+	PROF_DECL
 	if (LDSWIN) {
-		m.wy0 = aux.y_min; m.ww0 = aux.w_min;
-		m.wrows = aux.y_max - aux.y_min + 1u; m.wwords = aux.w_max - aux.w_min + 1u;
-		m.pitch = m.wwords;
-		m.p = smem;
-		list = smem + LSD_WIN_WORDS_CAP;
-		const uint32_t wt = m.wrows * m.wwords;
-		for (uint32_t idx = tid; idx < wt; idx += LSD_BS) {
-			const uint32_t r = idx / m.wwords, c = idx - r * m.wwords;
-			smem[idx] = gbits[(size_t)(m.wy0 + r) * g.bits_pitch_w + m.ww0 + c];
+		wy0 = aux.y_min; ww0 = aux.w_min; wrows = aux.y_max - aux.y_min + 1u; wwords = aux.w_max - aux.w_min + 1u;
+		const uint32_t pitch = (wwords + 2u) | 1u;                     // odd pitch: rows spread over the LDS banks
+		m.p = smem; m.pitch4 = pitch * 4u;
+		m.y_lo = (int)wy0 - 1; m.rows_hi = wrows + 1u;
+		m.xbias = (int)g.m_xoff - 32 * ((int)ww0 - 1); m.cols_hi = wwords + 1u;
+		const uint32_t total = (wrows + 2u) * pitch;
+		for (uint32_t idx = tid; idx < total; idx += LSD_BS) {
+			const uint32_t r = idx / pitch, c = idx - r * pitch;
+			uint32_t v = 0;
+			if (r >= 1u && r <= wrows && c >= 1u && c <= wwords) v = gbits[(size_t)(wy0 + r - 1u) * g.bits_pitch_w + ww0 + c - 1u];
+			smem[idx] = v;
 		}
+		list = smem + LSD_WIN_WORDS_CAP;
 	} else {
-		m.wy0 = 0; m.ww0 = 0; m.wrows = g.rh; m.wwords = g.bits_pitch_w; m.pitch = g.bits_pitch_w;
-		m.p = gbits;
+		wy0 = 0; ww0 = 0; wrows = g.rh; wwords = g.bits_pitch_w;
+		m.p = gbits; m.pitch4 = g.bits_pitch_w * 4u;
+		m.y_lo = 0; m.rows_hi = g.rh - 1u;
+		m.xbias = (int)g.m_xoff; m.cols_hi = g.bits_pitch_w - 1u;
 		list = smem;
 	}
-	const uint32_t WT = m.wrows * m.wwords;
-	if (tid == 0) sh.steps = 0ull;
-
-	float rdx[LSD_RPT], rdy[LSD_RPT];
-#pragma unroll
-	for (int j = 0; j < LSD_RPT; ++j) {
-		const uint32_t i = min(tid + LSD_BS * j, (uint32_t)SMH_LSD_RAYS - 1u);
-		rdx[j] = __uint_as_float(g_ray_table[i].dx);
-		rdy[j] = __uint_as_float(g_ray_table[i].dy);
-	}
+	queue = list + LSD_LIST_CAP;
+	const uint32_t WT = wrows * wwords;   // compaction domain: word index wi -> row wi / wwords, column wi % wwords
 	__syncthreads();
-
-	uint32_t steps = 0, rounds = 0, n_lines = 0;
+	// word of the compaction domain
+	auto dom_word = [&](uint32_t wi) -> uint32_t {
+		const uint32_t r = wi / wwords, c = wi - r * wwords;
+		return LDSWIN ? m.p[(r + 1u) * (m.pitch4 >> 2) + c + 1u] : m.p[wi];
+	};
 
 	if (mode == 1) {   // Vision::find_longest_line on an arbitrary point
-		const uint64_t key = ray_round(m, sh, spx, spy, max_gap, rdx, rdy, steps);
+		if (tid < LSD_GROUPS) sh.unit_key[tid] = 0ull;
+		if (tid == 0) { sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
+		__syncthreads();
+		ray_engine(m, sh, queue, 1u, max_gap PROF_ARG);
 		if (tid == 0) {
-			res->lines[0].x0 = spx; res->lines[0].y0 = spy; res->lines[0].x1 = sh.best[0]; res->lines[0].y1 = sh.best[1];
-			res->length_px[0] = (double)__uint_as_float((uint32_t)(key >> 32));
-			res->n_lines = 1; res->rounds = 1;
+			res->lines[0].x0 = spx; res->lines[0].y0 = spy; res->lines[0].x1 = sh.cand_end[0][0]; res->lines[0].y1 = sh.cand_end[0][1];
+			res->length_px[0] = (double)__uint_as_float((uint32_t)(sh.cand_best[0] >> 32));
+			res->n_lines = 1; res->rounds = 1; res->ray_steps = sh.cand_steps[0];
 		}
 		return;
 	}
 
-	uint32_t seg_start = 0;
+	uint32_t rounds = 0, n_lines = 0;
+	unsigned long long steps = 0ull;
+	uint32_t seg_start = 0, cmax = 1u;
 	bool done = false;
+	PROF_MARK(0);   // window load
 	while (!done) {
 		// ---- ordered compaction of the non-zero mask words in [seg_start, WT) into `list` ----
 		const uint32_t range = WT - seg_start;
 		const uint32_t per = (range + LSD_BS - 1u) / LSD_BS;
 		const uint32_t my0 = min(seg_start + tid * per, WT), my1 = min(my0 + per, WT);
 		uint32_t cnt = 0;
-		for (uint32_t wi = my0; wi < my1; ++wi) cnt += m.p[wi] != 0u ? 1u : 0u;
+		for (uint32_t wi = my0; wi < my1; ++wi) cnt += dom_word(wi) != 0u ? 1u : 0u;
 		uint32_t incl = cnt;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
 		if (lane == 63) sh.scan[wave] = incl;
@@ -580,25 +922,26 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		for (int k = 0; k < LSD_NW; ++k) { const uint32_t s = sh.scan[k]; if ((uint32_t)k < wave) wprefix += s; total += s; }
 		uint32_t o = wprefix + incl - cnt;
 		for (uint32_t wi = my0; wi < my1; ++wi)
-			if (m.p[wi] != 0u) {
+			if (dom_word(wi) != 0u) {
 				if (o < LSD_LIST_CAP) list[o] = wi;
 				else if (o == LSD_LIST_CAP) sh.segnext = wi;
 				++o;
 			}
 		__syncthreads();
-		const uint32_t T = min(total, LSD_LIST_CAP);
+		const uint32_t Tn = min(total, LSD_LIST_CAP);
 		const uint32_t segnext = sh.segnext;
+		PROF_MARK(1);   // compaction
 
-		for (uint32_t cbase = 0; cbase < T && !done; cbase += LSD_BS) {
+		for (uint32_t cbase = 0; cbase < Tn && !done; cbase += LSD_BS) {
 			const uint32_t e = cbase + tid;
 			uint32_t surv = 0;
 			float py = 0.0f, px0 = 0.0f;
-			if (e < T) {
+			if (e < Tn) {
 				const uint32_t wi = list[e];
-				surv = m.p[wi];
-				const uint32_t r = wi / m.pitch, c = wi - r * m.pitch;
-				py = (float)(m.wy0 + r);
-				px0 = (float)(int)((m.ww0 + c) * 32u - m.xoff);
+				surv = dom_word(wi);
+				const uint32_t r = wi / wwords, c = wi - r * wwords;
+				py = (float)(wy0 + r);
+				px0 = (float)((int)((ww0 + c) * 32u) - (int)g.m_xoff);
 				for (uint32_t l = 0; l < n_lines && surv; ++l) {
 					const float x0 = sh.lines[l][0], y0 = sh.lines[l][1], x1 = sh.lines[l][2], y1 = sh.lines[l][3];
 					uint32_t s = surv;
@@ -610,59 +953,99 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				}
 			}
 			while (true) {
-				// ---- first surviving white pixel in raster order ----
-				const uint64_t bal = __ballot(surv != 0u);
-				uint32_t key = 0xFFFFFFFFu;
-				if (bal) {
-					const uint32_t src = (uint32_t)__builtin_ctzll(bal);
-					const uint32_t mine = (tid << 5) | (surv ? (uint32_t)__builtin_ctz(surv) : 0u);
-					key = __shfl(mine, src);
-				}
-				if (lane == 0) sh.cand[wave] = key;
+				// ---- the next (up to) LSD_C surviving white pixels in raster order ----
+				const uint32_t pc = __popc(surv);
+				uint32_t pin = pc;
+				for (int o2 = 1; o2 < 64; o2 <<= 1) { const uint32_t t = __shfl_up(pin, o2); if (lane >= (uint32_t)o2) pin += t; }
+				if (lane == 63) sh.scan[wave] = pin;
 				__syncthreads();
-				uint32_t first = 0xFFFFFFFFu;
+				uint32_t wp = 0, tot = 0;
 #pragma unroll
-				for (int k = 0; k < LSD_NW; ++k) first = min(first, sh.cand[k]);
-				if (first == 0xFFFFFFFFu) break;
-				const uint32_t otid = first >> 5, obit = first & 31u;
-				if (tid == otid) surv &= ~(1u << obit);
-				const uint32_t cwi = list[cbase + otid];
-				const uint32_t cr = cwi / m.pitch, cc = cwi - cr * m.pitch;
-				const float cy = (float)(m.wy0 + cr);
-				const float cx = (float)(int)((m.ww0 + cc) * 32u - m.xoff + obit);
+				for (int k = 0; k < LSD_NW; ++k) { const uint32_t s = sh.scan[k]; if ((uint32_t)k < wave) wp += s; tot += s; }
+				if (tot == 0u) break;
+				const uint32_t nc = min(tot, cmax);
+				uint32_t rank = wp + pin - pc;
+				while (surv && rank < cmax) {
+					const uint32_t bit = __builtin_ctz(surv);
+					surv &= surv - 1u;
+					sh.cand_key[rank] = (tid << 5) | bit;
+					++rank;
+				}
+				if (tid < nc * LSD_GROUPS) sh.unit_key[tid] = 0ull;
+				if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; }
+				if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; }
+				__syncthreads();
+				if (tid < nc) {
+					const uint32_t key = sh.cand_key[tid];
+					const uint32_t cwi = list[cbase + (key >> 5)];
+					const uint32_t cr = cwi / wwords, cc = cwi - cr * wwords;
+					const float cy = (float)(wy0 + cr);
+					const float cx = (float)((int)((ww0 + cc) * 32u + (key & 31u)) - (int)g.m_xoff);
+					float ptx, pty;
+					get_centre(m, cx, cy, ptx, pty);
+					sh.cand_pt[tid][0] = ptx; sh.cand_pt[tid][1] = pty;
+				}
+				__syncthreads();
+				PROF_MARK(2);   // chunk filter + candidate selection + centres
+				ray_engine(m, sh, queue, nc, max_gap PROF_ARG);
+#ifdef SMH_LSD_PROFILE
+				prof_last = __builtin_amdgcn_s_memtime();
+#endif
 
-				float ptx, pty;
-				get_centre(m, cx, cy, ptx, pty);
-				const uint64_t gk = ray_round(m, sh, ptx, pty, max_gap, rdx, rdy, steps);
-				++rounds;
-				const float len = __uint_as_float((uint32_t)(gk >> 32));
-				if (len > SMH_LSD_ACCEPT_LEN_SQ) {
-					float ex, ey;
-					get_centre(m, sh.best[0], sh.best[1], ex, ey);
-					if (tid == 0) { sh.lines[n_lines][0] = ptx; sh.lines[n_lines][1] = pty; sh.lines[n_lines][2] = ex; sh.lines[n_lines][3] = ey; }
-					++n_lines;
-					if (n_lines == SMH_LSD_MAX_LINES) { done = true; break; }
+				// ---- resolve in raster order (every thread computes the same thing) ----
+				const uint32_t first_new = n_lines;
+				for (uint32_t c = 0; c < nc; ++c) {
+					const uint32_t key = sh.cand_key[c];
+					const uint32_t cwi = list[cbase + (key >> 5)];
+					const uint32_t cr = cwi / wwords, cc = cwi - cr * wwords;
+					const float cy = (float)(wy0 + cr);
+					const float cx = (float)((int)((ww0 + cc) * 32u + (key & 31u)) - (int)g.m_xoff);
+					bool skip = false;
+					for (uint32_t l = first_new; l < n_lines; ++l)
+						skip = skip || near_line(cx, cy, sh.lines[l][0], sh.lines[l][1], sh.lines[l][2], sh.lines[l][3]);
+					if (skip) continue;                     // the sequential scan would not have visited it
+					++rounds;
+					steps += sh.cand_steps[c];
+					const float len = __uint_as_float((uint32_t)(sh.cand_best[c] >> 32));
+					if (len > SMH_LSD_ACCEPT_LEN_SQ) {
+						float ex, ey;
+						get_centre(m, sh.cand_end[c][0], sh.cand_end[c][1], ex, ey);
+						// every thread stores the same four values (no barrier needed for its own later reads)
+						sh.lines[n_lines][0] = sh.cand_pt[c][0]; sh.lines[n_lines][1] = sh.cand_pt[c][1];
+						sh.lines[n_lines][2] = ex; sh.lines[n_lines][3] = ey;
+						++n_lines;
+						if (n_lines == SMH_LSD_MAX_LINES) { done = true; break; }
+					}
+				}
+				if (done) break;
+				// Speculation width: a line accepted inside a group invalidates the later candidates of that
+				// group near it (wasted ray casts), and acceptances cluster (first pixels of a marker), so the
+				// width restarts at 1 after an acceptance and doubles after every acceptance-free group.
+				cmax = (n_lines != first_new) ? 1u : min(cmax * 2u, LSD_C);
+				PROF_MARK(5);   // resolve
+				for (uint32_t l = first_new; l < n_lines && surv; ++l) {
+					const float x0 = sh.lines[l][0], y0 = sh.lines[l][1], x1 = sh.lines[l][2], y1 = sh.lines[l][3];
 					uint32_t s = surv;
 					while (s) {
 						const uint32_t bit = __builtin_ctz(s);
 						s &= s - 1u;
-						if (near_line(px0 + (float)bit, py, ptx, pty, ex, ey)) surv &= ~(1u << bit);
+						if (near_line(px0 + (float)bit, py, x0, y0, x1, y1)) surv &= ~(1u << bit);
 					}
 				}
 			}
-			__syncthreads();   // sh.cand is rewritten by the next chunk's first search
+			__syncthreads();
 		}
 		if (segnext >= WT) break;
 		seg_start = segnext;
 		__syncthreads();
 	}
-	atomicAdd(&sh.steps, (unsigned long long)steps);
 	__syncthreads();
 	if (tid < n_lines) {
 		res->lines[tid].x0 = sh.lines[tid][0]; res->lines[tid].y0 = sh.lines[tid][1];
 		res->lines[tid].x1 = sh.lines[tid][2]; res->lines[tid].y1 = sh.lines[tid][3];
 	}
-	if (tid == 0) { res->n_lines = n_lines; res->rounds = rounds; res->ray_steps = sh.steps; }
+	if (tid == 0) { res->n_lines = n_lines; res->rounds = rounds; res->ray_steps = steps; }
+	PROF_STORE(res);
 }
 
 __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
@@ -677,15 +1060,10 @@ __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap
 	bool lds = false;
 	if (aux.n_mask_px != 0) {
 		const uint32_t wrows = aux.y_max - aux.y_min + 1u, wwords = aux.w_max - aux.w_min + 1u;
-		lds = wrows * wwords <= LSD_WIN_WORDS_CAP;
-	}
-	if (mode == 1 && aux.n_mask_px == 0) {
-		// empty mask: window degenerates; use the global view (all zeros) for the single round
-		lsd_frame<false>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
-		return;
+		lds = (wrows + 2u) * ((wwords + 2u) | 1u) <= LSD_WIN_WORDS_CAP;
 	}
 	if (lds) lsd_frame<true>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
-	else lsd_frame<false>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+	else lsd_frame<false>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);   // also the empty-mask single-round case
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -787,7 +1165,11 @@ __global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t sta
 			ang = atan2f(ln.y0 - ln.y1, ln.x0 - ln.x1);
 		}
 		res->lines[l] = ln;
-		res->length_px[l] = len; res->meters[l] = met; res->angle[l] = ang;
+		res->length_px[l] = len; res->angle[l] = ang;
+#ifdef SMH_LSD_PROFILE
+		if (l < 24)
+#endif
+		res->meters[l] = met;
 	}
 	if (l == 0) {
 		res->map_open = open ? 1u : 0u;

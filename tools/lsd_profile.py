@@ -1,0 +1,36 @@
+"""Diagnostic: per-phase cycle shares inside k_lsd (needs `make -C squad-mortar-helper_amd/csrc prof`).
+Run with SMH_VISION_HIP_LIB=squad-mortar-helper_amd/libsmh_vision_hip_prof.so python tools/lsd_profile.py"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import squad_mortar_helper_amd as smh
+from squad_mortar_helper_amd import synth
+
+W, H, N = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 256
+host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
+_, infos = synth.make_batch(W, H, N, out=host.numpy())
+d = host.cuda()
+v = smh.HipVision.init(0)
+fb = smh.FrameBatch(v, W, H, N)
+anc = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+fb.enable_timing(True)
+for _ in range(3):
+    fb.run(d.data_ptr(), N, anchors=anc, stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+print("stage ms", fb.stage_ms())
+recs = fb.read_results(0, N)
+names = ["A:batches(+load,compaction)", "A:queue+endpoint", "A:reductions", "phaseA-sync-wait", "phaseB", "resolve+select", "queued_rays", "groups"]
+tot = np.zeros(8)
+rows = []
+for r in recs:
+    raw = np.frombuffer(bytes(r), np.uint8)
+    off = smh._lib.FrameResult.meters.offset + 24 * 8
+    p = np.frombuffer(raw[off:off + 64].tobytes(), np.uint64).astype(np.float64)
+    rows.append((r.rounds, p))
+    tot += p
+cyc = tot[:6].sum()
+print("sum over frames: " + ", ".join("%s %.1f%%" % (n, 100 * t / cyc) for n, t in zip(names[:6], tot[:6])))
+print("queued rays per group: %.1f, groups per frame %.1f" % (tot[6] / max(tot[7], 1), tot[7] / N))
+rows.sort(key=lambda x: -x[1][:6].sum())
+for rounds, p in rows[:5]:
+    print("rounds %d total Mcycles(100MHz ticks?) %.2f " % (rounds, p[:6].sum() / 1e6), ["%.2f" % (x / 1e6) for x in p[:6]], "queued/group %.0f groups %d" % (p[6] / max(p[7], 1), p[7]))
