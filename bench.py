@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--stages", type=lambda s: int(s, 0), default=0xF)
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="steps in flight: consecutive steps alternate between this many HIP streams / output buffer sets, so "
+                         "the tail of one step's per-frame LSD workgroups overlaps the next step's streaming passes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,40 +84,54 @@ def main():
     h2d_s = time.perf_counter() - t0
 
     vision = smh.HipVision.init(local_rank)
-    fb = smh.FrameBatch(vision, W, H, n)
+    depth = max(1, args.pipeline_depth)
+    fbs = [smh.FrameBatch(vision, W, H, n) for _ in range(depth)]
+    fb = fbs[0]
     anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
-    ptrs = fb.device_ptrs()
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
 
-    class _Rec:   # torch view over the library's device result records (for the RCCL gather)
-        __cuda_array_interface__ = {"shape": (n * sdist.RECORD_BYTES,), "typestr": "|u1", "data": (ptrs["results"], False), "version": 2}
-    rec_tensor = torch.as_tensor(_Rec(), device="cuda")
+    def rec_view(b):   # torch view over the library's device result records (for the RCCL gather)
+        class _Rec:
+            __cuda_array_interface__ = {"shape": (n * sdist.RECORD_BYTES,), "typestr": "|u1", "data": (b.device_ptrs()["results"], False), "version": 2}
+        return torch.as_tensor(_Rec(), device="cuda")
+    rec_tensors = [rec_view(b) for b in fbs]
+    for st in streams[1:]:
+        st.wait_stream(streams[0])          # the frame upload happened on the current stream
 
-    stream = torch.cuda.current_stream().cuda_stream
+    step_no = [0]
 
     def step():
-        fb.run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=stream)
-        if world > 1:
-            return sdist.gather_records(rec_tensor, dist, sizes=[n * sdist.RECORD_BYTES] * world)
+        k = step_no[0] % depth
+        step_no[0] += 1
+        with torch.cuda.stream(streams[k]):
+            fbs[k].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[k].cuda_stream)
+            if world > 1:
+                return sdist.gather_records(rec_tensors[k], dist, sizes=[n * sdist.RECORD_BYTES] * world)
         return None
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()           # all streams of the device
 
     for _ in range(args.warmup):
         step()
     barrier()
     if not args.no_stage_timing:
-        fb.enable_timing(True)
+        for b in fbs:
+            b.enable_timing(True)
     t0 = time.perf_counter()
     gathered = None
     for _ in range(args.steps):
         gathered = step()
     barrier()
     dt = time.perf_counter() - t0
-    stages_ms = fb.stage_ms() if not args.no_stage_timing else None
-    fb.enable_timing(False)
+    stages_ms = None
+    if not args.no_stage_timing:
+        per = [b.stage_ms() for b in fbs[:min(depth, args.steps)]]
+        stages_ms = {k: float(np.mean([p[k] for p in per])) for k in per[0]}
+    for b in fbs:
+        b.enable_timing(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -149,7 +166,8 @@ def main():
                                "(button, ui_map, marker mask+dilate, LSD, ocr_preprocess, scales+m/px)%s" % (
                                    n, W, H, ", RCCL gather of result records" if world > 1 else ""),
                    "frames_per_gpu": n, "global_batch": n * world, "frame": [W, H], "stages": args.stages,
-                   "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world},
+                   "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world,
+                   "pipeline_depth": depth},
         "per_gpu_frames_per_s": value / world,
         "h2d_seconds_for_batch": h2d_s,
         "all_map_open": bool(all_open),

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t absdiff(uint32_t a, uint32_t b) { return a >
 //   ((g-b)/delta) % 6.0   : |(g-b)/delta| <= 1 < 6, so fmodf returns its argument unchanged;
 //   modulo(h, 360.0)      : h is in [-60, 300], so fmodf(h,360) == h and only the `+ 360` applies.
 // tests/test_gpu_parity.py checks the device predicate against the oracle on all 2^24 colours.
-__device__ __forceinline__ bool marker_exact(uint32_t r8, uint32_t g8, uint32_t b8) {
+__device__ bool marker_exact(uint32_t r8, uint32_t g8, uint32_t b8) {
 	const float r = (float)r8 / 255.0f, g = (float)g8 / 255.0f, b = (float)b8 / 255.0f;
 	const float mx = fmaxf(r, fmaxf(g, b));
 	const float mn = fminf(r, fminf(g, b));
@@ -76,11 +76,28 @@ __device__ __forceinline__ bool marker_exact(uint32_t r8, uint32_t g8, uint32_t 
 // Cheap integer necessary condition in front of the exact float path (most map terrain fails it,
 // so whole waves skip the divisions):  s >= 35 needs 100*d/m >= 34.99 (the f32 result is within
 // 1e-4 of the rational), and every team window needs v >= 70, i.e. max channel >= 178.
-__device__ __forceinline__ bool is_marker(uint32_t r8, uint32_t g8, uint32_t b8) {
+__device__ __forceinline__ bool marker_prefilter(uint32_t bgra) {
+	const uint32_t b8 = bgra & 255u, g8 = (bgra >> 8) & 255u, r8 = (bgra >> 16) & 255u;
 	const uint32_t m = max(r8, max(g8, b8)), n = min(r8, min(g8, b8)), d = m - n;
+	return m >= 178u && d * 10000u >= 3499u * m;
+}
+__device__ __forceinline__ bool is_marker(uint32_t r8, uint32_t g8, uint32_t b8) {
 	bool res = false;
-	if (m >= 178u && d * 10000u >= 3499u * m) res = marker_exact(r8, g8, b8);
+	if (marker_prefilter(b8 | (g8 << 8) | (r8 << 16))) res = marker_exact(r8, g8, b8);
 	return res;
+}
+
+// Exact test for the pixels of a quad selected by `sel` (bit c = pixel c); out of line on purpose.
+__device__ __attribute__((noinline)) uint32_t marker_exact_quad(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t sel) {
+	uint32_t hit = 0;
+	const uint32_t pv[4] = {p0, p1, p2, p3};
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		if ((sel >> c) & 1u) {
+			const uint32_t p = pv[c];
+			if (marker_exact((p >> 16) & 255u, (p >> 8) & 255u, p & 255u)) hit |= 1u << c;
+		}
+	return hit;
 }
 
 __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
@@ -167,12 +184,20 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 	const int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
 	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
 
+	// Software pipeline: the loads of the next four rows are issued before the current four are
+	// processed, so they fly under the compute and the stores (vmcnt is in-order: a load issued after
+	// the stores would also wait for them).  Inactive lanes re-read quad 0 (no divergent load).
+	const uint8_t *lp = qact ? fp : fp - (size_t)q * 16;
+	uint4 nx[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
 	for (int r = rs; r <= re; r += 4) {
 		uint4 px[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int rr = min(r + k, re);
-			px[k] = qact ? *(const uint4 *)(fp + (size_t)rr * row_bytes) : make_uint4(0, 0, 0, 0);
+		for (int k = 0; k < 4; ++k) px[k] = nx[k];
+		if (r + 4 <= re) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(r + 4 + k, re) * row_bytes);
 		}
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
@@ -192,12 +217,18 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
 			}
 			if (do_mask) {
-				const int bit = row - (r0 - 1);
+				// Branch-free integer pre-filter on the four pixels, then ONE rarely taken branch per
+				// quad-row into the exact f32 HSV test.  That test is a real (non-inlined) function: inlined
+				// per pixel it made the streaming loop ~15 KB and instruction fetch, not HBM, set the pace.
+				uint32_t pre = 0;
 #pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const uint32_t p = pv[c];
-					const bool m = ((vmask >> c) & 1u) && is_marker((p >> 16) & 255u, (p >> 8) & 255u, p & 255u);
-					P[c] |= (uint64_t)(m ? 1u : 0u) << bit;
+				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
+				pre &= vmask;
+				if (pre) {
+					const uint32_t hit = marker_exact_quad(pv[0], pv[1], pv[2], pv[3], pre);
+					const uint64_t bm = 1ull << (row - (r0 - 1));
+#pragma unroll
+					for (int c = 0; c < 4; ++c) P[c] |= ((hit >> c) & 1u) ? bm : 0ull;
 				}
 			}
 		}
@@ -226,7 +257,11 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 
 	// ---- outputs: u8 mask rows and bit-packed rows ----
 	const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
+#ifdef EXP_NO_PHASE3
+	if (q < quads_padded && D[0] == 0x123456789ull) {
+#else
 	if (q < quads_padded) {
+#endif
 		uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
 		uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
 		for (int row = r0; row < r1; ++row) {
@@ -235,11 +270,13 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 			                     ((uint32_t)((D[2] >> bit) & 1ull) << 2) | ((uint32_t)((D[3] >> bit) & 1ull) << 3);
 			*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;
 			// gather 8 lanes' nibbles into one dword of the bit-packed row (lane l supplies bits 4(l%8)..)
+#ifndef EXP_NO_BITS
 			uint32_t v = nib;
 			v |= __shfl_down(v, 1) << 4;
 			v |= __shfl_down(v, 2) << 8;
 			v |= __shfl_down(v, 4) << 16;
 			if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
+#endif
 		}
 	}
 	// ---- bounding box + population count of the set bits (drives the LDS window of k_lsd) ----
@@ -1067,35 +1104,44 @@ __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scale_ratio: src/vision/mpx_ratio.rs.  One lane per OCR label anchor (<= 3), sequential scan as
-// in the reference.  Reads below the image count as non-zero (reference: unchecked read).
+// k_scale_ratio: src/vision/mpx_ratio.rs.  One wave per OCR label anchor (<= 3 per frame).  The scan
+// order of the reference is kept (rows downwards from the anchor; first tick column to the right,
+// then to the left), but each "first column whose 4 pixels below are all 0" search tests 64 columns
+// per step and takes the first hit with a ballot.  Pixels below the image count as non-zero
+// (reference: unchecked read).
 // ------------------------------------------------------------------------------------------------
 __device__ bool find_scale_width(const uint8_t *img, size_t pitch, uint32_t w, uint32_t h, uint32_t meters, uint32_t x, uint32_t y, double *ratio,
                                  uint32_t bar[3]) {
+	const uint32_t lane = threadIdx.x & 63u;
 	if (y < SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT || x >= w) return false;
 	// ((20.0 / 640.0) * w as f64).round(): 0.03125*w has at most 5 fractional bits, so t + 0.5 is exact
 	// and floor(t + 0.5) is round-half-away-from-zero for t >= 0
 	const double t = (20.0 / 640.0) * (double)w;
 	const uint32_t max_off = (uint32_t)floor(t + 0.5);
 	const uint32_t y_end = min(h, y + max_off);
+	auto tick = [&](uint32_t xx, uint32_t yy) -> bool {    // rows yy..yy+3 of column xx all 0
+		bool all0 = true;
+		for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty) all0 = all0 && ty < h && img[(size_t)ty * pitch + xx] == 0;
+		return all0;
+	};
 	for (uint32_t yy = y; yy < y_end; ++yy) {
-		if (img[(size_t)yy * pitch + x] != 0) continue;
+		if (img[(size_t)yy * pitch + x] != 0) continue;      // wave-uniform
 		uint32_t right = 0;
-		for (uint32_t xx = x; xx < w; ++xx) {
-			bool all0 = true;
-			for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty)
-				if (ty >= h || img[(size_t)ty * pitch + xx] != 0) { all0 = false; break; }
-			if (all0) { right = xx; break; }
+		for (uint32_t base = x; base < w; base += 64u) {     // Go right...
+			const uint32_t xx = base + lane;
+			const uint64_t hit = __ballot(xx < w && tick(xx, yy));
+			if (hit) { right = base + (uint32_t)__builtin_ctzll(hit); break; }
 		}
 		if (right == 0) continue;
 		right -= 1;
 		uint32_t left = 0;
-		for (uint32_t xx = x; xx-- > 0;) {
-			bool all0 = true;
-			for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty)
-				if (ty >= h || img[(size_t)ty * pitch + xx] != 0) { all0 = false; break; }
-			if (all0) { left = xx; break; }
+		bool found = false;
+		for (uint32_t base = 0; base < x; base += 64u) {     // Go left... (columns x-1, x-2, ...)
+			const uint32_t off = base + lane;
+			const uint64_t hit = __ballot(off < x && tick(x - 1u - off, yy));
+			if (hit) { left = x - 1u - (base + (uint32_t)__builtin_ctzll(hit)); found = true; break; }
 		}
+		(void)found;
 		if (left == 0) continue;
 		left += 1;
 		const uint32_t width = right - left;   // wraps like release Rust (mpx_ratio.rs:58)
@@ -1107,8 +1153,8 @@ __device__ bool find_scale_width(const uint8_t *img, size_t pitch, uint32_t w, u
 	return false;
 }
 
-__global__ void __launch_bounds__(64) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) {
-	const uint32_t f = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) {
+	const uint32_t f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	__shared__ double s_ratio[SMHV_MAX_SCALES];
 	__shared__ uint32_t s_ok[SMHV_MAX_SCALES];
 	smhv_frame_result *res = &b.results[f];
@@ -1116,22 +1162,24 @@ __global__ void __launch_bounds__(64) k_scale_ratio(Geom g, Buffers b, uint32_t 
 	const smhv_anchors an = b.anchors[f];
 	const uint32_t n = open ? min(an.n, (uint32_t)SMHV_MAX_SCALES) : 0u;
 	const bool valid = an.scales_start_y <= g.qh;
-	if (lane < SMHV_MAX_SCALES) {
+	{
 		double r = 0.0;
 		uint32_t bar[3] = {0, 0, 0};
 		bool ok = false;
-		if (lane < n && valid) {
+		if (wave < n && valid) {                               // wave-uniform
 			const uint8_t *img = b.scales + (size_t)f * g.ocr_stride + g.q_xoff;
-			ok = find_scale_width(img, g.ocr_pitch, g.qw, g.qh, an.scales[lane][0], an.scales[lane][1], an.scales[lane][2], &r, bar);
+			ok = find_scale_width(img, g.ocr_pitch, g.qw, g.qh, an.scales[wave][0], an.scales[wave][1], an.scales[wave][2], &r, bar);
 		}
-		s_ratio[lane] = r; s_ok[lane] = ok ? 1u : 0u;
-		if (bars) {
-			uint32_t *o = bars + ((size_t)f * SMHV_MAX_SCALES + lane) * 4;
-			o[0] = bar[0]; o[1] = bar[1]; o[2] = bar[2]; o[3] = ok ? 1u : 0u;
+		if (lane == 0) {
+			s_ratio[wave] = r; s_ok[wave] = ok ? 1u : 0u;
+			if (bars) {
+				uint32_t *o = bars + ((size_t)f * SMHV_MAX_SCALES + wave) * 4;
+				o[0] = bar[0]; o[1] = bar[1]; o[2] = bar[2]; o[3] = ok ? 1u : 0u;
+			}
 		}
 	}
 	__syncthreads();
-	if (lane == 0) {
+	if (threadIdx.x == 0) {
 		// the "Rayon ladder" (mpx_ratio.rs:93-125): mean of the successes, summed in index order
 		double sum = 0.0; uint32_t k = 0;
 		for (uint32_t i = 0; i < SMHV_MAX_SCALES; ++i)
@@ -1256,7 +1304,7 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 }
 
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s) {
-	hipLaunchKernelGGL(k_scale_ratio, dim3(n), dim3(64), 0, s, g, b, d_bars);
+	hipLaunchKernelGGL(k_scale_ratio, dim3(n), dim3(64 * SMHV_MAX_SCALES), 0, s, g, b, d_bars);
 	return hipGetLastError();
 }
 
