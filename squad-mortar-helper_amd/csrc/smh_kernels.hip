@@ -79,7 +79,7 @@ __device__ bool marker_exact(uint32_t r8, uint32_t g8, uint32_t b8) {
 __device__ __forceinline__ bool marker_prefilter(uint32_t bgra) {
 	const uint32_t b8 = bgra & 255u, g8 = (bgra >> 8) & 255u, r8 = (bgra >> 16) & 255u;
 	const uint32_t m = max(r8, max(g8, b8)), n = min(r8, min(g8, b8)), d = m - n;
-	return m >= 178u && d * 10000u >= 3499u * m;
+	return (uint32_t)(m >= 178u) & (uint32_t)(d * 10000u >= 3499u * m);
 }
 __device__ __forceinline__ bool is_marker(uint32_t r8, uint32_t g8, uint32_t b8) {
 	bool res = false;
@@ -469,7 +469,19 @@ struct Win {
 	uint32_t rows_hi, cols_hi;
 	uint32_t w, h;
 	float wf, hf;
+	// LSD_MODE_ROWS only: whole (bit-realigned: bit x of a row = pixel x) rows of the window in LDS
+	const char *rows0;                // address of bit 0 of image row 0 (may lie before the buffer)
+	float ylo_f, yhi_f;               // the two zero border rows, as floats
 };
+
+// Mask residency modes of k_lsd, chosen per frame from the bounding box of the set bits:
+//   ROWS   whole rows [y_min-1, y_max+1] in LDS, realigned so that bit x == pixel x.  The sample needs
+//          no horizontal clamp: a batch never strays more than 33 px from the image (see ray_batch), and
+//          the two words in front of / behind the block absorb that; out-of-window rows are clamped (in
+//          the float domain, one v_med3_f32) onto the zero border rows.
+//   XWIN   bounding box (+ zero border) in LDS, coordinates clamped into it (narrow, tall boxes)
+//   GLOBAL the whole bit-packed mask in global memory (box larger than LDS)
+enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2 };
 
 // One sample.  Coordinates below/left of the window wrap to huge unsigned values and clamp to the far
 // (zero) border just like coordinates beyond it, so each axis costs one v_min_u32.  24-bit multiply:
@@ -483,6 +495,15 @@ __device__ __forceinline__ uint32_t win_raw(const Win &m, int xi, int yi) {   //
 	return word >> ((uint32_t)X & 31u);
 }
 __device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) { return win_raw(m, xi, yi) & 1u; }
+
+// LSD_MODE_ROWS sample straight from the float position (bit 0 = the pixel).
+__device__ __forceinline__ uint32_t win_raw_rows(const Win &m, float x, float y) {
+	const int yi = (int)__builtin_amdgcn_fmed3f(y, m.ylo_f, m.yhi_f);
+	const int xi = (int)x;
+	const char *row = m.rows0 + __mul24(yi, (int)m.pitch4);
+	const uint32_t word = *(const uint32_t *)(row + ((xi >> 5) << 2));
+	return word >> ((uint32_t)xi & 31u);
+}
 
 __device__ __forceinline__ bool in_image(const Win &m, float x, float y) { return x >= 0.0f && y >= 0.0f && x < m.wf && y < m.hf; }
 
@@ -528,6 +549,7 @@ enum { RAY_CONTINUE = 0, RAY_ABORTED = 1, RAY_LEFT_IMAGE = 2 };
 // non-white sample, and restores the position where that run started.
 //   RAY_ABORTED    : the run started at global step s.gk0 + s.gj; samples taken = *steps
 //   RAY_LEFT_IMAGE : the first out-of-image position is step s.k0 + s.nexit
+template <int MODE>
 __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float dx, float dy, uint32_t T, RayState &s, uint32_t &steps) {
 	float xo = s.bxo, yo = s.byo, x = 0.0f, y = 0.0f;
 	uint32_t Wm = 0;
@@ -539,7 +561,9 @@ __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			x = xo + xs; y = yo + ys;                   // x = x_offset + x_start
-			Wm = __builtin_amdgcn_alignbit(win_raw(m, (int)x, (int)y), Wm, 1);   // shifts in bit 0 of its first operand
+			// shifts in bit 0 of its first operand
+			if (MODE == LSD_MODE_ROWS) Wm = __builtin_amdgcn_alignbit(win_raw_rows(m, x, y), Wm, 1);
+			else Wm = __builtin_amdgcn_alignbit(win_raw(m, (int)x, (int)y), Wm, 1);
 			xo += dx; yo += dy;                         // x_offset += dx
 		}
 		taken += 8u;
@@ -719,13 +743,14 @@ __device__ __forceinline__ uint32_t wave_sum32_dpp(uint32_t v) {
 // candidate's largest K.  Every ray that could win or tie is therefore still evaluated exactly, with
 // the reference's arithmetic; rays that left the image (which may legitimately end with length 0)
 // and the long rays of phase B are always evaluated exactly.
+template <int MODE>
 __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_t nc, float max_gap, unsigned long long *prof_t = nullptr) {
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 #ifdef SMH_LSD_PROFILE
 	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
 #endif
-	const bool fast = max_gap > 0.0f && max_gap <= 60000.0f;
-	const uint32_t T = fast ? (uint32_t)ceilf(max_gap) : 0u;
+	const bool fast_gap = max_gap > 0.0f && max_gap <= 60000.0f;
+	const uint32_t T = fast_gap ? (uint32_t)ceilf(max_gap) : 0u;
 	const uint32_t nunits = nc * LSD_GROUPS;
 
 	// ---- pass 1: first LSD_A_BATCHES x 32 samples of every ray; unit = (candidate, 64 consecutive angles).
@@ -748,6 +773,8 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			un = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
 		}
 		const float xs = sh.cand_pt[c][0], ys = sh.cand_pt[c][1];
+		// the batched walker needs a start inside the image (always true for find_lines candidates)
+		const bool fast = fast_gap && in_image(m, xs, ys);
 		float xe = xs, ye = ys;
 		uint32_t steps = 0;
 		int status = RAY_ABORTED;                          // invalid lanes: "finished", K = 0
@@ -757,7 +784,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			if (fast) {
 				status = RAY_CONTINUE;
 #pragma unroll 1
-				for (uint32_t bi = 0; bi < LSD_A_BATCHES && status == RAY_CONTINUE; ++bi) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+				for (uint32_t bi = 0; bi < LSD_A_BATCHES && status == RAY_CONTINUE; ++bi) status = ray_batch<MODE>(m, xs, ys, dx, dy, T, s, steps);
 			} else {
 				cast_ray_literal(m, xs, ys, max_gap, dx, dy, xe, ye, steps);
 				exact = true;
@@ -770,7 +797,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
 			const uint32_t slot = base + (uint32_t)__popcll(sv & ((1ull << lane) - 1ull));
 			if (status == RAY_CONTINUE && slot >= LSD_QCAP) {      // queue full: finish this ray here, exactly
-				while (status == RAY_CONTINUE) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+				while (status == RAY_CONTINUE) status = ray_batch<MODE>(m, xs, ys, dx, dy, T, s, steps);
 				ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye);
 				exact = true;
 			} else if (status == RAY_CONTINUE) {
@@ -826,7 +853,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			float xe = xs, ye = ys;
 			uint32_t steps = 0;
 			int status = RAY_CONTINUE;
-			while (status == RAY_CONTINUE) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+			while (status == RAY_CONTINUE) status = ray_batch<MODE>(m, xs, ys, dx, dy, T, s, steps);
 			ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye);
 			const float ddx = xs - xe, ddy = ys - ye;
 			const unsigned long long key = ((unsigned long long)__float_as_uint(ddx * ddx + ddy * ddy) << 32) | i;
@@ -840,11 +867,12 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 	PROF_MARK(4);
 
 	// ---- pass 2: exact end points for the units that can still hold the winner ----
-	if (fast) {
+	if (fast_gap) {
 		for (uint32_t u2 = wave; u2 < nunits; u2 += LSD_NW) {
 			const uint32_t c = u2 / LSD_GROUPS;
 			const uint32_t kbar = sh.cand_kmax[c];
 			if (sh.unit_kmax[u2] + 2u < kbar) continue;        // wave-uniform
+			if (!in_image(m, sh.cand_pt[c][0], sh.cand_pt[c][1])) continue;   // walked literally (exactly) in pass 1
 			const uint32_t i = (u2 - c * LSD_GROUPS) * 64u + lane;
 			const bool valid = i < SMH_LSD_RAYS;
 			const RayDir d = g_ray_table[min(i, (uint32_t)SMH_LSD_RAYS - 1u)];
@@ -856,7 +884,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			RayState s = {0.0f, 0.0f, 0u, 0u, 0.0f, 0.0f, 0u, 0u, 0u};
 			if (valid) {
 #pragma unroll 1
-				for (uint32_t bi = 0; bi < LSD_A_BATCHES && status == RAY_CONTINUE; ++bi) status = ray_batch(m, xs, ys, dx, dy, T, s, steps);
+				for (uint32_t bi = 0; bi < LSD_A_BATCHES && status == RAY_CONTINUE; ++bi) status = ray_batch<MODE>(m, xs, ys, dx, dy, T, s, steps);
 			}
 			unsigned long long key = 0;
 			if (valid && status == RAY_ABORTED && s.gk0 + s.gj + 2u >= kbar) {
@@ -882,7 +910,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 	__syncthreads();
 }
 
-template <bool LDSWIN>
+template <int MODE>
 __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max_gap, int mode, float spx, float spy, const FrameAux &aux,
                           uint32_t *smem, LsdShared &sh) {
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -891,11 +919,37 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 
 	Win m;
 	m.w = g.rw; m.h = g.rh; m.wf = (float)g.rw; m.hf = (float)g.rh;
+	m.rows0 = nullptr; m.ylo_f = 0.0f; m.yhi_f = 0.0f;
 	uint32_t *list, *queue;
-	uint32_t wy0, ww0, wrows, wwords;   // geometry of the compaction domain (unpadded window)
+	// compaction domain: wrows x wwords words; word (r, c) holds pixels x = xorg + 32 c + [0,32) of image row wy0 + r
+	uint32_t wy0, wrows, wwords;
+	int xorg;
 	PROF_DECL
-	if (LDSWIN) {
-		wy0 = aux.y_min; ww0 = aux.w_min; wrows = aux.y_max - aux.y_min + 1u; wwords = aux.w_max - aux.w_min + 1u;
+	if (MODE == LSD_MODE_ROWS) {
+		wy0 = aux.y_min; wrows = aux.y_max - aux.y_min + 1u; wwords = g.bits_pitch_w; xorg = 0;
+		const uint32_t pitch = g.bits_pitch_w;
+		// [2 pad words][row y_min-1 = zeros][rows y_min..y_max, shifted right by xoff bits][row y_max+1 = zeros][2 pad words]
+		const uint32_t total = (wrows + 2u) * pitch + 4u;
+		for (uint32_t idx = tid; idx < total; idx += LSD_BS) {
+			uint32_t v = 0;
+			if (idx >= 2u + pitch && idx < 2u + (wrows + 1u) * pitch) {
+				const uint32_t k = idx - 2u - pitch, r = k / pitch, c = k - r * pitch;
+				const uint32_t *src = gbits + (size_t)(wy0 + r) * pitch + c;
+				const uint32_t lo = src[0], hi = (c + 1u < pitch) ? src[1] : 0u;
+				v = __builtin_amdgcn_alignbit(hi, lo, g.m_xoff);           // bit x of the row = pixel x
+			}
+			smem[idx] = v;
+		}
+		m.p = smem + 2; m.pitch4 = pitch * 4u;
+		m.y_lo = (int)wy0 - 1; m.rows_hi = wrows + 1u;
+		m.xbias = 0; m.cols_hi = pitch - 1u;
+		m.rows0 = (const char *)(smem + 2) - (ptrdiff_t)((int)wy0 - 1) * (ptrdiff_t)(pitch * 4u);
+		m.ylo_f = (float)((int)wy0 - 1); m.yhi_f = (float)(wy0 + wrows);
+		list = smem + LSD_WIN_WORDS_CAP;
+	} else if (MODE == LSD_MODE_XWIN) {
+		const uint32_t ww0 = aux.w_min;
+		wy0 = aux.y_min; wrows = aux.y_max - aux.y_min + 1u; wwords = aux.w_max - aux.w_min + 1u;
+		xorg = (int)(ww0 * 32u) - (int)g.m_xoff;
 		const uint32_t pitch = (wwords + 2u) | 1u;                     // odd pitch: rows spread over the LDS banks
 		m.p = smem; m.pitch4 = pitch * 4u;
 		m.y_lo = (int)wy0 - 1; m.rows_hi = wrows + 1u;
@@ -909,26 +963,27 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		}
 		list = smem + LSD_WIN_WORDS_CAP;
 	} else {
-		wy0 = 0; ww0 = 0; wrows = g.rh; wwords = g.bits_pitch_w;
+		wy0 = 0; wrows = g.rh; wwords = g.bits_pitch_w; xorg = -(int)g.m_xoff;
 		m.p = gbits; m.pitch4 = g.bits_pitch_w * 4u;
 		m.y_lo = 0; m.rows_hi = g.rh - 1u;
 		m.xbias = (int)g.m_xoff; m.cols_hi = g.bits_pitch_w - 1u;
 		list = smem;
 	}
 	queue = list + LSD_LIST_CAP;
-	const uint32_t WT = wrows * wwords;   // compaction domain: word index wi -> row wi / wwords, column wi % wwords
+	const uint32_t WT = wrows * wwords;   // word index wi -> row wi / wwords, column wi % wwords
 	__syncthreads();
-	// word of the compaction domain
 	auto dom_word = [&](uint32_t wi) -> uint32_t {
 		const uint32_t r = wi / wwords, c = wi - r * wwords;
-		return LDSWIN ? m.p[(r + 1u) * (m.pitch4 >> 2) + c + 1u] : m.p[wi];
+		if (MODE == LSD_MODE_ROWS) return m.p[(r + 1u) * wwords + c];
+		if (MODE == LSD_MODE_XWIN) return m.p[(r + 1u) * (m.pitch4 >> 2) + c + 1u];
+		return m.p[wi];
 	};
 
 	if (mode == 1) {   // Vision::find_longest_line on an arbitrary point
 		if (tid < LSD_GROUPS) sh.unit_key[tid] = 0ull;
 		if (tid == 0) { sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
 		__syncthreads();
-		ray_engine(m, sh, queue, 1u, max_gap PROF_ARG);
+		ray_engine<MODE>(m, sh, queue, 1u, max_gap PROF_ARG);
 		if (tid == 0) {
 			res->lines[0].x0 = spx; res->lines[0].y0 = spy; res->lines[0].x1 = sh.cand_end[0][0]; res->lines[0].y1 = sh.cand_end[0][1];
 			res->length_px[0] = (double)__uint_as_float((uint32_t)(sh.cand_best[0] >> 32));
@@ -978,7 +1033,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				surv = dom_word(wi);
 				const uint32_t r = wi / wwords, c = wi - r * wwords;
 				py = (float)(wy0 + r);
-				px0 = (float)((int)((ww0 + c) * 32u) - (int)g.m_xoff);
+				px0 = (float)(xorg + (int)(c * 32u));
 				for (uint32_t l = 0; l < n_lines && surv; ++l) {
 					const float x0 = sh.lines[l][0], y0 = sh.lines[l][1], x1 = sh.lines[l][2], y1 = sh.lines[l][3];
 					uint32_t s = surv;
@@ -1017,14 +1072,14 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					const uint32_t cwi = list[cbase + (key >> 5)];
 					const uint32_t cr = cwi / wwords, cc = cwi - cr * wwords;
 					const float cy = (float)(wy0 + cr);
-					const float cx = (float)((int)((ww0 + cc) * 32u + (key & 31u)) - (int)g.m_xoff);
+					const float cx = (float)(xorg + (int)(cc * 32u + (key & 31u)));
 					float ptx, pty;
 					get_centre(m, cx, cy, ptx, pty);
 					sh.cand_pt[tid][0] = ptx; sh.cand_pt[tid][1] = pty;
 				}
 				__syncthreads();
 				PROF_MARK(2);   // chunk filter + candidate selection + centres
-				ray_engine(m, sh, queue, nc, max_gap PROF_ARG);
+				ray_engine<MODE>(m, sh, queue, nc, max_gap PROF_ARG);
 #ifdef SMH_LSD_PROFILE
 				prof_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -1036,7 +1091,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					const uint32_t cwi = list[cbase + (key >> 5)];
 					const uint32_t cr = cwi / wwords, cc = cwi - cr * wwords;
 					const float cy = (float)(wy0 + cr);
-					const float cx = (float)((int)((ww0 + cc) * 32u + (key & 31u)) - (int)g.m_xoff);
+					const float cx = (float)(xorg + (int)(cc * 32u + (key & 31u)));
 					bool skip = false;
 					for (uint32_t l = first_new; l < n_lines; ++l)
 						skip = skip || near_line(cx, cy, sh.lines[l][0], sh.lines[l][1], sh.lines[l][2], sh.lines[l][3]);
@@ -1094,13 +1149,15 @@ __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap
 		if (threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
 		if (!aux.open || aux.n_mask_px == 0) return;
 	}
-	bool lds = false;
+	int lmode = LSD_MODE_GLOBAL;                           // also the empty-mask single-round case
 	if (aux.n_mask_px != 0) {
 		const uint32_t wrows = aux.y_max - aux.y_min + 1u, wwords = aux.w_max - aux.w_min + 1u;
-		lds = (wrows + 2u) * ((wwords + 2u) | 1u) <= LSD_WIN_WORDS_CAP;
+		if ((wrows + 2u) * g.bits_pitch_w + 4u <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_ROWS;
+		else if ((wrows + 2u) * ((wwords + 2u) | 1u) <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_XWIN;
 	}
-	if (lds) lsd_frame<true>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
-	else lsd_frame<false>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);   // also the empty-mask single-round case
+	if (lmode == LSD_MODE_ROWS) lsd_frame<LSD_MODE_ROWS>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+	else if (lmode == LSD_MODE_XWIN) lsd_frame<LSD_MODE_XWIN>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+	else lsd_frame<LSD_MODE_GLOBAL>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
