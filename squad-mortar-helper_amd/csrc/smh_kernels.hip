@@ -87,19 +87,6 @@ __device__ __forceinline__ bool is_marker(uint32_t r8, uint32_t g8, uint32_t b8)
 	return res;
 }
 
-// Exact test for the pixels of a quad selected by `sel` (bit c = pixel c); out of line on purpose.
-__device__ __attribute__((noinline)) uint32_t marker_exact_quad(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t sel) {
-	uint32_t hit = 0;
-	const uint32_t pv[4] = {p0, p1, p2, p3};
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
-		if ((sel >> c) & 1u) {
-			const uint32_t p = pv[c];
-			if (marker_exact((p >> 16) & 255u, (p >> 8) & 255u, p & 255u)) hit |= 1u << c;
-		}
-	return hit;
-}
-
 __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
 	for (int o = 32; o; o >>= 1) v |= __shfl_xor(v, o);
 	return v;
@@ -191,8 +178,11 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 	uint4 nx[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
+	__shared__ uint32_t s_hit_px[16][64], s_hit_res[16][64];
+	__shared__ unsigned short s_hit_id[16][64];
 	for (int r = rs; r <= re; r += 4) {
 		uint4 px[4];
+		uint32_t prehits = 0;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) px[k] = nx[k];
 		if (r + 4 <= re) {
@@ -217,18 +207,60 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
 			}
 			if (do_mask) {
-				// Branch-free integer pre-filter on the four pixels, then ONE rarely taken branch per
-				// quad-row into the exact f32 HSV test.  That test is a real (non-inlined) function: inlined
-				// per pixel it made the streaming loop ~15 KB and instruction fetch, not HBM, set the pace.
+				// branch-free integer pre-filter; hits of the four rows are collected (bit 4k+c)
 				uint32_t pre = 0;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
-				pre &= vmask;
-				if (pre) {
-					const uint32_t hit = marker_exact_quad(pv[0], pv[1], pv[2], pv[3], pre);
-					const uint64_t bm = 1ull << (row - (r0 - 1));
+				prehits |= (pre & vmask) << (4 * k);
+			}
+		}
+		// ---- exact f32 HSV test for the pre-filter hits of this wave, one hit per lane ----
+		// A marker line crosses most rows of a band but only a few pixels of each, so testing hits where
+		// they sit would run the (long, divergent) exact test several times per row for two or three
+		// active lanes.  Instead the hit pixels of the whole wave and of all four rows are compacted into
+		// a 64-entry LDS list, every lane tests one of them, and the verdicts are scattered back with
+		// LDS atomic ORs.  (This path used to be 40 % of the kernel's time.)
+		if (do_mask && __any(prehits != 0u)) {
+			uint32_t *hpx = s_hit_px[wave];
+			uint32_t *hres = s_hit_res[wave];
+			unsigned short *hid = s_hit_id[wave];
+			const uint32_t cnt = (uint32_t)__popc(prehits);
+			uint32_t incl = cnt;
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
+			const uint32_t total = __shfl(incl, 63);
+			const uint32_t off = incl - cnt;
+			hres[lane] = 0u;
+			for (uint32_t base = 0; base < total; base += 64u) {
+				uint32_t o = off - base;                           // may wrap: compared unsigned below
 #pragma unroll
-					for (int c = 0; c < 4; ++c) P[c] |= ((hit >> c) & 1u) ? bm : 0ull;
+				for (int k = 0; k < 4; ++k) {
+					const uint32_t pk[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+					for (int c = 0; c < 4; ++c)
+						if ((prehits >> (4 * k + c)) & 1u) {
+							if (o < 64u) { hpx[o] = pk[c]; hid[o] = (unsigned short)((lane << 4) | (uint32_t)(4 * k + c)); }
+							++o;
+						}
+				}
+				__builtin_amdgcn_wave_barrier();
+				const uint32_t e = base + lane;
+				if (e < total) {
+					const uint32_t p = hpx[lane];
+					if (marker_exact((p >> 16) & 255u, (p >> 8) & 255u, p & 255u)) {
+						const uint32_t id = hid[lane];
+						atomicOr(&hres[id >> 4], 1u << (id & 15u));
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			const uint32_t res = hres[lane];                       // bit 4k+c: pixel c of row r+k is a marker colour
+			if (res) {
+				const int sh = r - (r0 - 1);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					uint32_t y = (res >> c) & 0x1111u;                 // rows k = 0..3 at bits 0,4,8,12
+					y = (y | (y >> 3) | (y >> 6) | (y >> 9)) & 0xFu;   // -> bits 0..3
+					P[c] |= (uint64_t)y << sh;
 				}
 			}
 		}
