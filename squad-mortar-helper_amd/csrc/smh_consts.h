@@ -43,6 +43,8 @@
 #define SMH_LSD_PROXIMITY_SQ 50.0f
 #define SMH_LSD_CENTRE_REACH 5.0f
 #define SMH_LSD_MAX_LINES 32
+// a ray whose final gap starts at step K ends K-1 unit steps (+-0.25) from its start: K <= 49 => len^2 < 2500
+#define SMH_LSD_REJECT_K 49u
 
 // mpx_ratio.rs:5-6,12
 #define SMH_MIN_SCALE_WIDTH 10u

@@ -480,15 +480,19 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 #include "ray_table.inc"
 };
 
+#ifndef LSD_BS
 #define LSD_BS 1024
+#endif
 #define LSD_NW (LSD_BS / 64)
 #define LSD_C 8u                                   // candidates ray-cast per group
 #define LSD_GROUPS ((SMH_LSD_RAYS + 63) / 64)      // 64-ray units per candidate (57)
 #define LSD_UNITS (LSD_C * LSD_GROUPS)
 #define LSD_LIST_CAP 2048u
 #define LSD_QCAP 2048u
+#define LSD_QPT (LSD_QCAP / LSD_BS)                   // queue entries per thread in phase B
 #define LSD_A_BATCHES 2u                            // 32-sample batches walked in phase A before a ray is queued
 #define LSD_WIN_WORDS_CAP 30000u                   // 1080p whole-ROI padded window = 824 x 35 = 28840 words
+#define LSD_ROWS_PITCH(gp) ((gp) | 1u)                 // LDS row pitch (words) of LSD_MODE_ROWS
 #define LSD_DYN_LDS_BYTES ((LSD_WIN_WORDS_CAP + LSD_LIST_CAP + 2u * LSD_QCAP) * 4u)
 
 // Window of the bit-packed mask.  In LDS it is the bounding box of the set bits plus a one-word /
@@ -776,7 +780,7 @@ __device__ __forceinline__ uint32_t wave_sum32_dpp(uint32_t v) {
 // the reference's arithmetic; rays that left the image (which may legitimately end with length 0)
 // and the long rays of phase B are always evaluated exactly.
 template <int MODE>
-__device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_t nc, float max_gap, unsigned long long *prof_t = nullptr) {
+__device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_t nc, float max_gap, bool always_exact, unsigned long long *prof_t = nullptr) {
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 #ifdef SMH_LSD_PROFILE
 	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
@@ -822,6 +826,9 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 				exact = true;
 			}
 		}
+#ifdef SMH_LSD_PROFILE
+		if (prof_t) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[0] += _n - prof_last; prof_last = _n; }
+#endif
 		const uint64_t sv = __ballot(status == RAY_CONTINUE);
 		if (sv) {
 			uint32_t base = 0;
@@ -853,6 +860,9 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 		const uint32_t Kw = wave_max32_dpp((fin && !exact) ? s.gk0 + s.gj : 0u);
 		const uint32_t wsteps = wave_sum32_dpp(steps);
 		if (lane == 0) { sh.unit_kmax[ucur] = Kw; atomicMax(&sh.cand_kmax[c], Kw); atomicAdd(&sh.cand_steps[c], wsteps); }
+#ifdef SMH_LSD_PROFILE
+		if (prof_t) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[1] += _n - prof_last; prof_last = _n; }
+#endif
 	}
 	__syncthreads();
 	PROF_MARK(3);
@@ -862,11 +872,13 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 #ifdef SMH_LSD_PROFILE
 	if (prof_t) { prof_t[6] += sh.qtail; prof_t[7] += 1; }
 #endif
-	unsigned long long bkey[2] = {0ull, 0ull};
-	float bxe[2] = {0.0f, 0.0f}, bye[2] = {0.0f, 0.0f};
-	uint32_t bc[2] = {0u, 0u};
+	unsigned long long bkey[LSD_QPT];
+	float bxe[LSD_QPT], bye[LSD_QPT];
+	uint32_t bc[LSD_QPT];
 #pragma unroll
-	for (int r = 0; r < 2; ++r) {                          // LSD_QCAP == 2 * LSD_BS
+	for (int r = 0; r < (int)LSD_QPT; ++r) { bkey[r] = 0ull; bxe[r] = 0.0f; bye[r] = 0.0f; bc[r] = 0u; }
+#pragma unroll
+	for (int r = 0; r < (int)LSD_QPT; ++r) {
 		const uint32_t e = tid + (uint32_t)r * LSD_BS;
 		if (e < Q) {
 			const uint32_t id = queue[2u * e], st = queue[2u * e + 1u];
@@ -904,6 +916,11 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			const uint32_t c = u2 / LSD_GROUPS;
 			const uint32_t kbar = sh.cand_kmax[c];
 			if (sh.unit_kmax[u2] + 2u < kbar) continue;        // wave-uniform
+			// find_lines only keeps a candidate whose best ray has len^2 > 2500 (lsd.rs:94).  With every
+			// aborted ray's gap starting at step <= 49 its length is < 48.3 < 50, so the candidate is rejected
+			// whatever the exact end points are (rays evaluated exactly in pass 1 / phase B already compete in
+			// cand_best): no need for them.  Vision::find_longest_line (mode 1) always gets the exact answer.
+			if (!always_exact && kbar <= SMH_LSD_REJECT_K) continue;
 			if (!in_image(m, sh.cand_pt[c][0], sh.cand_pt[c][1])) continue;   // walked literally (exactly) in pass 1
 			const uint32_t i = (u2 - c * LSD_GROUPS) * 64u + lane;
 			const bool valid = i < SMH_LSD_RAYS;
@@ -931,9 +948,12 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 		}
 	}
 	__syncthreads();
+#ifdef SMH_LSD_PROFILE
+	if (prof_t) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[2] += _n - prof_last; prof_last = _n; }
+#endif
 	// ---- the winning ray of each candidate publishes its end point (keys are unique per ray) ----
 #pragma unroll
-	for (int r = 0; r < 2; ++r)
+	for (int r = 0; r < (int)LSD_QPT; ++r)
 		if (bkey[r] != 0ull && bkey[r] == sh.cand_best[bc[r]]) { sh.cand_end[bc[r]][0] = bxe[r]; sh.cand_end[bc[r]][1] = bye[r]; }
 	if (tid < nunits) {
 		const uint32_t c = tid / LSD_GROUPS;
@@ -958,17 +978,19 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	int xorg;
 	PROF_DECL
 	if (MODE == LSD_MODE_ROWS) {
-		wy0 = aux.y_min; wrows = aux.y_max - aux.y_min + 1u; wwords = g.bits_pitch_w; xorg = 0;
-		const uint32_t pitch = g.bits_pitch_w;
+		wy0 = aux.y_min; wrows = aux.y_max - aux.y_min + 1u; wwords = LSD_ROWS_PITCH(g.bits_pitch_w); xorg = 0;
+		const uint32_t pitch = wwords, gp = g.bits_pitch_w;          // odd LDS pitch: consecutive rows fall on different banks
 		// [2 pad words][row y_min-1 = zeros][rows y_min..y_max, shifted right by xoff bits][row y_max+1 = zeros][2 pad words]
 		const uint32_t total = (wrows + 2u) * pitch + 4u;
 		for (uint32_t idx = tid; idx < total; idx += LSD_BS) {
 			uint32_t v = 0;
 			if (idx >= 2u + pitch && idx < 2u + (wrows + 1u) * pitch) {
 				const uint32_t k = idx - 2u - pitch, r = k / pitch, c = k - r * pitch;
-				const uint32_t *src = gbits + (size_t)(wy0 + r) * pitch + c;
-				const uint32_t lo = src[0], hi = (c + 1u < pitch) ? src[1] : 0u;
-				v = __builtin_amdgcn_alignbit(hi, lo, g.m_xoff);           // bit x of the row = pixel x
+				if (c < gp) {
+					const uint32_t *src = gbits + (size_t)(wy0 + r) * gp + c;
+					const uint32_t lo = src[0], hi = (c + 1u < gp) ? src[1] : 0u;
+					v = __builtin_amdgcn_alignbit(hi, lo, g.m_xoff);       // bit x of the row = pixel x
+				}
 			}
 			smem[idx] = v;
 		}
@@ -1015,7 +1037,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		if (tid < LSD_GROUPS) sh.unit_key[tid] = 0ull;
 		if (tid == 0) { sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
 		__syncthreads();
-		ray_engine<MODE>(m, sh, queue, 1u, max_gap PROF_ARG);
+		ray_engine<MODE>(m, sh, queue, 1u, max_gap, true PROF_ARG);
 		if (tid == 0) {
 			res->lines[0].x0 = spx; res->lines[0].y0 = spy; res->lines[0].x1 = sh.cand_end[0][0]; res->lines[0].y1 = sh.cand_end[0][1];
 			res->length_px[0] = (double)__uint_as_float((uint32_t)(sh.cand_best[0] >> 32));
@@ -1111,7 +1133,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				}
 				__syncthreads();
 				PROF_MARK(2);   // chunk filter + candidate selection + centres
-				ray_engine<MODE>(m, sh, queue, nc, max_gap PROF_ARG);
+				ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);
 #ifdef SMH_LSD_PROFILE
 				prof_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -1184,7 +1206,7 @@ __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap
 	int lmode = LSD_MODE_GLOBAL;                           // also the empty-mask single-round case
 	if (aux.n_mask_px != 0) {
 		const uint32_t wrows = aux.y_max - aux.y_min + 1u, wwords = aux.w_max - aux.w_min + 1u;
-		if ((wrows + 2u) * g.bits_pitch_w + 4u <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_ROWS;
+		if ((wrows + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_ROWS;
 		else if ((wrows + 2u) * ((wwords + 2u) | 1u) <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_XWIN;
 	}
 	if (lmode == LSD_MODE_ROWS) lsd_frame<LSD_MODE_ROWS>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);

@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 print("stage ms", fb.stage_ms())
 recs = fb.read_results(0, N)
-names = ["A:batches(+load,compaction)", "A:queue+endpoint", "A:reductions", "phaseA-sync-wait", "phaseB", "resolve+select", "queued_rays", "groups"]
+names = ["pass1:batches", "pass1:unit-overhead", "pass2(+sync)", "pass1-end-sync-wait", "phaseB", "select+resolve", "queued_rays", "groups"]
 tot = np.zeros(8)
 rows = []
 for r in recs:
