@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--stages", type=lambda s: int(s, 0), default=0xF)
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-box testing of the N>1 code path)")
+    ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="steps in flight: consecutive steps alternate between this many HIP streams / output buffer sets, so "
                          "the tail of one step's per-frame LSD workgroups overlaps the next step's streaming passes")
@@ -64,11 +66,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
 
+    if args.force_device is not None:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import dist as sdist
@@ -106,7 +113,8 @@ def main():
         with torch.cuda.stream(streams[k]):
             fbs[k].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[k].cuda_stream)
             if world > 1:
-                return sdist.gather_records(rec_tensors[k], dist, sizes=[n * sdist.RECORD_BYTES] * world)
+                t = rec_tensors[k] if args.dist_backend == "nccl" else rec_tensors[k].cpu()   # gloo gathers host tensors
+                return sdist.gather_records(t, dist, sizes=[n * sdist.RECORD_BYTES] * world)
         return None
 
     def barrier():
@@ -130,9 +138,18 @@ def main():
     if not args.no_stage_timing:
         per = [b.stage_ms() for b in fbs[:min(depth, args.steps)]]
         stages_ms = {k: float(np.mean([p[k] for p in per])) for k in per[0]}
+    # the same step, not overlapped with anything (outside the timed region): per-stage durations in isolation
+    iso_ms = None
+    if not args.no_stage_timing:
+        fbs[0].enable_timing(True)
+        for _ in range(3):
+            with torch.cuda.stream(streams[0]):
+                fbs[0].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[0].cuda_stream)
+            torch.cuda.synchronize()
+        iso_ms = fbs[0].stage_ms()
     for b in fbs:
         b.enable_timing(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -175,9 +192,26 @@ def main():
     if stages_ms is not None:
         t_map = stages_ms["map_pass"] * 1e-3
         ach = n * map_bytes / t_map / 1e9 if t_map > 0 else 0.0
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction);
+        # only quoted when it was measured on this frame size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("frame") == [W, H] and args.stages == 0xF:
+                traffic = tj["bytes_per_frame"] * n
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": "k_map_pass", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "algorithmic_bytes_per_frame": map_bytes, "launch_ms": stages_ms["map_pass"]}
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes_per_frame": map_bytes, "launch_ms": stages_ms["map_pass"],
+                           "note": "launch duration from hipEvents inside the timed (pipelined) region: with pipeline_depth > 1 the "
+                                   "kernel shares the chip with the previous step's LSD tail; roofline_isolated is the same kernel "
+                                   "timed alone right after the timed region"}
+        if iso_ms is not None and iso_ms["map_pass"] > 0:
+            a2 = n * map_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9
+            out["roofline_isolated"] = {"kernel": "k_map_pass", "achieved": a2, "frac": a2 / HBM_PEAK_GBS, "unit": "GB/s",
+                                        "launch_ms": iso_ms["map_pass"], "stages_ms": iso_ms}
         out["stages_ms"] = stages_ms
         out["pipeline_algorithmic_GBps"] = value / world * full_bytes / 1e9
         out["pipeline_hbm_frac"] = value / world * full_bytes / 1e9 / HBM_PEAK_GBS

@@ -124,6 +124,11 @@ struct smhv_batch {
 	FrameAux *d_aux = nullptr;
 	smhv_frame_result *d_results = nullptr;   // max_frames (+2 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
+	// pinned staging for the per-run anchor upload (a pageable source would make hipMemcpyAsync synchronous);
+	// two slots + events so a run never overwrites a slot whose copy is still in flight
+	smhv_anchors *h_anchors[2] = {nullptr, nullptr};
+	hipEvent_t anchors_done[2] = {};
+	uint32_t anchors_slot = 0;
 	// per-stage hipEvent ring: up to TIMING_RING timed runs are kept so a benchmark loop can read the
 	// average stage durations afterwards without synchronising between steps
 	static constexpr int TIMING_RING = 64;
@@ -256,6 +261,11 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 	ALLOC0(b->d_anchors, sizeof(smhv_anchors) * n);
 	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
 #undef ALLOC0
+	for (int i = 0; i < 2; ++i) {
+		hipError_t e = hipHostMalloc((void **)&b->h_anchors[i], sizeof(smhv_anchors) * n);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->anchors_done[i], hipEventDisableTiming);
+		if (e != hipSuccess) { smhv_batch_destroy(b); return fail(SMHV_E_HIP, "anchor staging: %s", hipGetErrorString(e)); }
+	}
 	*out = b;
 	return SMHV_OK;
 }
@@ -267,6 +277,10 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
+	for (int i = 0; i < 2; ++i) {
+		if (b->h_anchors[i]) (void)hipHostFree(b->h_anchors[i]);
+		if (b->anchors_done[i]) (void)hipEventDestroy(b->anchors_done[i]);
+	}
 	if (b->ev) {
 		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
 			for (int i = 0; i < 6; ++i) (void)hipEventDestroy(b->ev[r][i]);
@@ -312,7 +326,13 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
 	const bool scales = (stages & SMHV_STAGE_SCALES) && anchors;
-	if (scales) HIPCHK(hipMemcpyAsync(b->d_anchors, anchors, sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, s));
+	if (scales) {
+		const uint32_t slot = b->anchors_slot++ & 1u;
+		HIPCHK(hipEventSynchronize(b->anchors_done[slot]));      // the copy that last used this slot (two runs ago)
+		memcpy(b->h_anchors[slot], anchors, sizeof(smhv_anchors) * n);
+		HIPCHK(hipMemcpyAsync(b->d_anchors, b->h_anchors[slot], sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, s));
+		HIPCHK(hipEventRecord(b->anchors_done[slot], s));
+	}
 	const bool t = b->timing;
 	hipEvent_t *ev = t ? b->ev[b->timed_runs % smhv_batch::TIMING_RING] : nullptr;
 	if (t) HIPCHK(hipEventRecord(ev[0], s));
