@@ -343,3 +343,136 @@ def test_1440p_batch_window_and_global_mask_paths(vision):
 def test_smoke_entry_point(vision):
     import __graft_entry__ as g
     g.smoke()
+
+
+# ---------------------------------------------------------------------------------------------------
+# stress cases for the restructured kernels (speculative candidate groups, batched ray walking,
+# LDS hit compaction): every one compares complete outputs with the oracle
+# ---------------------------------------------------------------------------------------------------
+GREEN = (0, 255, 64, 255)       # BGRA of RGB(64,255,0)
+PURPLE = (217, 117, 192, 255)   # BGRA of RGB(192,117,217)
+
+
+def _blank(W, H, idx=0):
+    from squad_mortar_helper_amd import synth
+    import squad_mortar_helper_amd as smh
+    frame, _ = synth.make_frame(W, H, idx, n_lines=0)
+    return frame, smh.map_bounds(W, H)
+
+
+def _check_markers(vision, frame, max_gap=15):
+    ref = o.process_frame(frame, stages=0x1, max_gap=max_gap, want_images=True)
+    res = run_trait_sequence(vision, frame, max_gap=max_gap)
+    lsd = vision.lsd_image()
+    assert np.array_equal(lsd, ref["lsd"])
+    assert res.markers.shape == ref["lines"].shape and np.array_equal(res.markers, ref["lines"]), (res.markers, ref["lines"])
+    return ref
+
+
+def test_stress_dense_noise_many_isolated_candidates(vision):
+    """Thousands of isolated marker pixels: more non-zero mask words than the LDS candidate list holds
+    (segmented compaction), every candidate rejected, every ray dies in the first batch."""
+    W, H = 1920, 1080
+    frame, (x, y, rw, rh) = _blank(W, H, 21)
+    rng = np.random.default_rng(5)
+    n = 3000
+    xs, ys = rng.integers(0, rw, n), rng.integers(0, rh, n)
+    frame[y + ys, x + xs] = GREEN
+    ref = _check_markers(vision, frame)
+    assert ref["rounds"] > 2048
+
+
+def test_stress_filled_areas_overflow_the_long_ray_queue(vision):
+    """Large filled marker areas: most rays survive 64 samples, so the LDS queue of long rays overflows
+    and rays are finished in place; also >64 pre-filter hits per wave (chunked hit compaction)."""
+    W, H = 1920, 1080
+    frame, (x, y, rw, rh) = _blank(W, H, 22)
+    frame[y + 100:y + 420, x + 150:x + 560] = GREEN
+    frame[y + 500:y + 760, x + 600:x + 980] = PURPLE          # touches the right border region
+    frame[y + 600:y + 620, x + 0:x + 300] = GREEN              # starts at the left border
+    _check_markers(vision, frame)
+
+
+@pytest.mark.parametrize("max_gap", [1, 2, 7, 22, 31, 32, 40, 100])
+def test_stress_max_gap_values(vision, max_gap):
+    """Gap thresholds around the 32-sample batch size (T <= 31: bit-trick state machine, T > 31: run loop)."""
+    from squad_mortar_helper_amd import synth
+    frame, info = synth.make_frame(1280, 1024, 30 + max_gap, n_lines=3)
+    x, y, rw, rh = info["roi"]
+    for k in range(12):                                        # dashed line: 6 px on, k px off
+        x0 = x + 40 + 25 * k
+        frame[y + 300:y + 303, x0:x0 + 6 + k] = GREEN
+    _check_markers(vision, frame, max_gap=max_gap)
+
+
+def test_stress_find_longest_line_odd_gaps_and_outside_points(vision):
+    """Vision::find_longest_line with max_gap <= 0 / fractional / huge and start points outside the image."""
+    frame, e, g = fx.load_fixture("point_intersect_png")
+    run_trait_sequence(vision, frame)
+    lsd = vision.lsd_image()
+    h, w = lsd.shape
+    ys, xs = np.nonzero(lsd == 255)
+    inside = (float(xs[len(xs) // 2]), float(ys[len(ys) // 2]))
+    pts = [inside, (-3.0, 10.0), (10.0, -2.5), (w + 5.0, 20.0), (30.0, h + 1.0), (w - 0.5, h - 0.5), (0.25, 0.75)]
+    for gap in (0.0, -1.0, 0.5, 15.5, 31.0, 31.5, 64.0, 1e6):
+        for p in pts:
+            line, ln = vision.find_longest_line(p, gap)
+            rl, rn = o.find_longest_line(lsd, p[0], p[1], gap)
+            assert np.array_equal(line, rl) and ln == rn, (p, gap, line, rl, ln, rn)
+
+
+def test_stress_lines_hugging_all_borders(vision):
+    """Marker lines along and into all four ROI borders (rays leave the image: end-point quirk paths)."""
+    W, H = 1600, 1024
+    frame, (x, y, rw, rh) = _blank(W, H, 23)
+    frame[y:y + 3, x + 20:x + rw - 20] = GREEN                # along the top edge
+    frame[y + rh - 3:y + rh, x + 20:x + rw - 20] = PURPLE     # along the bottom edge
+    frame[y + 40:y + rh - 40, x:x + 3] = GREEN                # left edge
+    frame[y + 40:y + rh - 40, x + rw - 3:x + rw] = PURPLE     # right edge
+    for k in range(200):                                       # diagonal into the bottom-right corner
+        frame[y + rh - 1 - k, x + rw - 1 - k] = GREEN
+        frame[y + rh - 1 - k, x + rw - 2 - k] = GREEN
+    _check_markers(vision, frame)
+
+
+def test_stress_4k_frame(vision):
+    """3840x2160: 494 quads per row (8 waves per workgroup), 2160p ROI 1972x1644 does not fit LDS."""
+    from squad_mortar_helper_amd import synth
+    frame, info = synth.make_frame(3840, 2160, 3, n_lines=3)
+    ref = o.process_frame(frame, stages=0xF, anchors=info["anchors"], scales_start_y=info["scales_start_y"], want_images=True)
+    res = run_trait_sequence(vision, frame, anchors=info["anchors"])
+    assert np.array_equal(res.map, ref["ui_map"]) and np.array_equal(vision.lsd_image(), ref["lsd"])
+    assert np.array_equal(res.markers, ref["lines"]) and res.meters_to_px_ratio == ref["mpx"]
+    assert np.array_equal(vision.ocr_preprocess(), ref["ocr"])
+
+
+def test_stress_random_scenes(vision):
+    """Random mixes of lines (all angles, 1-5 px thick), blobs, rings and noise at three sizes."""
+    from squad_mortar_helper_amd import synth
+    import squad_mortar_helper_amd as smh
+    rng = np.random.default_rng(77)
+    for trial, (W, H) in enumerate([(1024, 768), (1920, 1080), (1280, 1024), (1920, 1080), (2560, 1440), (1600, 1024)]):
+        frame, _ = synth.make_frame(W, H, 50 + trial, n_lines=0)
+        x, y, rw, rh = smh.map_bounds(W, H)
+        roi = frame[y:y + rh, x:x + rw]
+        for _ in range(int(rng.integers(1, 6))):
+            col = GREEN if rng.random() < 0.5 else PURPLE
+            p0 = rng.uniform([0, 0], [rw, rh]); ang = rng.uniform(0, 2 * np.pi); L = rng.uniform(30, 0.8 * min(rw, rh))
+            t = np.linspace(0, 1, int(L * 2) + 2)
+            px = np.clip(np.rint(p0[0] + np.cos(ang) * L * t), 0, rw - 1).astype(int)
+            py = np.clip(np.rint(p0[1] + np.sin(ang) * L * t), 0, rh - 1).astype(int)
+            th = int(rng.integers(1, 6))
+            for dy in range(th):
+                for dx in range(th):
+                    roi[np.clip(py + dy, 0, rh - 1), np.clip(px + dx, 0, rw - 1)] = col
+        for _ in range(int(rng.integers(0, 4))):               # blobs and rings
+            cx, cy, r = int(rng.integers(20, rw - 20)), int(rng.integers(20, rh - 20)), int(rng.integers(4, 18))
+            yy, xx = np.ogrid[-r:r + 1, -r:r + 1]
+            d2 = xx * xx + yy * yy
+            m = (d2 <= r * r) & ((d2 >= (r - 3) ** 2) if rng.random() < 0.5 else True)
+            sub = roi[max(cy - r, 0):cy + r + 1, max(cx - r, 0):cx + r + 1]
+            mm = m[max(r - cy, 0):max(r - cy, 0) + sub.shape[0], max(r - cx, 0):max(r - cx, 0) + sub.shape[1]]
+            sub[mm] = GREEN
+        k = int(rng.integers(0, 60))
+        roi[rng.integers(0, rh, k), rng.integers(0, rw, k)] = PURPLE
+        _check_markers(vision, frame, max_gap=int(rng.choice([15, 15, 22, 9])))
