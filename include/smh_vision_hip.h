@@ -104,6 +104,11 @@ SMHV_API int smhv_find_marker_lines(smhv_ctx *ctx, uint32_t max_gap, smhv_line o
  * find_scales_preprocess.  scales = n x {meters, x, y} (OCR label anchors, BRQ coordinates), n <= 3.
  * *has = 0 reproduces None.  bars (optional) = n x {left, y, right, found} (the scales_debug lines). */
 SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *ctx, const uint32_t *scales, uint32_t n, double *ratio, int *has, uint32_t *bars);
+/* find_minimap (src/vision/find_minimap.rs:47-146; host code in the reference, run on get_cpu_frame().view(roi)
+ * right after crop_to_map, src/vision/mod.rs:85) on the resident frame: four directed walks from the ROI centre
+ * over the "edginess" (max neighbour colour distance) of the BGRA frame.  rect = {left, right, top, bottom} in
+ * ROI coordinates; *found = 0 reproduces None. */
+SMHV_API int smhv_find_minimap(smhv_ctx *ctx, uint32_t rect[4], int *found);
 /* Vision::get_debug_view (vision-cpu/src/lib.rs:451-460): RGBA copy; rgba may be NULL to query w,h. */
 SMHV_API int smhv_get_debug_view(smhv_ctx *ctx, int which, uint8_t *rgba, uint32_t *w, uint32_t *h);
 
@@ -113,6 +118,7 @@ SMHV_API int smhv_get_debug_view(smhv_ctx *ctx, int which, uint8_t *rgba, uint32
 #define SMHV_STAGE_OCR 0x4u     /* ocr_preprocess                                                */
 #define SMHV_STAGE_SCALES 0x8u  /* find_scales_preprocess + calc_meters_to_px_ratio (needs anchors) */
 #define SMHV_STAGE_ALL 0xFu
+#define SMHV_STAGE_MINIMAP 0x10u /* find_minimap (not a Vision trait method; the caller's next step, not in STAGE_ALL) */
 
 /* One record per frame (what a node-level gather moves between GPUs).  mpx/derived fields follow
  * src/ui/mod.rs:131-140 (length_px, meters in f64) and src/ui/markers.rs:98 (angle = atan2f). */
@@ -129,6 +135,9 @@ typedef struct {
 	double length_px[SMHV_MAX_LINES];
 	double meters[SMHV_MAX_LINES];  /* length_px * mpx (0 when !has_mpx)                           */
 	float angle[SMHV_MAX_LINES];
+	uint32_t minimap[4];            /* find_minimap: {left, right, top, bottom} in map-ROI coordinates  */
+	uint32_t has_minimap;           /* 1 iff SMHV_STAGE_MINIMAP ran and the map is open                 */
+	uint32_t reserved;
 } smhv_frame_result;
 
 /* per-frame OCR anchors for SMHV_STAGE_SCALES: OCR (Tesseract) is outside this library */

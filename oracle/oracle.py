@@ -68,6 +68,7 @@ def lib():
         L.orc_marker_new.argtypes = [f32p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_marker_angle.restype = C.c_float
         L.orc_marker_angle.argtypes = [f32p]
+        L.orc_find_minimap.argtypes = [u8p, C.c_uint32, C.c_uint32, u32p]
         L.orc_process_frame.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                         C.c_uint32, C.POINTER(FrameResult), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_process_batch.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -220,6 +221,16 @@ def calc_meters_to_px_ratio(scales, img):
     r = C.c_double()
     ok = lib().orc_calc_meters_to_px_ratio(sc, len(sc), np.ascontiguousarray(img), w, h, C.byref(r))
     return r.value if ok else None
+
+
+def find_minimap(frame_bgra):
+    """-> (left, right, top, bottom) in map-ROI coordinates, or None (src/vision/find_minimap.rs:47)."""
+    H, W, _ = frame_bgra.shape
+    rect = np.zeros(4, np.uint32)
+    rc = lib().orc_find_minimap(np.ascontiguousarray(frame_bgra), W, H, rect)
+    if rc < 0:
+        raise ValueError("geometry")
+    return tuple(int(v) for v in rect) if rc == 1 else None
 
 
 def marker_new(line, ratio):

@@ -568,6 +568,64 @@ ORC_API void orc_marker_new(const float line[4], double ratio, double *length_px
 }
 ORC_API float orc_marker_angle(const float line[4]) { return atan2f(line[1] - line[3], line[0] - line[2]); }
 
+/* ---- find_minimap: src/vision/find_minimap.rs:8-146 (the step next to crop_to_map in process()) ---- */
+/* get_edginess (find_minimap.rs:8-45): max over the 8 neighbours of sum |dB|+|dG|+|dR|, as f32 / 765.0 */
+static float get_edginess(const uint8_t *bgra, uint32_t W, uint32_t ox, uint32_t oy, uint32_t x, uint32_t y) {
+	static const int per[8][2] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 1}, {0, 1}, {1, 1}, {-1, 0}, {1, 0}};
+	const uint8_t *p = bgra + ((size_t)(oy + y) * W + ox + x) * 4;
+	uint16_t max = 0;
+	for (int k = 0; k < 8; ++k) {
+		const uint8_t *q = bgra + ((size_t)(oy + y + per[k][1]) * W + ox + x + per[k][0]) * 4;
+		uint16_t s = (uint16_t)(abs_diff_i(p[0], q[0]) + abs_diff_i(p[1], q[1]) + abs_diff_i(p[2], q[2]));
+		if (s > max) max = s;
+	}
+	return (float)max / 765.0f;
+}
+/* find_edge (find_minimap.rs:63-129); dir: 0 = Up, 1 = Down, 2 = Left, 3 = Right.  u32 arithmetic wraps as in a
+ * release build. */
+static uint32_t find_edge(const uint8_t *bgra, uint32_t W, uint32_t ox, uint32_t oy, uint32_t w, uint32_t h, uint32_t x, uint32_t y, int dir) {
+	const float EDGINESS_THRESHOLD = 0.01f;
+	uint32_t xy[2] = {x, y};
+	const int c = dir < 2 ? 1 : 0, oc = dir < 2 ? 0 : 1;
+	uint32_t c_max = dir < 2 ? h : w, oc_max = dir < 2 ? w : h;
+	const int cod = (dir == 0 || dir == 2) ? -1 : 1;
+	const uint32_t d = oc_max > xy[oc] ? oc_max - xy[oc] : xy[oc] - oc_max;
+	const uint32_t min_line_length0 = d / 2u - 1u;
+	c_max -= 3u; oc_max -= 3u;
+	for (;;) {
+		xy[c] = (uint32_t)((int32_t)xy[c] + cod);
+		if (xy[c] > c_max) return c_max + 2u;
+		else if (xy[c] < 3u) return 0u;
+		if (get_edginess(bgra, W, ox, oy, xy[0], xy[1]) <= EDGINESS_THRESHOLD) {
+			const uint32_t ret = xy[c];
+			uint32_t p[2] = {xy[0], xy[1]};
+			uint32_t min_line_length = min_line_length0;
+			int ok = 1;
+			while (min_line_length > 0u) {
+				p[oc] = (uint32_t)((int32_t)p[oc] - cod);
+				if (p[oc] < 3u || p[oc] > oc_max) { ok = 0; break; }
+				if (get_edginess(bgra, W, ox, oy, p[0], p[1]) <= EDGINESS_THRESHOLD) min_line_length -= 1u;
+				else { ok = 0; break; }
+			}
+			if (ok) return (uint32_t)((int32_t)ret - cod);
+		}
+	}
+}
+/* find_minimap on the map ROI of the frame (src/vision/mod.rs:85).  rect = {left, right, top, bottom} in ROI
+ * coordinates; returns 1 = Some, 0 = None, -1 = geometry invalid. */
+ORC_API int orc_find_minimap(const uint8_t *bgra, uint32_t W, uint32_t H, uint32_t rect[4]) {
+	uint32_t mb[4];
+	if (!orc_map_bounds(W, H, mb)) return -1;
+	const uint32_t w = mb[2], h = mb[3];
+	if (w < 3u || h < 3u) return 0;
+	const uint32_t x = w / 2u, y = h / 2u;
+	rect[0] = find_edge(bgra, W, mb[0], mb[1], w, h, x, y, 2);
+	rect[1] = find_edge(bgra, W, mb[0], mb[1], w, h, x, y, 3);
+	rect[2] = find_edge(bgra, W, mb[0], mb[1], w, h, x, y, 0);
+	rect[3] = find_edge(bgra, W, mb[0], mb[1], w, h, x, y, 1);
+	return 1;
+}
+
 /* ---- whole-frame driver (call order of src/vision/mod.rs:36-240) -------------------------- */
 /* Used for the CPU baseline timing and for end-to-end goldens.  anchors = n x (meters,x,y)
  * OCR label anchors in BRQ coordinates (OCR itself is out of scope; anchors are inputs).

@@ -33,7 +33,8 @@ def results_to_dicts(recs):
             mpx=(r.mpx if r.has_mpx else None), n_mask_px=int(r.n_mask_px), red_pixels=int(r.red_pixels),
             rounds=int(r.rounds), ray_steps=int(r.ray_steps),
             length_px=np.array(r.length_px[:n], np.float64), meters=np.array(r.meters[:n], np.float64),
-            angle=np.array(r.angle[:n], np.float32)))
+            angle=np.array(r.angle[:n], np.float32),
+            minimap=(tuple(r.minimap) if r.has_minimap else None)))
     return out
 
 

@@ -56,6 +56,7 @@ hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 // mode 0: find_lines (whole frame); mode 1: one find_longest_line round from (px,py), result in results[f].lines[0], len^2 in length_px[0]
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s);
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
+hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);
 hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s);
 // which: SMHV_VIEW_*; isolated: LSDPreprocess shows the marker-isolated crop (after isolate_map_markers)
 hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s);

@@ -15,6 +15,7 @@
 //                 candidate groups, batched ray walking,
 //                 mask window resident in LDS                                (lsd.rs:5-107, lib.rs:387-449)
 //   k_scale_ratio calc_meters_to_px_ratio / find_scale_width                 (src/vision/mpx_ratio.rs:3-134)
+//   k_find_minimap find_minimap (the caller's next step)                      (src/vision/find_minimap.rs)
 //   k_finalize    derived marker outputs                                     (src/ui/mod.rs:131-140, markers.rs:98)
 #include "smh_kernels.h"
 #include "smh_consts.h"
@@ -1301,6 +1302,81 @@ __global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Bu
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_find_minimap: src/vision/find_minimap.rs (the caller's step right after crop_to_map).
+// One wave per direction (Left, Right, Up, Down), four waves per frame.  The reference walks pixel by
+// pixel from the ROI centre and, at every pixel whose "edginess" is <= 0.01, tries a perpendicular run of
+// min_line_length equally flat pixels.  Here 64 steps of the main walk are tested at once (ballot, handled
+// in walk order) and the perpendicular run is tested 64 pixels per step; the result is the reference's.
+// edginess = max over the 8 neighbours of |dB|+|dG|+|dR|, as f32 / 765.0 <= 0.01  <=>  that max <= 7
+// (7/765 = 0.00915, 8/765 = 0.01046).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool flat_pixel(const uint8_t *roi0, uint32_t W, uint32_t x, uint32_t y) {
+	const uint32_t *p = (const uint32_t *)(roi0 + ((size_t)y * W + x) * 4);
+	const int Wi = (int)W;
+	const uint32_t c = p[0] & 0x00FFFFFFu;
+	uint32_t mx = 0;
+#pragma unroll
+	for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+		for (int dx = -1; dx <= 1; ++dx)
+			if (dx != 0 || dy != 0) mx = max(mx, (uint32_t)__builtin_amdgcn_sad_u8(c, p[dy * Wi + dx] & 0x00FFFFFFu, 0u));
+	return (float)mx / 765.0f <= 0.01f;
+}
+
+__device__ uint32_t find_edge(const uint8_t *roi0, uint32_t W, uint32_t w, uint32_t h, uint32_t x0, uint32_t y0, int dir) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool vertical = dir < 2;                         // Up, Down move y; Left, Right move x
+	uint32_t c_max = vertical ? h : w, oc_max = vertical ? w : h;
+	const int cod = (dir == 0 || dir == 2) ? -1 : 1;
+	const uint32_t c0 = vertical ? y0 : x0, oc0 = vertical ? x0 : y0;
+	const uint32_t d = oc_max > oc0 ? oc_max - oc0 : oc0 - oc_max;
+	const uint32_t mll = d / 2u - 1u;                      // min_line_length (wraps like release Rust; >= 0 for dims >= 3)
+	c_max -= 3u; oc_max -= 3u;
+	uint32_t cbase = c0;
+	for (;;) {
+		const uint32_t cc = (uint32_t)((int32_t)cbase + cod * (int32_t)(lane + 1u));
+		const int st = cc > c_max ? 1 : (cc < 3u ? 2 : 0);     // order of the reference's two tests
+		bool low = false;
+		if (st == 0) low = flat_pixel(roi0, W, vertical ? oc0 : cc, vertical ? cc : oc0);
+		const uint64_t term = __ballot(st != 0);
+		uint64_t lows = __ballot(low);
+		for (;;) {
+			const uint64_t both = term | lows;
+			if (!both) break;
+			const uint32_t first = (uint32_t)__builtin_ctzll(both);
+			const uint32_t fc = (uint32_t)((int32_t)cbase + cod * (int32_t)(first + 1u));
+			if ((term >> first) & 1ull) return fc > c_max ? c_max + 2u : 0u;
+			// a flat pixel: "try and find a straight line of pixels that are also under the edginess threshold"
+			bool ok = true;
+			for (uint32_t kb = 0; kb < mll && ok; kb += 64u) {
+				const uint32_t k = kb + lane + 1u;
+				bool good = true;
+				if (k <= mll) {
+					const uint32_t oc = (uint32_t)((int32_t)oc0 - cod * (int32_t)k);
+					good = !(oc < 3u || oc > oc_max) && flat_pixel(roi0, W, vertical ? oc : fc, vertical ? fc : oc);
+				}
+				ok = __all(good);
+			}
+			if (ok) return (uint32_t)((int32_t)fc - cod);
+			lows &= ~(1ull << first);
+		}
+		cbase = (uint32_t)((int32_t)cbase + cod * 64);
+	}
+}
+
+__global__ void __launch_bounds__(256) k_find_minimap(Geom g, Buffers b) {
+	const uint32_t f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	smhv_frame_result *res = &b.results[f];
+	if (!b.aux[f].open) { if (threadIdx.x < 4) res->minimap[threadIdx.x] = 0; if (threadIdx.x == 0) res->has_minimap = 0; return; }
+	const uint8_t *roi0 = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.rx) * 4;
+	// rect = {left, right, top, bottom}; reference direction order: Left, Right, Up, Down
+	const int dir = wave == 0 ? 2 : (wave == 1 ? 3 : (wave == 2 ? 0 : 1));
+	const uint32_t v = find_edge(roi0, g.W, g.rw, g.rh, g.rw / 2u, g.rh / 2u, dir);
+	if (lane == 0) res->minimap[wave] = v;
+	if (threadIdx.x == 0) res->has_minimap = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_finalize: per-frame record header + ui::Marker::new / angle (src/ui/mod.rs:131-140, markers.rs:98)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t stages) {
@@ -1337,6 +1413,8 @@ __global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t sta
 		res->n_mask_px = (open && markers) ? aux.n_mask_px : 0u;
 		res->red_pixels = aux.red;
 		if (!(open && markers)) { res->rounds = 0; res->ray_steps = 0; }
+		if (!(stages & SMHV_STAGE_MINIMAP)) { res->has_minimap = 0; res->minimap[0] = 0; res->minimap[1] = 0; res->minimap[2] = 0; res->minimap[3] = 0; }
+		res->reserved = 0;
 	}
 }
 
@@ -1416,6 +1494,11 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s) {
 	hipLaunchKernelGGL(k_scale_ratio, dim3(n), dim3(64 * SMHV_MAX_SCALES), 0, s, g, b, d_bars);
+	return hipGetLastError();
+}
+
+hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s) {
+	hipLaunchKernelGGL(k_find_minimap, dim3(n), dim3(256), 0, s, g, b);
 	return hipGetLastError();
 }
 

@@ -122,7 +122,7 @@ struct smhv_batch {
 	uint8_t *d_ui = nullptr, *d_mask = nullptr, *d_ocr = nullptr, *d_scales = nullptr;
 	uint32_t *d_bits = nullptr, *d_bars = nullptr;
 	FrameAux *d_aux = nullptr;
-	smhv_frame_result *d_results = nullptr;   // max_frames (+2 spare records for the per-frame trait path)
+	smhv_frame_result *d_results = nullptr;   // max_frames (+3 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
 	// pinned staging for the per-run anchor upload (a pageable source would make hipMemcpyAsync synchronous);
 	// two slots + events so a run never overwrites a slot whose copy is still in flight
@@ -257,7 +257,7 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 	ALLOC0(b->d_ocr, g.ocr_stride * n);
 	ALLOC0(b->d_scales, g.ocr_stride * n);      // zero-initialised like GrayImage::new (lib.rs:86)
 	ALLOC0(b->d_aux, sizeof(FrameAux) * n);
-	ALLOC0(b->d_results, sizeof(smhv_frame_result) * (n + 2));
+	ALLOC0(b->d_results, sizeof(smhv_frame_result) * (n + 3));
 	ALLOC0(b->d_anchors, sizeof(smhv_anchors) * n);
 	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
 #undef ALLOC0
@@ -321,7 +321,7 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                                        const smhv_anchors *anchors, void *stream) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
-	if ((stages & SMHV_STAGE_ALL) == 0) return fail(SMHV_E_INVALID, "no stage selected");
+	if ((stages & (SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP)) == 0) return fail(SMHV_E_INVALID, "no stage selected");
 	hipStream_t s = (hipStream_t)stream;
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
@@ -350,6 +350,7 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	if (t) HIPCHK(hipEventRecord(ev[3], s));
 	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, s));
 	if (t) HIPCHK(hipEventRecord(ev[4], s));
+	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, s));
 	if (scales) HIPCHK(launch_scale_ratio(g, bf, n, b->d_bars, s));
 	HIPCHK(launch_finalize(g, bf, n, scales ? stages : (stages & ~SMHV_STAGE_SCALES), s));
 	if (t) { HIPCHK(hipEventRecord(ev[5], s)); b->timed_runs++; }
@@ -656,6 +657,22 @@ extern "C" SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *c, const uint32_t
 	*has = c->h_res[1].has_mpx ? 1 : 0;
 	*ratio = c->h_res[1].mpx;
 	if (bars) memcpy(bars, c->h_bars, sizeof(uint32_t) * 4 * n);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_find_minimap(smhv_ctx *c, uint32_t rect[4], int *found) {
+	int rc = require_open(c, "find_minimap");
+	if (rc) return rc;
+	if (!rect || !found) return fail(SMHV_E_INVALID, "null output");
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	Buffers bf = make_buffers(b, c->frame_ptr, 3);          // its own record slot: runs on the crop stream
+	hipStream_t s = c->s_main;
+	HIPCHK(launch_find_minimap(b->g, bf, 1, s));
+	HIPCHK(hipMemcpyAsync(&c->h_res[3], b->d_results + 3, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	*found = c->h_res[3].has_minimap ? 1 : 0;
+	memcpy(rect, c->h_res[3].minimap, sizeof(uint32_t) * 4);
 	return SMHV_OK;
 }
 

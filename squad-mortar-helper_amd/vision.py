@@ -100,6 +100,12 @@ class HipVision:
         L.check(self._lib.smhv_red_pixels(self._ctx, C.byref(n)))
         return n.value
 
+    def find_minimap(self):
+        """src/vision/find_minimap.rs:47 on the resident frame -> (left, right, top, bottom) in ROI coordinates or None."""
+        rect, found = (C.c_uint32 * 4)(), C.c_int()
+        L.check(self._lib.smhv_find_minimap(self._ctx, rect, C.byref(found)))
+        return tuple(rect) if found.value else None
+
     # -- trait: scales branch -----------------------------------------------------------------
     def ocr_preprocess(self):
         """-> uint8[h/2, w/2] (copy of the borrowed buffer the reference returns as (ptr, len))."""
@@ -175,6 +181,7 @@ class VisionResults:
     def __init__(self):
         self.map = None
         self.roi = None
+        self.minimap_bounds = None
         self.markers = np.zeros((0, 4), np.float32)
         self.meters_to_px_ratio = None
         self.debug_view = None
@@ -197,6 +204,7 @@ class VisionState:
             return None
         res = VisionResults()
         res.map, res.roi = cropped
+        res.minimap_bounds = vision.find_minimap()           # src/vision/mod.rs:85
         out, err = {}, []
 
         def markers():

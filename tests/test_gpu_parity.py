@@ -476,3 +476,45 @@ def test_stress_random_scenes(vision):
         k = int(rng.integers(0, 60))
         roi[rng.integers(0, rh, k), rng.integers(0, rw, k)] = PURPLE
         _check_markers(vision, frame, max_gap=int(rng.choice([15, 15, 22, 9])))
+
+
+# ---------------------------------------------------------------------------------------------------
+# find_minimap (the caller's step next to crop_to_map)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stem", fx.FULL_STEMS + ["in_mortar_png", "full_jpg"])
+def test_find_minimap_matches_oracle_on_samples(vision, stem):
+    frame, e, _ = fx.load_fixture(stem)
+    res = run_trait_sequence(vision, frame)
+    assert res.minimap_bounds == o.find_minimap(frame)
+
+
+def test_find_minimap_synthetic_and_batch(vision):
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N = 1920, 1080, 6
+    frames, infos = synth.make_batch(W, H, N, first_idx=300)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    rng = np.random.default_rng(9)
+    for i in range(1, N):                                        # flat rectangles of different extents around the centre
+        l, r = int(rng.integers(5, rw // 2 - 5)), int(rng.integers(rw // 2 + 5, rw - 5))
+        t, b = int(rng.integers(5, rh // 2 - 5)), int(rng.integers(rh // 2 + 5, rh - 5))
+        frames[i, y + t:y + b, x + l:x + r, :3] = (40 + 30 * i, 90, 120)
+        if i == 3:
+            frames[i, y + t + 40:y + b - 40, x + l + 70, :3] = 255   # a bright vertical line inside: edge found earlier on one side
+        if i == 4:
+            frames[i, y + rh // 2 - 1, x + l:x + r, 1] = 97          # a faint (<= threshold) horizontal line through the centre row
+    frames[5], _ = synth.make_frame(W, H, 305, map_open=False)
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_MINIMAP, stream=torch.cuda.current_stream().cuda_stream)
+    recs = smh.results_to_dicts(fb.read_results(0, N))
+    for i in range(N):
+        want = o.find_minimap(frames[i]) if o.crop_to_map(frames[i]) is not None else None
+        assert recs[i]["minimap"] == want, (i, recs[i]["minimap"], want)
+        vision.load_frame(frames[i])
+        if vision.crop_to_map(True) is not None:
+            assert vision.find_minimap() == want
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL, stream=torch.cuda.current_stream().cuda_stream)
+    assert all(r["minimap"] is None for r in smh.results_to_dicts(fb.read_results(0, N)))   # stage not selected
+    fb.close()

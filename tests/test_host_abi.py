@@ -21,7 +21,7 @@ def header_symbols():
 def test_library_exports_every_declared_symbol(built):
     from squad_mortar_helper_amd import _lib
     names = header_symbols()
-    assert len(names) >= 29 and set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert len(names) >= 30 and set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
     lib = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
@@ -74,8 +74,8 @@ def test_init_without_gpu_fails_loudly_not_silently(built):
 
 def test_record_layout_matches_header(built):
     from squad_mortar_helper_amd import _lib
-    # smhv_frame_result: 8 + 32*16 + 8 + 4*4 + 8 + 32*8*2 + 32*4 = 1192
-    assert C.sizeof(_lib.FrameResult) == 1192
+    # smhv_frame_result: 8 + 32*16 + 8 + 4*4 + 8 + 32*8*2 + 32*4 + 6*4 = 1216
+    assert C.sizeof(_lib.FrameResult) == 1216 and _lib.FrameResult.minimap.offset == 1192
     assert _lib.FrameResult.lines.offset == 8 and _lib.FrameResult.mpx.offset == 520
     assert _lib.FrameResult.ray_steps.offset == 544 and _lib.FrameResult.length_px.offset == 552
     assert C.sizeof(_lib.Anchors) == 44 and C.sizeof(_lib.Line) == 16

@@ -226,3 +226,37 @@ def test_synthetic_frames_are_deterministic_and_marker_free_terrain(built):
     assert res["map_open"] == 1 and res["n_mask_px"] == 0 and res["n_lines"] == 0
     closed, _ = synth.make_frame(1024, 768, 5, map_open=False)
     assert o.process_frame(closed)["map_open"] == 0
+
+
+# find_minimap: rects produced by the oracle on the full fixtures when the row was added.
+# full_1600x1024: a 689 x 690 px minimap square inside the 714 x 779 ROI, as the screenshot shows.
+MINIMAP_GOLDEN = {
+    "full_1024x768_png": (7, 359, 128, 493), "full_1280x1024_png": (15, 393, 214, 584), "full_1600x1024_png": (24, 713, 54, 744),
+    "point_intersect_png": (141, 1208, 29, 1095), "points_intersect_png": (141, 1208, 29, 1095), "snowpoints_png": (141, 1208, 29, 1095),
+    "tinyscales_png": (15, 393, 11, 778), "whiteout_png": (657, 657, 548, 548),
+}
+
+
+@pytest.mark.parametrize("stem", sorted(MINIMAP_GOLDEN))
+def test_find_minimap_goldens(stem):
+    frame, e, _ = fx.load_fixture(stem)
+    assert o.find_minimap(frame) == MINIMAP_GOLDEN[stem]
+
+
+def test_find_minimap_hand_made():
+    """A textured (minimap-like) rectangle around the ROI centre inside flat UI: each walk stops at the first flat
+    pixel that has a long flat run perpendicular to the walk, i.e. just outside the textured rectangle."""
+    from squad_mortar_helper_amd import synth
+    W, H = 1024, 768
+    frame, _ = synth.make_frame(W, H, 1, n_lines=0)             # terrain is per-pixel noise: edginess is high everywhere
+    x, y, w, h = o.map_bounds(W, H)
+    assert o.find_minimap(frame) == (0, w - 1, 0, h - 1)       # never finds a flat run: walks to the ROI borders
+    tex = frame[y:y + h, x:x + w].copy()
+    frame[y:y + h, x:x + w, :3] = 90                             # flat UI ...
+    l, r, t, b = 60, 300, 100, 500
+    frame[y + t:y + b, x + l:x + r] = tex[t:b, l:r]              # ... around a textured rectangle that holds the centre
+    got = o.find_minimap(frame)
+    assert got == (l - 1, r, t - 1, b), got                      # the last pixel whose 3x3 neighbourhood still touches the texture
+    centre_flat = frame.copy()
+    centre_flat[y + h // 2 - 5:y + h // 2 + 5, x + 20:x + w - 20, :3] = 90   # a flat band through the centre: found at once
+    assert o.find_minimap(centre_flat)[:2] == (w // 2, w // 2)
