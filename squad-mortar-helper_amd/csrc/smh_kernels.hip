@@ -492,7 +492,9 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 #define LSD_QCAP 2048u
 #define LSD_QPT (LSD_QCAP / LSD_BS)                   // queue entries per thread in phase B
 #define LSD_A_BATCHES 2u                            // 32-sample batches walked in phase A before a ray is queued
-#define LSD_WIN_WORDS_CAP 30000u                   // 1080p whole-ROI padded window = 824 x 35 = 28840 words
+#define LSD_WIN_WORDS_CAP 30000u                   // 1080p whole ROI in ROWS mode = 824 rows x 33 words + 4 = 27196 words.
+// (With 153 KB of LDS per workgroup nothing else shares the CU.  Tried: a 28000-word cap lets a streaming workgroup of the
+// next pipelined step co-reside -- measured 2 % slower overall and k_map_pass 0.52 -> 0.62 ms, the two compete for VALU issue.)
 #define LSD_ROWS_PITCH(gp) ((gp) | 1u)                 // LDS row pitch (words) of LSD_MODE_ROWS
 #define LSD_DYN_LDS_BYTES ((LSD_WIN_WORDS_CAP + LSD_LIST_CAP + 2u * LSD_QCAP) * 4u)
 
@@ -1195,24 +1197,31 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	PROF_STORE(res);
 }
 
-__global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	__shared__ LsdShared sh;
-	const uint32_t f = blockIdx.x;
-	const FrameAux aux = b.aux[f];
-	if (mode == 0) {
-		if (threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
-		if (!aux.open || aux.n_mask_px == 0) return;
-	}
+// One kernel per mask residency mode, launched back to back over all frames: a workgroup whose frame
+// needs another mode exits at once.  Split this way the common ROWS kernel carries no call to the rarely
+// used variants, needs 104 VGPRs and no scratch (the three-in-one kernel needed 128 and spilled at its call sites).
+__device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux) {
 	int lmode = LSD_MODE_GLOBAL;                           // also the empty-mask single-round case
 	if (aux.n_mask_px != 0) {
 		const uint32_t wrows = aux.y_max - aux.y_min + 1u, wwords = aux.w_max - aux.w_min + 1u;
 		if ((wrows + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_ROWS;
 		else if ((wrows + 2u) * ((wwords + 2u) | 1u) <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_XWIN;
 	}
-	if (lmode == LSD_MODE_ROWS) lsd_frame<LSD_MODE_ROWS>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
-	else if (lmode == LSD_MODE_XWIN) lsd_frame<LSD_MODE_XWIN>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
-	else lsd_frame<LSD_MODE_GLOBAL>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+	return lmode;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	__shared__ LsdShared sh;
+	const uint32_t f = blockIdx.x;
+	const FrameAux aux = b.aux[f];
+	if (mode == 0) {
+		if (MODE == LSD_MODE_ROWS && threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
+		if (!aux.open || aux.n_mask_px == 0) return;
+	}
+	if (lsd_mode_for(g, aux) != MODE) return;
+	lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1483,12 +1492,16 @@ size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s) {
 	static bool attr_set = false;
+	const unsigned lds_full = LSD_DYN_LDS_BYTES, lds_global = (LSD_LIST_CAP + 2u * LSD_QCAP) * 4u;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_lsd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSD_DYN_LDS_BYTES);
+		hipError_t e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL(k_lsd, dim3(n), dim3(LSD_BS), LSD_DYN_LDS_BYTES, s, g, b, max_gap, mode, px, py);
+	hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py);
+	hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py);
+	hipLaunchKernelGGL(k_lsd<LSD_MODE_GLOBAL>, dim3(n), dim3(LSD_BS), lds_global, s, g, b, max_gap, mode, px, py);
 	return hipGetLastError();
 }
 
