@@ -518,3 +518,32 @@ def test_find_minimap_synthetic_and_batch(vision):
     fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL, stream=torch.cuda.current_stream().cuda_stream)
     assert all(r["minimap"] is None for r in smh.results_to_dicts(fb.read_results(0, N)))   # stage not selected
     fb.close()
+
+
+def test_two_batches_in_flight_on_two_streams_do_not_interfere(vision):
+    """bench.py keeps two steps in flight (two FrameBatch objects, two HIP streams): records must equal the
+    ones produced one step at a time."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N = 1920, 1080, 48
+    fa, ia = synth.make_batch(W, H, N, first_idx=500)
+    fb_, ib = synth.make_batch(W, H, N, first_idx=700, n_lines=3)
+    da, db = torch.from_numpy(fa).cuda(), torch.from_numpy(fb_).cuda()
+    anc_a = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in ia])
+    anc_b = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in ib])
+    ba, bb = smh.FrameBatch(vision, W, H, N), smh.FrameBatch(vision, W, H, N)
+    s0 = torch.cuda.current_stream()
+    ba.run(da.data_ptr(), N, anchors=anc_a, stream=s0.cuda_stream)
+    ref_a = bytes(ba.read_results(0, N))
+    bb.run(db.data_ptr(), N, anchors=anc_b, stream=s0.cuda_stream)
+    ref_b = bytes(bb.read_results(0, N))
+    assert ref_a != ref_b
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(s0); s2.wait_stream(s0)
+    for _ in range(4):                                           # A and B alternate, two steps in flight
+        ba.run(da.data_ptr(), N, anchors=anc_a, stream=s1.cuda_stream)
+        bb.run(db.data_ptr(), N, anchors=anc_b, stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert bytes(ba.read_results(0, N)) == ref_a and bytes(bb.read_results(0, N)) == ref_b
+    ba.close(); bb.close()
