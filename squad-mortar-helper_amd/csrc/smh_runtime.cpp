@@ -132,9 +132,15 @@ struct smhv_batch {
 	// per-stage hipEvent ring: up to TIMING_RING timed runs are kept so a benchmark loop can read the
 	// average stage durations afterwards without synchronising between steps
 	static constexpr int TIMING_RING = 64;
+	static constexpr int TIMING_EVENTS = 10;              // start/end of button, map pass, brq pass, lsd, scale ratio
 	bool timing = false;
-	hipEvent_t (*ev)[6] = nullptr;
+	hipEvent_t (*ev)[TIMING_EVENTS] = nullptr;
 	uint64_t timed_runs = 0;
+	// The scales branch (brq pass + scale ratio) runs on its own stream beside the markers branch, like the two
+	// concurrent branches of VisionState::process (src/vision/mod.rs:219-223): fork after the button test, join
+	// before the record is finalised.
+	hipStream_t s_scales = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct smhv_ctx {
@@ -261,6 +267,12 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 	ALLOC0(b->d_anchors, sizeof(smhv_anchors) * n);
 	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
 #undef ALLOC0
+	{
+		hipError_t e = hipStreamCreateWithFlags(&b->s_scales, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+		if (e != hipSuccess) { smhv_batch_destroy(b); return fail(SMHV_E_HIP, "scales-branch stream: %s", hipGetErrorString(e)); }
+	}
 	for (int i = 0; i < 2; ++i) {
 		hipError_t e = hipHostMalloc((void **)&b->h_anchors[i], sizeof(smhv_anchors) * n);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->anchors_done[i], hipEventDisableTiming);
@@ -283,9 +295,12 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	}
 	if (b->ev) {
 		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
-			for (int i = 0; i < 6; ++i) (void)hipEventDestroy(b->ev[r][i]);
+			for (int i = 0; i < smhv_batch::TIMING_EVENTS; ++i) (void)hipEventDestroy(b->ev[r][i]);
 		delete[] b->ev;
 	}
+	if (b->s_scales) (void)hipStreamDestroy(b->s_scales);
+	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+	if (b->ev_join) (void)hipEventDestroy(b->ev_join);
 	delete b;
 }
 
@@ -309,9 +324,9 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 	if (!b) return fail(SMHV_E_INVALID, "null batch");
 	if (enable && !b->ev) {
 		HIPCHK(hipSetDevice(b->ctx->device));
-		b->ev = new hipEvent_t[smhv_batch::TIMING_RING][6];
+		b->ev = new hipEvent_t[smhv_batch::TIMING_RING][smhv_batch::TIMING_EVENTS];
 		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
-			for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreate(&b->ev[r][i]));
+			for (int i = 0; i < smhv_batch::TIMING_EVENTS; ++i) HIPCHK(hipEventCreate(&b->ev[r][i]));
 	}
 	b->timing = enable != 0;
 	b->timed_runs = 0;
@@ -335,25 +350,46 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	}
 	const bool t = b->timing;
 	hipEvent_t *ev = t ? b->ev[b->timed_runs % smhv_batch::TIMING_RING] : nullptr;
-	if (t) HIPCHK(hipEventRecord(ev[0], s));
+#define STAGE_BEGIN(i, st) do { if (t) HIPCHK(hipEventRecord(ev[2 * (i)], (st))); } while (0)
+#define STAGE_END(i, st) do { if (t) HIPCHK(hipEventRecord(ev[2 * (i) + 1], (st))); } while (0)
+	STAGE_BEGIN(0, s);
 	HIPCHK(launch_button(g, bf, n, 0, s));
-	if (t) HIPCHK(hipEventRecord(ev[1], s));
-	uint32_t mflags = 0;
+	STAGE_END(0, s);
+	uint32_t mflags = 0;                            // ---- markers branch: streaming pass ----
 	if (stages & SMHV_STAGE_MARKERS) mflags |= MAP_MASK;
 	if (stages & SMHV_STAGE_UI_MAP) mflags |= MAP_UI;
+	STAGE_BEGIN(1, s);
 	if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
-	if (t) HIPCHK(hipEventRecord(ev[2], s));
+	STAGE_END(1, s);
 	uint32_t qflags = 0;
 	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
 	if (scales) qflags |= BRQ_SCALES;
-	if (qflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
-	if (t) HIPCHK(hipEventRecord(ev[3], s));
+	hipStream_t sq = b->s_scales;
+	if (qflags) {
+		// ---- scales branch, concurrent with the LSD of the markers branch.  It forks after the map pass: both
+		// are HBM streaming passes and gain nothing from sharing the chip, while the LSD launch (one workgroup
+		// per frame, VALU/LDS-bound) ends with a tail of idle CUs that the quadrant pass fills.
+		HIPCHK(hipEventRecord(b->ev_fork, s));
+		HIPCHK(hipStreamWaitEvent(sq, b->ev_fork, 0));
+		STAGE_BEGIN(2, sq);
+		HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, sq));
+		STAGE_END(2, sq);
+		STAGE_BEGIN(4, sq);
+		if (scales) HIPCHK(launch_scale_ratio(g, bf, n, b->d_bars, sq));
+		STAGE_END(4, sq);
+		HIPCHK(hipEventRecord(b->ev_join, sq));
+	} else {
+		STAGE_BEGIN(2, s); STAGE_END(2, s); STAGE_BEGIN(4, s); STAGE_END(4, s);
+	}
+	STAGE_BEGIN(3, s);
 	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, s));
-	if (t) HIPCHK(hipEventRecord(ev[4], s));
+	STAGE_END(3, s);
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, s));
-	if (scales) HIPCHK(launch_scale_ratio(g, bf, n, b->d_bars, s));
+	if (qflags) HIPCHK(hipStreamWaitEvent(s, b->ev_join, 0));
 	HIPCHK(launch_finalize(g, bf, n, scales ? stages : (stages & ~SMHV_STAGE_SCALES), s));
-	if (t) { HIPCHK(hipEventRecord(ev[5], s)); b->timed_runs++; }
+#undef STAGE_BEGIN
+#undef STAGE_END
+	if (t) b->timed_runs++;
 	return SMHV_OK;
 }
 
@@ -364,8 +400,12 @@ extern "C" SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]) {
 	double acc[5] = {0, 0, 0, 0, 0};
 	for (uint64_t r = 0; r < runs; ++r) {
 		hipEvent_t *ev = b->ev[(b->timed_runs - 1 - r) % smhv_batch::TIMING_RING];
-		HIPCHK(hipEventSynchronize(ev[5]));
-		for (int i = 0; i < 5; ++i) { float m = 0; HIPCHK(hipEventElapsedTime(&m, ev[i], ev[i + 1])); acc[i] += m; }
+		for (int i = 0; i < 5; ++i) {
+			float m = 0;
+			HIPCHK(hipEventSynchronize(ev[2 * i + 1]));
+			HIPCHK(hipEventElapsedTime(&m, ev[2 * i], ev[2 * i + 1]));
+			acc[i] += m;
+		}
 	}
 	for (int i = 0; i < 5; ++i) ms[i] = (float)(acc[i] / (double)runs);
 	b->timed_runs = 0;
