@@ -187,6 +187,41 @@ class VisionResults:
         self.debug_view = None
 
 
+def parse_ocr_labels(ocr_results, max_scales=3):
+    """The label filter of the scales branch (src/vision/mod.rs:150-196).  `ocr_results` is an iterable of OCR
+    hits with fields text, left, right, bottom (dicts or objects; Tesseract itself is outside this path).
+    Returns (scales, scales_start_y): scales = [(meters, x, y)] with x = (left + right) / 2 and y = bottom of the
+    label, at most `max_scales`, duplicates of the same meter value dropped; scales_start_y = min bottom over ALL
+    accepted labels (also the duplicates, as in the reference).  ([], None) reproduces the `return Ok(None)`."""
+    scales, start_y = [], None
+    for hit in ocr_results:
+        get = (lambda k: hit[k]) if isinstance(hit, dict) else (lambda k: getattr(hit, k))
+        text = get("text")
+        if not text.isascii():                       # if !ocr.text.is_ascii() { continue }
+            continue
+        m = text.rfind("m")                          # does the text end with an "m"?
+        if m < 0:
+            continue
+        digits = text[:m]
+        # Rust `str::parse::<u32>`: optional leading '+', then ASCII digits only, no whitespace, must fit u32
+        body = digits[1:] if digits.startswith("+") else digits
+        if not body or not all("0" <= ch <= "9" for ch in body):
+            continue
+        value = int(body)
+        if value == 0 or value > 0xFFFFFFFF:
+            continue
+        bottom = int(get("bottom"))
+        start_y = bottom if start_y is None else min(start_y, bottom)
+        if any(mm == value for (mm, _, _) in scales):
+            continue
+        scales.append((value, (int(get("left")) + int(get("right"))) // 2, bottom))
+        if len(scales) == max_scales:
+            break
+    if not scales or start_y is None:
+        return [], None
+    return scales, start_y
+
+
 class VisionState:
     """Caller contract of src/vision/mod.rs:36-240: load_frame, crop_to_map (None => frame skipped),
     then the markers branch and the scales branch CONCURRENTLY on two threads, each calling
@@ -197,7 +232,10 @@ class VisionState:
         self.detect_markers = detect_markers
         self.max_gap = max_gap
 
-    def process(self, vision, frame, ocr_labels=None, debug_view=DebugView.NONE):
+    def process(self, vision, frame, ocr_labels=None, debug_view=DebugView.NONE, ocr=None):
+        """ocr_labels: [(meters, x, y)] label anchors, or `ocr`: a callable (image uint8[h,w], w, h) -> OCR hits
+        (text/left/right/bottom) that plays the part of the reference's Tesseract call (`ocr::read`, mod.rs:169);
+        its hits go through parse_ocr_labels exactly like the reference filters them."""
         vision.load_frame(frame)
         cropped = vision.crop_to_map(self.grayscale_map)
         if cropped is None:
@@ -221,10 +259,16 @@ class VisionState:
             try:
                 vision.thread_ctx()
                 out["ocr"] = vision.ocr_preprocess()
-                labels = list(ocr_labels or [])[:3]
-                if not labels:
-                    return
-                start_y = min(y for (_, _, y) in labels)
+                if ocr is not None:
+                    h_, w_ = out["ocr"].shape
+                    labels, start_y = parse_ocr_labels(ocr(out["ocr"], w_, h_))
+                    if not labels:
+                        return
+                else:
+                    labels = list(ocr_labels or [])[:3]
+                    if not labels:
+                        return
+                    start_y = min(y for (_, _, y) in labels)
                 vision.find_scales_preprocess(start_y)
                 out["mpx"] = vision.calc_meters_to_px_ratio(labels)
             except Exception as e:  # noqa: BLE001

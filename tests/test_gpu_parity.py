@@ -547,3 +547,25 @@ def test_two_batches_in_flight_on_two_streams_do_not_interfere(vision):
     torch.cuda.synchronize()
     assert bytes(ba.read_results(0, N)) == ref_a and bytes(bb.read_results(0, N)) == ref_b
     ba.close(); bb.close()
+
+
+def test_ocr_callback_hand_off(vision):
+    """The scales branch with a pluggable OCR step: ocr_preprocess output goes to the
+    callback, its hits are filtered like the reference filters Tesseract's, and the labels drive the scale scan."""
+    import squad_mortar_helper_amd as smh
+    frame, e, g = fx.load_fixture("point_intersect_png")
+    seen = {}
+
+    def fake_tesseract(img, w, h):
+        seen["shape"] = (img.shape, w, h)
+        seen["sha"] = sha(img)
+        # boxes read off the screenshot; (left+right)/2 = 594, bottoms 433 / 465 (tests/golden/make_goldens.py)
+        return [dict(text="300m", left=560, right=628, bottom=433), dict(text="Jensen's Training Range", left=300, right=600, bottom=500),
+                dict(text="900m", left=559, right=629, bottom=465)]
+
+    res = smh.VisionState().process(vision, frame, ocr=fake_tesseract)
+    assert seen["shape"] == ((548, 657), 657, 548) and seen["sha"] == e["sha_ocr"]
+    want = o.calc_meters_to_px_ratio([(300, 594, 433), (900, 594, 465)],
+                                     o.find_scales_preprocess(o.crop_to_map(frame)["cropped_brq"], 433))
+    assert res.meters_to_px_ratio == want and 3.7 < want < 4.0
+    assert smh.VisionState().process(vision, frame, ocr=lambda img, w, h: []).meters_to_px_ratio is None
