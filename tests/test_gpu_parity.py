@@ -569,3 +569,28 @@ def test_ocr_callback_hand_off(vision):
                                      o.find_scales_preprocess(o.crop_to_map(frame)["cropped_brq"], 433))
     assert res.meters_to_px_ratio == want and 3.7 < want < 4.0
     assert smh.VisionState().process(vision, frame, ocr=lambda img, w, h: []).meters_to_px_ratio is None
+
+
+def test_stress_large_white_area_all_rays_leave_the_image(vision):
+    """Marker-coloured bands along the top and bottom ROI borders: thousands of rays run to the image border (the
+    reference's end-point quirk gives them length 0 there) and the long-ray queue overflows.  (A fully white ROI
+    is the reference's own O(n^2) worst case -- 210,600 rounds of 3600 full-length rays, minutes even on the
+    GPU -- so it is not part of the suite.)"""
+    W, H = 1024, 768
+    frame, (x, y, rw, rh) = _blank(W, H, 31)
+    frame[y:y + 40, x:x + rw] = GREEN
+    frame[y + 12:y + 28, x + 30:x + rw - 30] = (40, 40, 40, 255)         # hole: not every pixel is a candidate start
+    frame[y + rh - 30:y + rh, x:x + rw] = PURPLE                          # and a solid band along the bottom border
+    _check_markers(vision, frame)
+
+
+def test_stress_checkerboard_of_blobs(vision):
+    """A regular grid of small blobs closer together than max_gap: rays hop from blob to blob (many gap openings
+    and closings per ray), lots of accepted lines up to the cap of 32."""
+    W, H = 1280, 1024
+    frame, (x, y, rw, rh) = _blank(W, H, 32)
+    for by in range(10, rh - 10, 12):
+        for bx in range(10, rw - 10, 12):
+            frame[y + by:y + by + 3, x + bx:x + bx + 3] = PURPLE
+    ref = _check_markers(vision, frame)
+    assert ref["n_lines"] == 32
