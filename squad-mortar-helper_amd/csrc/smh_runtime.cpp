@@ -202,12 +202,16 @@ extern "C" SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out) {
 	smhv_ctx *c = new (std::nothrow) smhv_ctx();
 	if (!c) return fail(SMHV_E_INVALID, "out of host memory");
 	c->device = device; c->log = log;
-	HIPCHK(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&c->s_markers, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&c->s_scales, hipStreamNonBlocking));
-	HIPCHK(hipHostMalloc((void **)&c->h_res, sizeof(smhv_frame_result) * 4));
-	HIPCHK(hipHostMalloc((void **)&c->h_aux, sizeof(FrameAux)));
-	HIPCHK(hipHostMalloc((void **)&c->h_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4));
+	hipError_t he = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
+	if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->s_markers, hipStreamNonBlocking);
+	if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->s_scales, hipStreamNonBlocking);
+	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_res, sizeof(smhv_frame_result) * 4);
+	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_aux, sizeof(FrameAux));
+	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4);
+	if (he != hipSuccess) {
+		smhv_shutdown(c);                                    // releases whatever was created
+		return fail(SMHV_E_HIP, "context setup failed: %s", hipGetErrorString(he));
+	}
 	logf(c, 3, "smh_vision_hip ready on device %d (%s, %d CUs)", device, prop.gcnArchName, prop.multiProcessorCount);
 	*out = c;
 	return SMHV_OK;
