@@ -100,6 +100,9 @@ SMHV_API int smhv_get_lsd_image(smhv_ctx *ctx, uint8_t *out, uint32_t *w, uint32
 SMHV_API int smhv_find_longest_line(smhv_ctx *ctx, float px, float py, float max_gap, smhv_line *line, float *len_sq);
 /* Vision::find_marker_lines (vision-cpu/src/lib.rs:377-385 -> lsd::find_lines::<32>, lsd.rs:60-107) */
 SMHV_API int smhv_find_marker_lines(smhv_ctx *ctx, uint32_t max_gap, smhv_line out[SMHV_MAX_LINES], uint32_t *n);
+/* rounds (find_longest_line invocations) and mask samples of the last smhv_find_marker_lines; exact != 0 repeats the
+ * scan with every ray cast (sample count == the reference's).  Diagnostic. */
+SMHV_API int smhv_lsd_stats(smhv_ctx *ctx, uint32_t max_gap, int exact, uint32_t *rounds, uint64_t *ray_steps);
 /* calc_meters_to_px_ratio (src/vision/mpx_ratio.rs:3-134) on the image of the last
  * find_scales_preprocess.  scales = n x {meters, x, y} (OCR label anchors, BRQ coordinates), n <= 3.
  * *has = 0 reproduces None.  bars (optional) = n x {left, y, right, found} (the scales_debug lines). */
@@ -119,6 +122,10 @@ SMHV_API int smhv_get_debug_view(smhv_ctx *ctx, int which, uint8_t *rgba, uint32
 #define SMHV_STAGE_SCALES 0x8u  /* find_scales_preprocess + calc_meters_to_px_ratio (needs anchors) */
 #define SMHV_STAGE_ALL 0xFu
 #define SMHV_STAGE_MINIMAP 0x10u /* find_minimap (not a Vision trait method; the caller's next step, not in STAGE_ALL) */
+#define SMHV_STAGE_EXACT_STATS 0x20u /* diagnostic: cast every ray of every visited pixel, so that `ray_steps` equals the
+                                        reference's sample count.  Without it the LSD skips angular sectors that provably
+                                        cannot hold an acceptable ray (lines, rounds and every other output are identical;
+                                        ray_steps then counts only the samples actually taken). */
 
 /* One record per frame (what a node-level gather moves between GPUs).  mpx/derived fields follow
  * src/ui/mod.rs:131-140 (length_px, meters in f64) and src/ui/markers.rs:98 (angle = atan2f). */
@@ -131,7 +138,8 @@ typedef struct {
 	uint32_t n_mask_px;             /* 255-pixels in the dilated marker mask                       */
 	uint32_t red_pixels;            /* close-deployment button count                               */
 	uint32_t rounds;                /* find_longest_line invocations (workload statistic)          */
-	uint64_t ray_steps;             /* mask samples taken by all rays (workload statistic)         */
+	uint64_t ray_steps;             /* mask samples taken by the rays that were cast (== the reference's count
+	                                   when SMHV_STAGE_EXACT_STATS is set)                          */
 	double length_px[SMHV_MAX_LINES];
 	double meters[SMHV_MAX_LINES];  /* length_px * mpx (0 when !has_mpx)                           */
 	float angle[SMHV_MAX_LINES];

@@ -15,6 +15,7 @@ MAX_SCALES = 3
 
 STAGE_MARKERS, STAGE_UI_MAP, STAGE_OCR, STAGE_SCALES, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 STAGE_MINIMAP = 0x10
+STAGE_EXACT_STATS = 0x20
 VIEW_NONE, VIEW_OCR_INPUT, VIEW_FIND_SCALES_INPUT, VIEW_LSD_PREPROCESS, VIEW_LSD_INPUT, VIEW_CROPPED_BRQ = range(6)
 IMAGE_UI_MAP = 100
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "smhv_get_lsd_image": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "smhv_find_longest_line": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(Line), C.POINTER(C.c_float)]),
     "smhv_find_marker_lines": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Line), C.POINTER(C.c_uint32)]),
+    "smhv_lsd_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "smhv_calc_meters_to_px_ratio": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "smhv_find_minimap": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "smhv_get_debug_view": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -45,7 +45,14 @@ struct Buffers {
 	FrameAux *aux;
 	smhv_frame_result *results;
 	const smhv_anchors *anchors;   // device copy, may be null
+	const unsigned long long *sector_tab;   // k_lsd sector culling table for this max_gap, or null (cast every ray)
 };
+
+// Sector culling table: (2R+1)^2 entries, entry (oy+R)*(2R+1) + (ox+R) = bit mask of the 64-ray units that can sample
+// the pixel at offset (ox, oy) from floor(start point) at a step in [50 - T, 50].
+#define SMH_SECTOR_R 52
+#define SMH_SECTOR_DIM (2 * SMH_SECTOR_R + 1)
+#define SMH_SECTOR_ENTRIES (SMH_SECTOR_DIM * SMH_SECTOR_DIM)
 
 enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u };
 enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
@@ -61,6 +68,7 @@ hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 // which: SMHV_VIEW_*; isolated: LSDPreprocess shows the marker-isolated crop (after isolate_map_markers)
 hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s);
 hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
+hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
 size_t lsd_lds_bytes();
 
 }  // namespace smh

@@ -487,6 +487,7 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 #define LSD_NW (LSD_BS / 64)
 #define LSD_C 8u                                   // candidates ray-cast per group
 #define LSD_GROUPS ((SMH_LSD_RAYS + 63) / 64)      // 64-ray units per candidate (57)
+#define LSD_GROUPS_HOST 57
 #define LSD_UNITS (LSD_C * LSD_GROUPS)
 #define LSD_LIST_CAP 2048u
 #define LSD_QCAP 2048u
@@ -534,6 +535,15 @@ __device__ __forceinline__ uint32_t win_raw(const Win &m, int xi, int yi) {   //
 	return word >> ((uint32_t)X & 31u);
 }
 __device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) { return win_raw(m, xi, yi) & 1u; }
+
+// The 32 mask bits of word `wq` (in the view's own bit coordinate B = x + xbias) of image row yi; 0 outside the
+// window / image.  Works for all three residency modes (ROWS: xbias = 0).
+__device__ __forceinline__ uint32_t win_word(const Win &m, int wq, int yi) {
+	const uint32_t ry = (uint32_t)(yi - m.y_lo), rc = (uint32_t)wq;
+	uint32_t v = 0;
+	if (ry <= m.rows_hi && rc <= m.cols_hi) v = *(const uint32_t *)((const char *)m.p + __umul24(ry, m.pitch4) + (rc << 2));
+	return v;
+}
 
 // LSD_MODE_ROWS sample straight from the float position (bit 0 = the pixel).
 __device__ __forceinline__ uint32_t win_raw_rows(const Win &m, float x, float y) {
@@ -748,6 +758,7 @@ struct LsdShared {
 	uint32_t cand_key[LSD_C];
 	uint32_t scan[LSD_NW];
 	uint32_t qtail, segnext, unit_next;
+	unsigned long long live[LSD_C];          // units (64-ray sectors) of each candidate that have to be cast
 	float lines[SMH_LSD_MAX_LINES][4];
 };
 
@@ -811,6 +822,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			if (lane == 0) un = atomicAdd(&sh.unit_next, 1u);
 			un = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
 		}
+		if (!((sh.live[c] >> (ucur - c * LSD_GROUPS)) & 1ull)) continue;   // sector culling: this unit cannot hold an acceptable ray
 		const float xs = sh.cand_pt[c][0], ys = sh.cand_pt[c][1];
 		// the batched walker needs a start inside the image (always true for find_lines candidates)
 		const bool fast = fast_gap && in_image(m, xs, ys);
@@ -1037,8 +1049,8 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	};
 
 	if (mode == 1) {   // Vision::find_longest_line on an arbitrary point
-		if (tid < LSD_GROUPS) sh.unit_key[tid] = 0ull;
-		if (tid == 0) { sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
+		if (tid < LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; }
+		if (tid == 0) { sh.live[0] = ~0ull; sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
 		__syncthreads();
 		ray_engine<MODE>(m, sh, queue, 1u, max_gap, true PROF_ARG);
 		if (tid == 0) {
@@ -1049,6 +1061,8 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		return;
 	}
 
+	// sector culling needs the table for this max_gap (absent in exact-statistics mode) and a gap threshold below 50
+	const bool cull = b.sector_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
 	uint32_t rounds = 0, n_lines = 0;
 	unsigned long long steps = 0ull;
 	uint32_t seg_start = 0, cmax = 1u;
@@ -1120,8 +1134,8 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					sh.cand_key[rank] = (tid << 5) | bit;
 					++rank;
 				}
-				if (tid < nc * LSD_GROUPS) sh.unit_key[tid] = 0ull;
-				if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; }
+				if (tid < nc * LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; }
+				if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; sh.live[tid] = cull ? 0ull : ~0ull; }
 				if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; }
 				__syncthreads();
 				if (tid < nc) {
@@ -1135,7 +1149,34 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					sh.cand_pt[tid][0] = ptx; sh.cand_pt[tid][1] = pty;
 				}
 				__syncthreads();
-				PROF_MARK(2);   // chunk filter + candidate selection + centres
+				if (cull) {
+					// ---- sector culling: which 64-ray units can see a white pixel at a distance in [50 - T, 50]? ----
+					// One thread per (row, mask word) of the (2R+1)^2 neighbourhood of each start point; white pixels
+					// look their unit mask up in the table (a few hundred lookups per candidate at most).
+					const uint32_t wpr = (uint32_t)(SMH_SECTOR_DIM + 31) / 32u + 1u;      // words that can overlap a row of the window
+					const uint32_t cells = (uint32_t)SMH_SECTOR_DIM * wpr;
+					for (uint32_t c = 0; c < nc; ++c) {
+						const int fx = (int)floorf(sh.cand_pt[c][0]), fy = (int)floorf(sh.cand_pt[c][1]);
+						unsigned long long acc = 0ull;
+						for (uint32_t t = tid; t < cells; t += LSD_BS) {
+							const int oy = (int)(t / wpr) - SMH_SECTOR_R;
+							const int yi = fy + oy;
+							const int b0 = fx - SMH_SECTOR_R + m.xbias;                       // first bit of the row window, view coordinates
+							const int wq = (b0 >> 5) + (int)(t % wpr);
+							uint32_t word = (yi >= 0 && yi < (int)m.h) ? win_word(m, wq, yi) : 0u;
+							while (word) {
+								const int bit = __builtin_ctz(word);
+								word &= word - 1u;
+								const int ox = (wq << 5) + bit - m.xbias - fx;
+								if (ox >= -SMH_SECTOR_R && ox <= SMH_SECTOR_R) acc |= b.sector_tab[(oy + SMH_SECTOR_R) * SMH_SECTOR_DIM + ox + SMH_SECTOR_R];
+							}
+						}
+						acc = wave_or64(acc);
+						if (lane == 0 && acc) atomicOr(&sh.live[c], acc);
+					}
+					__syncthreads();
+				}
+				PROF_MARK(2);   // chunk filter + candidate selection + centres (+ sector culling)
 				ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);
 #ifdef SMH_LSD_PROFILE
 				prof_last = __builtin_amdgcn_s_memtime();
@@ -1222,6 +1263,49 @@ __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap
 	}
 	if (lsd_mode_for(g, aux) != MODE) return;
 	lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sector culling for find_lines (k_lsd).  lsd.rs:94 keeps a candidate only if its longest ray has
+// len^2 > 2500, i.e. the ray's fatal gap starts at step K >= 51 (an aborted ray ends K-1 unit steps from its
+// start).  Such a ray has a WHITE sample at some step in [50 - T, 50]: T+1 consecutive non-white samples
+// there would have aborted it earlier (T = ceil(max_gap)); the same holds for a ray that leaves the image
+// after more than 50 steps.  So for a candidate only the angular sectors that can see a white pixel at a
+// distance in that range have to be ray-cast at all: the longest ray, if it is acceptable, lies in one of
+// them, and if none is acceptable the candidate is rejected whatever the other rays do.
+// The table maps a pixel offset (relative to floor(start point)) to the 64-ray units (6.4 degree sectors)
+// that could sample it at such a step, conservatively: the sample may sit anywhere in the pixel (0.71 px),
+// the start point anywhere in its pixel (0.71 px), plus 0.05 px for accumulated f32 rounding.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_build_sector_table(unsigned long long *tab, uint32_t T) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= SMH_SECTOR_ENTRIES) return;
+	const int oy = (int)(i / SMH_SECTOR_DIM) - SMH_SECTOR_R, ox = (int)(i % SMH_SECTOR_DIM) - SMH_SECTOR_R;
+	const double rho = 0.7072 + 0.7072 + 0.05;
+	const double kmin = T >= 50u ? 0.0 : (double)(50u - T), kmax = 50.0;
+	const double r0 = sqrt((double)(ox * ox + oy * oy));
+	unsigned long long m = 0ull;
+	if (r0 >= kmin - rho && r0 <= kmax + rho) {
+		if (r0 <= rho) {
+			m = ~0ull;                                    // the start pixel's neighbourhood: every direction
+		} else {
+			const double PI = 3.14159265358979323846;
+			double phi = atan2((double)oy, (double)ox) * 180.0 / PI;   // ray i points at (cos, sin)(i/10 degrees), y down
+			if (phi < 0.0) phi += 360.0;
+			const double delta = asin(rho / r0 > 1.0 ? 1.0 : rho / r0) * 180.0 / PI + 0.2;   // + two ray steps
+			for (int u = 0; u < LSD_GROUPS_HOST; ++u) {
+				const double a0 = 6.4 * u, a1 = 6.4 * u + 6.3;   // rays 64u .. 64u+63
+				// intersects [phi - delta, phi + delta] modulo 360?
+				bool hit = false;
+				for (int wrap = -1; wrap <= 1 && !hit; ++wrap) {
+					const double lo = phi - delta + 360.0 * wrap, hi = phi + delta + 360.0 * wrap;
+					hit = !(hi < a0 || lo > a1);
+				}
+				if (hit) m |= 1ull << u;
+			}
+		}
+	}
+	tab[i] = m;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1524,6 +1608,12 @@ hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, in
 	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
 	const uint32_t npx = brq ? g.qw * g.qh : g.rw * g.rh;
 	hipLaunchKernelGGL(k_debug_view, dim3((npx + 255) / 256), dim3(256), 0, s, g, b, frame, which, isolated, d_rgba);
+	return hipGetLastError();
+}
+
+hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s) {
+	static_assert(LSD_GROUPS == LSD_GROUPS_HOST && LSD_GROUPS <= 64, "sector masks are 64-bit");
+	hipLaunchKernelGGL(k_build_sector_table, dim3((SMH_SECTOR_ENTRIES + 255) / 256), dim3(256), 0, s, d_tab, T);
 	return hipGetLastError();
 }
 

@@ -161,6 +161,11 @@ struct smhv_ctx {
 	uint32_t *h_bars = nullptr;
 	// per-frame state
 	bool cropped = false, map_open = false, isolated = false, mask_valid = false, scales_valid = false;
+	// sector culling tables of k_lsd, one per gap threshold T = ceil(max_gap) seen so far (built on first use)
+	static constexpr int SECTOR_CACHE = 8;
+	uint32_t sector_T[SECTOR_CACHE] = {};
+	unsigned long long *sector_tab[SECTOR_CACHE] = {};
+	int sector_n = 0;
 	std::mutex mu;                      // serialises (re)allocation only
 };
 
@@ -174,8 +179,27 @@ static void logf(smhv_ctx *c, int lvl, const char *fmt, ...) {
 	c->log(lvl, buf);
 }
 
+// Device table for max_gap (nullptr => k_lsd casts every ray).  Built once per distinct threshold.
+static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, const unsigned long long **out) {
+	*out = nullptr;
+	if (max_gap == 0 || max_gap > 49) return SMHV_OK;        // nothing to cull
+	std::lock_guard<std::mutex> lk(c->mu);
+	for (int i = 0; i < c->sector_n; ++i)
+		if (c->sector_T[i] == max_gap) { *out = c->sector_tab[i]; return SMHV_OK; }
+	if (c->sector_n == smhv_ctx::SECTOR_CACHE) return SMHV_OK;   // cache full: fall back to casting every ray
+	unsigned long long *d = nullptr;
+	HIPCHK(hipMalloc((void **)&d, sizeof(unsigned long long) * SMH_SECTOR_ENTRIES));
+	hipError_t e = launch_build_sector_table(d, max_gap, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	if (e != hipSuccess) { (void)hipFree(d); return fail(SMHV_E_HIP, "sector table: %s", hipGetErrorString(e)); }
+	c->sector_T[c->sector_n] = max_gap; c->sector_tab[c->sector_n] = d; c->sector_n++;
+	*out = d;
+	return SMHV_OK;
+}
+
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
+	bf.sector_tab = nullptr;
 	bf.frames = frames;
 	bf.ui = b->d_ui; bf.mask = b->d_mask; bf.ocr = b->d_ocr; bf.scales = b->d_scales;
 	bf.bits = b->d_bits; bf.aux = b->d_aux;
@@ -222,6 +246,7 @@ extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
 	(void)hipSetDevice(c->device);
 	(void)hipDeviceSynchronize();
 	if (c->fb) { smhv_batch_destroy(c->fb); c->fb = nullptr; }
+	for (int i = 0; i < c->sector_n; ++i) (void)hipFree(c->sector_tab[i]);
 	if (c->d_frame) (void)hipFree(c->d_frame);
 	if (c->h_ocr) (void)hipHostFree(c->h_ocr);
 	if (c->h_scales) (void)hipHostFree(c->h_scales);
@@ -341,9 +366,14 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
                                        const smhv_anchors *anchors, void *stream) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
 	if ((stages & (SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP)) == 0) return fail(SMHV_E_INVALID, "no stage selected");
+	stages &= SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP | SMHV_STAGE_EXACT_STATS;
 	hipStream_t s = (hipStream_t)stream;
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
+	if ((stages & SMHV_STAGE_MARKERS) && !(stages & SMHV_STAGE_EXACT_STATS)) {
+		int rc = sector_table_for(b->ctx, max_gap, s, &bf.sector_tab);
+		if (rc) return rc;
+	}
 	const bool scales = (stages & SMHV_STAGE_SCALES) && anchors;
 	if (scales) {
 		const uint32_t slot = b->anchors_slot++ & 1u;
@@ -667,12 +697,34 @@ extern "C" SMHV_API int smhv_find_marker_lines(smhv_ctx *c, uint32_t max_gap, sm
 	smhv_batch *b = c->fb;
 	Buffers bf = make_buffers(b, c->frame_ptr, 0);
 	hipStream_t s = c->s_markers;
+	rc = sector_table_for(c, max_gap, s, &bf.sector_tab);
+	if (rc) return rc;
 	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s));
 	HIPCHK(launch_finalize(b->g, bf, 1, SMHV_STAGE_MARKERS, s));
 	HIPCHK(hipMemcpyAsync(&c->h_res[0], b->d_results, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
 	*n = c->h_res[0].n_lines;
 	memcpy(out, c->h_res[0].lines, sizeof(smhv_line) * SMHV_MAX_LINES);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_lsd_stats(smhv_ctx *c, uint32_t max_gap, int exact, uint32_t *rounds, uint64_t *ray_steps) {
+	int rc = require_mask(c, "lsd_stats");
+	if (rc) return rc;
+	if (!rounds || !ray_steps) return fail(SMHV_E_INVALID, "null output");
+	HIPCHK(hipSetDevice(c->device));
+	smhv_batch *b = c->fb;
+	Buffers bf = make_buffers(b, c->frame_ptr, 2);          // scratch record: does not disturb find_marker_lines' result
+	hipStream_t s = c->s_markers;
+	if (!exact) {
+		rc = sector_table_for(c, max_gap, s, &bf.sector_tab);
+		if (rc) return rc;
+	}
+	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s));
+	HIPCHK(hipMemcpyAsync(&c->h_res[2], b->d_results + 2, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	*rounds = c->h_res[2].rounds;
+	*ray_steps = c->h_res[2].ray_steps;
 	return SMHV_OK;
 }
 

@@ -160,6 +160,12 @@ class HipVision:
         L.check(self._lib.smhv_find_marker_lines(self._ctx, max_gap, lines, C.byref(n)))
         return np.array([[l.x0, l.y0, l.x1, l.y1] for l in lines[:n.value]], np.float32).reshape(-1, 4)
 
+    def lsd_stats(self, max_gap=15, exact=False):
+        """(rounds, ray_steps) of the line scan; exact=True casts every ray (sample count == the reference's)."""
+        r, st = C.c_uint32(), C.c_uint64()
+        L.check(self._lib.smhv_lsd_stats(self._ctx, max_gap, int(bool(exact)), C.byref(r), C.byref(st)))
+        return r.value, st.value
+
     def get_debug_view(self, choice):
         if choice == DebugView.NONE:
             return None

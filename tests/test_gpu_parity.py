@@ -52,6 +52,8 @@ def test_samples_match_goldens_and_oracle(vision, stem):
     assert np.array_equal(np.flatnonzero(lsd.reshape(-1) == 255).astype(np.uint32), g["mask_idx"])   # marker pixel coords
     assert set(np.unique(lsd)) <= {0, 255} and sha(lsd) == e["sha_lsd"]
     assert res.markers.shape == g["lines"].shape and np.array_equal(res.markers, g["lines"])
+    assert vision.lsd_stats(15, exact=True) == (e["rounds"], e["steps"])      # identical ray trajectories
+    assert vision.lsd_stats(15, exact=False)[0] == e["rounds"]                  # sector culling keeps the visit order
     assert sha(res.map) == e["sha_ui_gray"]
     assert sha(vision.ocr_preprocess()) == e["sha_ocr"]
     assert sha(vision.find_scales_preprocess(0)) == e["sha_scales0"]
@@ -247,9 +249,15 @@ def test_batch_matches_oracle_including_derived_outputs(vision):
     per[6] = (per[6][0], per[6][1] + [(50, 20, 20)])               # a third, bogus label
     d = torch.from_numpy(frames).cuda()
     fb = smh.FrameBatch(vision, W, H, N)
+    # default (sector-culled) run first: every output but the sample count must already be the reference's
     fb.run(d.data_ptr(), N, anchors=smh.make_anchors(per), stream=torch.cuda.current_stream().cuda_stream)
+    fast = smh.results_to_dicts(fb.read_results(0, N))
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_EXACT_STATS, anchors=smh.make_anchors(per), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     recs = smh.results_to_dicts(fb.read_results(0, N))
+    for a, b_ in zip(fast, recs):
+        assert np.array_equal(a["lines"], b_["lines"]) and a["rounds"] == b_["rounds"] and a["mpx"] == b_["mpx"]
+        assert a["ray_steps"] <= b_["ray_steps"] and np.array_equal(a["length_px"], b_["length_px"])
     for i in range(N):
         start_y, anc = per[i]
         ref = o.process_frame(frames[i], stages=0xF if anc else 0x7, anchors=anc, scales_start_y=start_y, want_images=True)
@@ -295,7 +303,12 @@ def test_full_size_batch_properties(vision):
     fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
     b = bytes(fb.read_results(0, N))
     assert a == b
+    fast = smh.results_to_dicts(fb.read_results(0, N))
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_EXACT_STATS, anchors=anchors, stream=s)
     recs = smh.results_to_dicts(fb.read_results(0, N))
+    for x_, y_ in zip(fast, recs):                                # sector culling changes nothing but the sample count
+        assert np.array_equal(x_["lines"], y_["lines"]) and x_["rounds"] == y_["rounds"] and x_["ray_steps"] <= y_["ray_steps"]
+    assert sum(r["ray_steps"] for r in fast) < 0.6 * sum(r["ray_steps"] for r in recs)
     assert all(r["map_open"] == 1 and r["mpx"] == recs[0]["mpx"] for r in recs)
     for i in (0, 17, 101, 255):
         ref = o.process_frame(host.numpy()[i], stages=0xF, anchors=infos[i]["anchors"], scales_start_y=infos[i]["scales_start_y"], want_images=True)
@@ -330,7 +343,11 @@ def test_1440p_batch_window_and_global_mask_paths(vision):
     fb = smh.FrameBatch(vision, W, H, N)
     per = [(i["scales_start_y"], i["anchors"]) for i in infos]
     fb.run(d.data_ptr(), N, anchors=smh.make_anchors(per), stream=torch.cuda.current_stream().cuda_stream)
+    fast = smh.results_to_dicts(fb.read_results(0, N))
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_EXACT_STATS, anchors=smh.make_anchors(per), stream=torch.cuda.current_stream().cuda_stream)
     recs = smh.results_to_dicts(fb.read_results(0, N))
+    for x_, y_ in zip(fast, recs):
+        assert np.array_equal(x_["lines"], y_["lines"]) and x_["rounds"] == y_["rounds"]
     for i in range(N):
         ref = o.process_frame(frames[i], stages=0xF, anchors=per[i][1], scales_start_y=per[i][0], want_images=True)
         assert np.array_equal(recs[i]["lines"], ref["lines"]) and recs[i]["mpx"] == ref["mpx"]
@@ -366,6 +383,9 @@ def _check_markers(vision, frame, max_gap=15):
     lsd = vision.lsd_image()
     assert np.array_equal(lsd, ref["lsd"])
     assert res.markers.shape == ref["lines"].shape and np.array_equal(res.markers, ref["lines"]), (res.markers, ref["lines"])
+    r_fast, s_fast = vision.lsd_stats(max_gap, exact=False)
+    r_exact, s_exact = vision.lsd_stats(max_gap, exact=True)
+    assert r_fast == r_exact == ref["rounds"] and s_exact == ref["steps"] and s_fast <= s_exact
     return ref
 
 
