@@ -45,14 +45,19 @@ struct Buffers {
 	FrameAux *aux;
 	smhv_frame_result *results;
 	const smhv_anchors *anchors;   // device copy, may be null
-	const unsigned long long *sector_tab;   // k_lsd sector culling table for this max_gap, or null (cast every ray)
+	// k_lsd sector culling table for this max_gap (null: cast every ray): SMH_CULL_CELLS cells of 3 words, cell = (row oy + R) * 4
+	// + word j covering offsets ox = -R + 32 j + [0, 32): [mask of the annulus pixels][unit ranges of bytes 0,1][of bytes 2,3],
+	// a range being first_unit | n_units << 6 (16 bits)
+	const uint32_t *cull_tab;
 };
 
-// Sector culling table: (2R+1)^2 entries, entry (oy+R)*(2R+1) + (ox+R) = bit mask of the 64-ray units that can sample
-// the pixel at offset (ox, oy) from floor(start point) at a step in [50 - T, 50].
+// Sector culling table as k_build_sector_table writes it: (2R+1)^2 entries, entry (oy+R)*(2R+1) + (ox+R) = bit mask of the
+// 64-ray units that can sample the pixel at offset (ox, oy) from floor(start point) at a step in [50 - T, 50].  The host
+// condenses it into the per-word cells of Buffers::cull_tab.
 #define SMH_SECTOR_R 52
 #define SMH_SECTOR_DIM (2 * SMH_SECTOR_R + 1)
 #define SMH_SECTOR_ENTRIES (SMH_SECTOR_DIM * SMH_SECTOR_DIM)
+#define SMH_CULL_CELLS (SMH_SECTOR_DIM * 4)
 
 enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u };
 enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };

@@ -735,9 +735,9 @@ __device__ __forceinline__ bool near_line(float x, float y, float x0, float y0, 
 // Diagnostic build only (-DSMH_LSD_PROFILE): thread 0 accumulates s_memtime deltas per phase and stores
 // them in the tail of the record's `meters` array (never read by product code in that build).
 #ifdef SMH_LSD_PROFILE
-#define PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = __builtin_amdgcn_s_memtime();
+#define PROF_DECL unsigned long long prof_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_last = __builtin_amdgcn_s_memtime();
 #define PROF_MARK(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[i] += _n - prof_last; prof_last = _n; } while (0)
-#define PROF_STORE(res) do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) ((unsigned long long *)(res)->meters)[24 + _i] = prof_t[_i]; } while (0)
+#define PROF_STORE(res) do { if (threadIdx.x == 0) for (int _i = 0; _i < 12; ++_i) ((unsigned long long *)(res)->meters)[20 + _i] = prof_t[_i]; } while (0)
 #define PROF_ARG , prof_t
 #else
 #define PROF_DECL
@@ -772,6 +772,14 @@ __device__ __forceinline__ uint32_t wave_max32_dpp(uint32_t v) {
 	v = max(v, SMH_DPP(v, 0x140));   // row_mirror
 	return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
 	           max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_or32_dpp(uint32_t v) {
+	v |= SMH_DPP(v, 0xB1);
+	v |= SMH_DPP(v, 0x4E);
+	v |= SMH_DPP(v, 0x141);
+	v |= SMH_DPP(v, 0x140);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+	       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 __device__ __forceinline__ uint32_t wave_sum32_dpp(uint32_t v) {
 	v += SMH_DPP(v, 0xB1);
@@ -979,7 +987,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 
 template <int MODE>
 __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max_gap, int mode, float spx, float spy, const FrameAux &aux,
-                          uint32_t *smem, LsdShared &sh) {
+                          uint32_t *smem, LsdShared &sh, uint32_t *cull_tab) {
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	smhv_frame_result *res = &b.results[f];
 	const uint32_t *gbits = b.bits + (size_t)f * g.bits_stride_w;
@@ -1062,12 +1070,13 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	}
 
 	// sector culling needs the table for this max_gap (absent in exact-statistics mode) and a gap threshold below 50
-	const bool cull = b.sector_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
+	const bool cull = b.cull_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
+	if (cull) for (uint32_t i = tid; i < 3u * SMH_CULL_CELLS; i += LSD_BS) cull_tab[i] = b.cull_tab[i];   // visible after the first barrier below
 	uint32_t rounds = 0, n_lines = 0;
 	unsigned long long steps = 0ull;
 	uint32_t seg_start = 0, cmax = 1u;
 	bool done = false;
-	PROF_MARK(0);   // window load
+	PROF_MARK(8);   // window load
 	while (!done) {
 		// ---- ordered compaction of the non-zero mask words in [seg_start, WT) into `list` ----
 		const uint32_t range = WT - seg_start;
@@ -1093,7 +1102,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		__syncthreads();
 		const uint32_t Tn = min(total, LSD_LIST_CAP);
 		const uint32_t segnext = sh.segnext;
-		PROF_MARK(1);   // compaction
+		PROF_MARK(9);   // compaction
 
 		for (uint32_t cbase = 0; cbase < Tn && !done; cbase += LSD_BS) {
 			const uint32_t e = cbase + tid;
@@ -1138,45 +1147,59 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; sh.live[tid] = cull ? 0ull : ~0ull; }
 				if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; }
 				__syncthreads();
-				if (tid < nc) {
-					const uint32_t key = sh.cand_key[tid];
+				if (tid < nc * 32u) {
+					// get_centre (lsd.rs:5-44) of the nc integer pixel positions, 32 lanes per candidate: lane (dir, k)
+					// evaluates the k-th loop condition of direction dir (left, right, up, down); the walk length is the
+					// number of leading true conditions (k = 5 always fails: |offset| < 5.0).  px - k is exact in f32.
+					const uint32_t c = tid >> 5, l = tid & 31u, dir = l >> 3, k = l & 7u;
+					const uint32_t key = sh.cand_key[c];
 					const uint32_t cwi = list[cbase + (key >> 5)];
 					const uint32_t cr = cwi / wwords, cc = cwi - cr * wwords;
 					const float cy = (float)(wy0 + cr);
 					const float cx = (float)(xorg + (int)(cc * 32u + (key & 31u)));
-					float ptx, pty;
-					get_centre(m, cx, cy, ptx, pty);
-					sh.cand_pt[tid][0] = ptx; sh.cand_pt[tid][1] = pty;
+					const float fk = (float)k;
+					bool cond = k < 5u;
+					if (dir == 0u) cond = cond && (cx - fk > 0.0f) && white_at(m, cx - fk, cy);
+					else if (dir == 1u) cond = cond && (cx + fk < (float)(m.w - 1u)) && white_at(m, cx + fk, cy);
+					else if (dir == 2u) cond = cond && (cy - fk > 0.0f) && white_at(m, cx, cy - fk);
+					else cond = cond && (cy + fk < (float)(m.h - 1u)) && white_at(m, cx, cy + fk);
+					const uint32_t bits = (uint32_t)(__ballot(cond) >> (tid & 32u));
+					if (l == 0u) {
+						const float nl = (float)__builtin_ctz(~(bits & 0xFFu)), nr = (float)__builtin_ctz(~((bits >> 8) & 0xFFu));
+						const float nu = (float)__builtin_ctz(~((bits >> 16) & 0xFFu)), nd = (float)__builtin_ctz(~((bits >> 24) & 0xFFu));
+						sh.cand_pt[c][0] = ((cx - nl) + (cx + nr)) / 2.0f;
+						sh.cand_pt[c][1] = ((cy - nu) + (cy + nd)) / 2.0f;
+					}
 				}
 				__syncthreads();
+				PROF_MARK(10);  // chunk filter + candidate selection + centres
 				if (cull) {
 					// ---- sector culling: which 64-ray units can see a white pixel at a distance in [50 - T, 50]? ----
-					// One thread per (row, mask word) of the (2R+1)^2 neighbourhood of each start point; white pixels
-					// look their unit mask up in the table (a few hundred lookups per candidate at most).
-					const uint32_t wpr = (uint32_t)(SMH_SECTOR_DIM + 31) / 32u + 1u;      // words that can overlap a row of the window
-					const uint32_t cells = (uint32_t)SMH_SECTOR_DIM * wpr;
-					for (uint32_t c = 0; c < nc; ++c) {
+					// One thread per (candidate, row, 32-pixel word) cell of the (2R+1)-row neighbourhood: the mask word,
+					// funnel-shifted so that bit 0 is offset -R from floor(start point), is ANDed with the annulus mask of
+					// the cell; each of its four bytes that holds a white annulus pixel contributes its unit range.
+					for (uint32_t id = tid; id < nc * SMH_CULL_CELLS; id += LSD_BS) {
+						const uint32_t c = id / SMH_CULL_CELLS, cell = id - c * SMH_CULL_CELLS;
 						const int fx = (int)floorf(sh.cand_pt[c][0]), fy = (int)floorf(sh.cand_pt[c][1]);
-						unsigned long long acc = 0ull;
-						for (uint32_t t = tid; t < cells; t += LSD_BS) {
-							const int oy = (int)(t / wpr) - SMH_SECTOR_R;
-							const int yi = fy + oy;
-							const int b0 = fx - SMH_SECTOR_R + m.xbias;                       // first bit of the row window, view coordinates
-							const int wq = (b0 >> 5) + (int)(t % wpr);
-							uint32_t word = (yi >= 0 && yi < (int)m.h) ? win_word(m, wq, yi) : 0u;
-							while (word) {
-								const int bit = __builtin_ctz(word);
-								word &= word - 1u;
-								const int ox = (wq << 5) + bit - m.xbias - fx;
-								if (ox >= -SMH_SECTOR_R && ox <= SMH_SECTOR_R) acc |= b.sector_tab[(oy + SMH_SECTOR_R) * SMH_SECTOR_DIM + ox + SMH_SECTOR_R];
+						const int yi = fy + (int)(cell >> 2) - SMH_SECTOR_R;
+						if ((uint32_t)yi >= m.h) continue;
+						const int b0 = fx - SMH_SECTOR_R + (int)((cell & 3u) << 5) + m.xbias;   // view bit coordinate of the cell's bit 0
+						const uint32_t lo = win_word(m, b0 >> 5, yi), hi = win_word(m, (b0 >> 5) + 1, yi);
+						const uint32_t hit = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)b0 & 31u) & cull_tab[3u * cell];
+						if (hit) {
+							const uint32_t r01 = cull_tab[3u * cell + 1u], r23 = cull_tab[3u * cell + 2u];
+							unsigned long long acc = 0ull;
+#pragma unroll
+							for (uint32_t q = 0; q < 4u; ++q) {
+								const uint32_t rg = ((q < 2u ? r01 : r23) >> ((q & 1u) * 16u)) & 0xFFFFu;   // first | n_units << 6
+								if ((hit >> (8u * q)) & 0xFFu) acc |= ((1ull << (rg >> 6)) - 1ull) << (rg & 63u);   // first + n <= 64 (host)
 							}
+							atomicOr(&sh.live[c], (acc | (acc >> LSD_GROUPS)) & ((1ull << LSD_GROUPS) - 1ull));   // units wrap at 57
 						}
-						acc = wave_or64(acc);
-						if (lane == 0 && acc) atomicOr(&sh.live[c], acc);
 					}
 					__syncthreads();
 				}
-				PROF_MARK(2);   // chunk filter + candidate selection + centres (+ sector culling)
+				PROF_MARK(11);  // sector culling scan
 				ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);
 #ifdef SMH_LSD_PROFILE
 				prof_last = __builtin_amdgcn_s_memtime();
@@ -1255,6 +1278,7 @@ template <int MODE>
 __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ LsdShared sh;
+	__shared__ uint32_t cull_tab[3 * SMH_CULL_CELLS];
 	const uint32_t f = blockIdx.x;
 	const FrameAux aux = b.aux[f];
 	if (mode == 0) {
@@ -1262,7 +1286,7 @@ __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap
 		if (!aux.open || aux.n_mask_px == 0) return;
 	}
 	if (lsd_mode_for(g, aux) != MODE) return;
-	lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh);
+	lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh, cull_tab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1495,7 +1519,7 @@ __global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t sta
 		res->lines[l] = ln;
 		res->length_px[l] = len; res->angle[l] = ang;
 #ifdef SMH_LSD_PROFILE
-		if (l < 24)
+		if (l < 20)
 #endif
 		res->meters[l] = met;
 	}

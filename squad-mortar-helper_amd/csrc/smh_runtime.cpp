@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -164,7 +165,7 @@ struct smhv_ctx {
 	// sector culling tables of k_lsd, one per gap threshold T = ceil(max_gap) seen so far (built on first use)
 	static constexpr int SECTOR_CACHE = 8;
 	uint32_t sector_T[SECTOR_CACHE] = {};
-	unsigned long long *sector_tab[SECTOR_CACHE] = {};
+	uint32_t *sector_tab[SECTOR_CACHE] = {};
 	int sector_n = 0;
 	std::mutex mu;                      // serialises (re)allocation only
 };
@@ -179,27 +180,68 @@ static void logf(smhv_ctx *c, int lvl, const char *fmt, ...) {
 	c->log(lvl, buf);
 }
 
-// Device table for max_gap (nullptr => k_lsd casts every ray).  Built once per distinct threshold.
-static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, const unsigned long long **out) {
-	*out = nullptr;
+// Smallest cyclic run of 64-ray units covering mask m (a superset only casts more rays), as first | n << 6; 0 = none.
+static uint32_t unit_range(unsigned long long m) {
+	const uint32_t NU = 57;                                   // units per candidate
+	m &= (1ull << NU) - 1ull;
+	if (!m) return 0;
+	uint32_t first = 0, cnt = NU, best_gap = 0;               // complement of the longest cyclic zero gap
+	for (uint32_t st = 0; st < NU; ++st) {
+		if (!((m >> st) & 1ull)) continue;
+		uint32_t gap = 0;
+		while (gap < NU - 1 && !((m >> ((st + 1 + gap) % NU)) & 1ull)) ++gap;
+		if (gap > best_gap) { best_gap = gap; first = (st + 1 + gap) % NU; cnt = NU - gap; }
+	}
+	if (best_gap == 0 || first + cnt > 64) { first = 0; cnt = NU; }   // keep (2^n - 1) << first inside 64 bits
+	return first | (cnt << 6);
+}
+
+// Device table for max_gap (nullptr => k_lsd casts every ray).  Built once per distinct threshold: the kernel
+// fills the dense (2R+1)^2 table, the host condenses it into per-word cells (smh_kernels.h, Buffers::cull_tab).
+static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffers *bf) {
+	bf->cull_tab = nullptr;
 	if (max_gap == 0 || max_gap > 49) return SMHV_OK;        // nothing to cull
 	std::lock_guard<std::mutex> lk(c->mu);
 	for (int i = 0; i < c->sector_n; ++i)
-		if (c->sector_T[i] == max_gap) { *out = c->sector_tab[i]; return SMHV_OK; }
+		if (c->sector_T[i] == max_gap) { bf->cull_tab = c->sector_tab[i]; return SMHV_OK; }
 	if (c->sector_n == smhv_ctx::SECTOR_CACHE) return SMHV_OK;   // cache full: fall back to casting every ray
-	unsigned long long *d = nullptr;
-	HIPCHK(hipMalloc((void **)&d, sizeof(unsigned long long) * SMH_SECTOR_ENTRIES));
-	hipError_t e = launch_build_sector_table(d, max_gap, s);
+	unsigned long long *d_dense = nullptr;
+	HIPCHK(hipMalloc((void **)&d_dense, sizeof(unsigned long long) * SMH_SECTOR_ENTRIES));
+	std::vector<unsigned long long> dense(SMH_SECTOR_ENTRIES);
+	hipError_t e = launch_build_sector_table(d_dense, max_gap, s);
+	if (e == hipSuccess) e = hipMemcpyAsync(dense.data(), d_dense, sizeof(unsigned long long) * SMH_SECTOR_ENTRIES, hipMemcpyDeviceToHost, s);
 	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	(void)hipFree(d_dense);
+	if (e != hipSuccess) return fail(SMHV_E_HIP, "sector table: %s", hipGetErrorString(e));
+	std::vector<uint32_t> cells(3 * SMH_CULL_CELLS, 0u);
+	for (uint32_t row = 0; row < SMH_SECTOR_DIM; ++row)
+		for (uint32_t j = 0; j < 4; ++j) {
+			uint32_t amask = 0, rng[4] = {0, 0, 0, 0};
+			for (uint32_t q = 0; q < 4; ++q) {
+				unsigned long long um = 0;
+				for (uint32_t bit = 8 * q; bit < 8 * q + 8; ++bit) {
+					const uint32_t col = 32 * j + bit;                 // ox + R
+					if (col >= SMH_SECTOR_DIM) continue;
+					const unsigned long long m = dense[row * SMH_SECTOR_DIM + col];
+					if (m) { amask |= 1u << bit; um |= m; }
+				}
+				rng[q] = unit_range(um);
+			}
+			uint32_t *cell = &cells[3 * (row * 4 + j)];
+			cell[0] = amask; cell[1] = rng[0] | (rng[1] << 16); cell[2] = rng[2] | (rng[3] << 16);
+		}
+	uint32_t *d = nullptr;
+	HIPCHK(hipMalloc((void **)&d, sizeof(uint32_t) * cells.size()));
+	e = hipMemcpy(d, cells.data(), sizeof(uint32_t) * cells.size(), hipMemcpyHostToDevice);
 	if (e != hipSuccess) { (void)hipFree(d); return fail(SMHV_E_HIP, "sector table: %s", hipGetErrorString(e)); }
 	c->sector_T[c->sector_n] = max_gap; c->sector_tab[c->sector_n] = d; c->sector_n++;
-	*out = d;
+	bf->cull_tab = d;
 	return SMHV_OK;
 }
 
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
-	bf.sector_tab = nullptr;
+	bf.cull_tab = nullptr;
 	bf.frames = frames;
 	bf.ui = b->d_ui; bf.mask = b->d_mask; bf.ocr = b->d_ocr; bf.scales = b->d_scales;
 	bf.bits = b->d_bits; bf.aux = b->d_aux;
@@ -371,7 +413,7 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
 	if ((stages & SMHV_STAGE_MARKERS) && !(stages & SMHV_STAGE_EXACT_STATS)) {
-		int rc = sector_table_for(b->ctx, max_gap, s, &bf.sector_tab);
+		int rc = sector_table_for(b->ctx, max_gap, s, &bf);
 		if (rc) return rc;
 	}
 	const bool scales = (stages & SMHV_STAGE_SCALES) && anchors;
@@ -697,7 +739,7 @@ extern "C" SMHV_API int smhv_find_marker_lines(smhv_ctx *c, uint32_t max_gap, sm
 	smhv_batch *b = c->fb;
 	Buffers bf = make_buffers(b, c->frame_ptr, 0);
 	hipStream_t s = c->s_markers;
-	rc = sector_table_for(c, max_gap, s, &bf.sector_tab);
+	rc = sector_table_for(c, max_gap, s, &bf);
 	if (rc) return rc;
 	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s));
 	HIPCHK(launch_finalize(b->g, bf, 1, SMHV_STAGE_MARKERS, s));
@@ -717,7 +759,7 @@ extern "C" SMHV_API int smhv_lsd_stats(smhv_ctx *c, uint32_t max_gap, int exact,
 	Buffers bf = make_buffers(b, c->frame_ptr, 2);          // scratch record: does not disturb find_marker_lines' result
 	hipStream_t s = c->s_markers;
 	if (!exact) {
-		rc = sector_table_for(c, max_gap, s, &bf.sector_tab);
+		rc = sector_table_for(c, max_gap, s, &bf);
 		if (rc) return rc;
 	}
 	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s));

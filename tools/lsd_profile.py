@@ -19,18 +19,23 @@ for _ in range(3):
 torch.cuda.synchronize()
 print("stage ms", fb.stage_ms())
 recs = fb.read_results(0, N)
-names = ["pass1:batches", "pass1:unit-overhead", "pass2(+sync)", "pass1-end-sync-wait", "phaseB", "select+resolve", "queued_rays", "groups"]
-tot = np.zeros(8)
+names = ["pass1:batches", "pass1:unit-overhead", "pass2(+sync)", "pass1-end-sync-wait", "phaseB", "resolve", "queued_rays", "groups", "window-load", "compaction", "select+centres", "cull-scan"]
+TIMED = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11]
+tot = np.zeros(12)
 rows = []
 for r in recs:
     raw = np.frombuffer(bytes(r), np.uint8)
-    off = smh._lib.FrameResult.meters.offset + 24 * 8
-    p = np.frombuffer(raw[off:off + 64].tobytes(), np.uint64).astype(np.float64)
+    off = smh._lib.FrameResult.meters.offset + 20 * 8
+    p = np.frombuffer(raw[off:off + 96].tobytes(), np.uint64).astype(np.float64)
     rows.append((r.rounds, p))
     tot += p
-cyc = tot[:6].sum()
-print("sum over frames: " + ", ".join("%s %.1f%%" % (n, 100 * t / cyc) for n, t in zip(names[:6], tot[:6])))
+cyc = tot[TIMED].sum()
+print("sum over frames: " + ", ".join("%s %.1f%%" % (n, 100 * t / cyc) for n, t in ((names[i], tot[i]) for i in TIMED)))
 print("queued rays per group: %.1f, groups per frame %.1f" % (tot[6] / max(tot[7], 1), tot[7] / N))
-rows.sort(key=lambda x: -x[1][:6].sum())
+rows.sort(key=lambda x: -x[1][TIMED].sum())
 for rounds, p in rows[:5]:
-    print("rounds %d total Mcycles(100MHz ticks?) %.2f " % (rounds, p[:6].sum() / 1e6), ["%.2f" % (x / 1e6) for x in p[:6]], "queued/group %.0f groups %d" % (p[6] / max(p[7], 1), p[7]))
+    print("rounds %d total Mcycles(100MHz ticks?) %.2f " % (rounds, p[TIMED].sum() / 1e6), ["%.2f" % (x / 1e6) for x in p[TIMED]], "queued/group %.0f groups %d" % (p[6] / max(p[7], 1), p[7]))
+tots = np.array([p[TIMED].sum() for _, p in rows])
+rnds = np.array([r for r, _ in rows])
+print("per-frame total ticks: min %.3g mean %.3g median %.3g p90 %.3g max %.3g (max/mean %.2f)" % (tots.min(), tots.mean(), np.median(tots), np.percentile(tots, 90), tots.max(), tots.max() / tots.mean()))
+print("rounds per frame: min %d mean %.1f max %d; corr(rounds, ticks) %.3f" % (rnds.min(), rnds.mean(), rnds.max(), np.corrcoef(rnds, tots)[0, 1]))
