@@ -45,9 +45,9 @@ struct Buffers {
 	FrameAux *aux;
 	smhv_frame_result *results;
 	const smhv_anchors *anchors;   // device copy, may be null
-	// k_lsd sector culling table for this max_gap (null: cast every ray): SMH_CULL_CELLS cells of 3 words, cell = (row oy + R) * 4
-	// + word j covering offsets ox = -R + 32 j + [0, 32): [mask of the annulus pixels][unit ranges of bytes 0,1][of bytes 2,3],
-	// a range being first_unit | n_units << 6 (16 bits)
+	// k_lsd sector culling table for this max_gap (null: cast every ray), SMH_CULL_TAB_WORDS words:
+	//   [SMH_CULL_CELLS words] cell (row oy + R) * 4 + j: mask of the annulus pixels among offsets ox = -R + 32 j + [0, 32)
+	//   [(2R+1)^2 bytes, row-major] unit range of each annulus pixel: first_unit | (n_units - 1) << 6, 0xFF = every unit
 	const uint32_t *cull_tab;
 };
 
@@ -58,6 +58,7 @@ struct Buffers {
 #define SMH_SECTOR_DIM (2 * SMH_SECTOR_R + 1)
 #define SMH_SECTOR_ENTRIES (SMH_SECTOR_DIM * SMH_SECTOR_DIM)
 #define SMH_CULL_CELLS (SMH_SECTOR_DIM * 4)
+#define SMH_CULL_TAB_WORDS (SMH_CULL_CELLS + (SMH_SECTOR_ENTRIES + 3) / 4)
 
 enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u };
 enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };

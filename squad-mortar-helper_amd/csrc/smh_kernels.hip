@@ -485,7 +485,12 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 #define LSD_BS 1024
 #endif
 #define LSD_NW (LSD_BS / 64)
+#ifndef LSD_C
 #define LSD_C 8u                                   // candidates ray-cast per group
+#endif
+#ifndef LSD_C_RESET
+#define LSD_C_RESET 2u
+#endif
 #define LSD_GROUPS ((SMH_LSD_RAYS + 63) / 64)      // 64-ray units per candidate (57)
 #define LSD_GROUPS_HOST 57
 #define LSD_UNITS (LSD_C * LSD_GROUPS)
@@ -493,9 +498,10 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 #define LSD_QCAP 2048u
 #define LSD_QPT (LSD_QCAP / LSD_BS)                   // queue entries per thread in phase B
 #define LSD_A_BATCHES 2u                            // 32-sample batches walked in phase A before a ray is queued
-#define LSD_WIN_WORDS_CAP 30000u                   // 1080p whole ROI in ROWS mode = 824 rows x 33 words + 4 = 27196 words.
-// (With 153 KB of LDS per workgroup nothing else shares the CU.  Tried: a 28000-word cap lets a streaming workgroup of the
-// next pipelined step co-reside -- measured 2 % slower overall and k_map_pass 0.52 -> 0.62 ms, the two compete for VALU issue.)
+#define LSD_WIN_WORDS_CAP 27400u                   // 1080p whole ROI in ROWS mode = 824 rows x 33 words + 4 = 27196 words;
+// the rest of the 160 KB holds the candidate list, the ray queue, LsdShared and the sector culling table (12.7 KB).
+// (Nothing else shares the CU.  Tried: a workgroup small enough for a streaming workgroup of the next pipelined step to
+// co-reside -- measured 2 % slower overall and k_map_pass 0.52 -> 0.62 ms, the two compete for VALU issue.)
 #define LSD_ROWS_PITCH(gp) ((gp) | 1u)                 // LDS row pitch (words) of LSD_MODE_ROWS
 #define LSD_DYN_LDS_BYTES ((LSD_WIN_WORDS_CAP + LSD_LIST_CAP + 2u * LSD_QCAP) * 4u)
 
@@ -1071,7 +1077,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 
 	// sector culling needs the table for this max_gap (absent in exact-statistics mode) and a gap threshold below 50
 	const bool cull = b.cull_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
-	if (cull) for (uint32_t i = tid; i < 3u * SMH_CULL_CELLS; i += LSD_BS) cull_tab[i] = b.cull_tab[i];   // visible after the first barrier below
+	if (cull) for (uint32_t i = tid; i < SMH_CULL_TAB_WORDS; i += LSD_BS) cull_tab[i] = b.cull_tab[i];   // visible after the first barrier below
 	uint32_t rounds = 0, n_lines = 0;
 	unsigned long long steps = 0ull;
 	uint32_t seg_start = 0, cmax = 1u;
@@ -1177,7 +1183,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					// ---- sector culling: which 64-ray units can see a white pixel at a distance in [50 - T, 50]? ----
 					// One thread per (candidate, row, 32-pixel word) cell of the (2R+1)-row neighbourhood: the mask word,
 					// funnel-shifted so that bit 0 is offset -R from floor(start point), is ANDed with the annulus mask of
-					// the cell; each of its four bytes that holds a white annulus pixel contributes its unit range.
+					// the cell; every white annulus pixel left contributes its unit range (a byte code per pixel).
 					for (uint32_t id = tid; id < nc * SMH_CULL_CELLS; id += LSD_BS) {
 						const uint32_t c = id / SMH_CULL_CELLS, cell = id - c * SMH_CULL_CELLS;
 						const int fx = (int)floorf(sh.cand_pt[c][0]), fy = (int)floorf(sh.cand_pt[c][1]);
@@ -1185,14 +1191,14 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 						if ((uint32_t)yi >= m.h) continue;
 						const int b0 = fx - SMH_SECTOR_R + (int)((cell & 3u) << 5) + m.xbias;   // view bit coordinate of the cell's bit 0
 						const uint32_t lo = win_word(m, b0 >> 5, yi), hi = win_word(m, (b0 >> 5) + 1, yi);
-						const uint32_t hit = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)b0 & 31u) & cull_tab[3u * cell];
+						uint32_t hit = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)b0 & 31u) & cull_tab[cell];
 						if (hit) {
-							const uint32_t r01 = cull_tab[3u * cell + 1u], r23 = cull_tab[3u * cell + 2u];
+							const uint8_t *codes = (const uint8_t *)(cull_tab + SMH_CULL_CELLS) + (cell >> 2) * SMH_SECTOR_DIM + ((cell & 3u) << 5);
 							unsigned long long acc = 0ull;
-#pragma unroll
-							for (uint32_t q = 0; q < 4u; ++q) {
-								const uint32_t rg = ((q < 2u ? r01 : r23) >> ((q & 1u) * 16u)) & 0xFFFFu;   // first | n_units << 6
-								if ((hit >> (8u * q)) & 0xFFu) acc |= ((1ull << (rg >> 6)) - 1ull) << (rg & 63u);   // first + n <= 64 (host)
+							while (hit) {                           // white annulus pixels of this word: their unit ranges
+								const uint32_t code = codes[__builtin_ctz(hit)];
+								hit &= hit - 1u;
+								acc |= code == 0xFFu ? ~0ull : ((2ull << (code >> 6)) - 1ull) << (code & 63u);   // first <= 56, n <= 4
 							}
 							atomicOr(&sh.live[c], (acc | (acc >> LSD_GROUPS)) & ((1ull << LSD_GROUPS) - 1ull));   // units wrap at 57
 						}
@@ -1234,7 +1240,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				// Speculation width: a line accepted inside a group invalidates the later candidates of that
 				// group near it (wasted ray casts), and acceptances cluster (first pixels of a marker), so the
 				// width restarts at 1 after an acceptance and doubles after every acceptance-free group.
-				cmax = (n_lines != first_new) ? 1u : min(cmax * 2u, LSD_C);
+				cmax = (n_lines != first_new) ? LSD_C_RESET : min(cmax * 2u, LSD_C);
 				PROF_MARK(5);   // resolve
 				for (uint32_t l = first_new; l < n_lines && surv; ++l) {
 					const float x0 = sh.lines[l][0], y0 = sh.lines[l][1], x1 = sh.lines[l][2], y1 = sh.lines[l][3];
@@ -1278,7 +1284,7 @@ template <int MODE>
 __global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ LsdShared sh;
-	__shared__ uint32_t cull_tab[3 * SMH_CULL_CELLS];
+	__shared__ uint32_t cull_tab[SMH_CULL_TAB_WORDS];
 	const uint32_t f = blockIdx.x;
 	const FrameAux aux = b.aux[f];
 	if (mode == 0) {

@@ -180,11 +180,11 @@ static void logf(smhv_ctx *c, int lvl, const char *fmt, ...) {
 	c->log(lvl, buf);
 }
 
-// Smallest cyclic run of 64-ray units covering mask m (a superset only casts more rays), as first | n << 6; 0 = none.
-static uint32_t unit_range(unsigned long long m) {
+// Smallest cyclic run of 64-ray units covering mask m (a superset only casts more rays) as the byte code of
+// Buffers::cull_tab: first | (n - 1) << 6 for n <= 4, else 0xFF = every unit.  m != 0.
+static uint8_t unit_code(unsigned long long m) {
 	const uint32_t NU = 57;                                   // units per candidate
 	m &= (1ull << NU) - 1ull;
-	if (!m) return 0;
 	uint32_t first = 0, cnt = NU, best_gap = 0;               // complement of the longest cyclic zero gap
 	for (uint32_t st = 0; st < NU; ++st) {
 		if (!((m >> st) & 1ull)) continue;
@@ -192,8 +192,8 @@ static uint32_t unit_range(unsigned long long m) {
 		while (gap < NU - 1 && !((m >> ((st + 1 + gap) % NU)) & 1ull)) ++gap;
 		if (gap > best_gap) { best_gap = gap; first = (st + 1 + gap) % NU; cnt = NU - gap; }
 	}
-	if (best_gap == 0 || first + cnt > 64) { first = 0; cnt = NU; }   // keep (2^n - 1) << first inside 64 bits
-	return first | (cnt << 6);
+	if (best_gap == 0 || cnt > 4) return 0xFF;
+	return (uint8_t)(first | ((cnt - 1) << 6));               // first <= 56: never 0xFF
 }
 
 // Device table for max_gap (nullptr => k_lsd casts every ray).  Built once per distinct threshold: the kernel
@@ -213,22 +213,14 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 	if (e == hipSuccess) e = hipStreamSynchronize(s);
 	(void)hipFree(d_dense);
 	if (e != hipSuccess) return fail(SMHV_E_HIP, "sector table: %s", hipGetErrorString(e));
-	std::vector<uint32_t> cells(3 * SMH_CULL_CELLS, 0u);
+	std::vector<uint32_t> cells(SMH_CULL_TAB_WORDS, 0u);
+	uint8_t *codes = (uint8_t *)&cells[SMH_CULL_CELLS];
 	for (uint32_t row = 0; row < SMH_SECTOR_DIM; ++row)
-		for (uint32_t j = 0; j < 4; ++j) {
-			uint32_t amask = 0, rng[4] = {0, 0, 0, 0};
-			for (uint32_t q = 0; q < 4; ++q) {
-				unsigned long long um = 0;
-				for (uint32_t bit = 8 * q; bit < 8 * q + 8; ++bit) {
-					const uint32_t col = 32 * j + bit;                 // ox + R
-					if (col >= SMH_SECTOR_DIM) continue;
-					const unsigned long long m = dense[row * SMH_SECTOR_DIM + col];
-					if (m) { amask |= 1u << bit; um |= m; }
-				}
-				rng[q] = unit_range(um);
-			}
-			uint32_t *cell = &cells[3 * (row * 4 + j)];
-			cell[0] = amask; cell[1] = rng[0] | (rng[1] << 16); cell[2] = rng[2] | (rng[3] << 16);
+		for (uint32_t col = 0; col < SMH_SECTOR_DIM; ++col) {
+			const unsigned long long m = dense[row * SMH_SECTOR_DIM + col] & ((1ull << 57) - 1ull);
+			if (!m) continue;
+			cells[row * 4 + (col >> 5)] |= 1u << (col & 31u);
+			codes[row * SMH_SECTOR_DIM + col] = unit_code(m);
 		}
 	uint32_t *d = nullptr;
 	HIPCHK(hipMalloc((void **)&d, sizeof(uint32_t) * cells.size()));
