@@ -192,6 +192,31 @@ SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
  * is_any_map_marker_color(r,g,b) (vision-common/src/markers/mod.rs:40-54) */
 SMHV_API int smhv_debug_marker_table(smhv_ctx *ctx, uint32_t *bits);
 
+/* ---- ingest queue: the capture hand-off in front of load_frame (src/capture.rs:33-63) --------------------------
+ * The reference's capture thread hashes each captured BGRA frame with crc32fast::hash (CRC-32/IEEE) and passes it
+ * on only if the CRC differs from the previous capture's (capture.rs:44-47, `last_frame_crc32` starts at 0).  Here
+ * the capture source fills pinned staging buffers (acquire -> write -> commit), every frame goes to HBM with an
+ * asynchronous copy on the queue's own stream, its CRC-32 is computed on the device, and frames that are not
+ * duplicates of the last accepted frame are appended, in order, to a device slab of `capacity` frames that
+ * smhv_batch_run (or smhv_load_frame_device) consumes.  One producer thread per queue. */
+typedef struct smhv_ingest smhv_ingest;
+SMHV_API int smhv_ingest_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t slots, uint32_t capacity, smhv_ingest **out);
+SMHV_API void smhv_ingest_destroy(smhv_ingest *q);
+/* next pinned staging buffer (frame_w * frame_h * 4 bytes); blocks only when all `slots` uploads are in flight */
+SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra);
+/* start upload + CRC of the acquired buffer; returns at once */
+SMHV_API int smhv_ingest_commit(smhv_ingest *q);
+/* acquire + memcpy + commit for frames that live in ordinary host memory */
+SMHV_API int smhv_ingest_push(smhv_ingest *q, const uint8_t *bgra);
+/* wait for everything committed; *d_frames = slab of *n accepted frames (valid until reset + next commit);
+ * *last_crc (optional) = CRC-32 of the last accepted frame.  SMHV_E_STATE if more than `capacity` frames were accepted. */
+SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames, uint32_t *n, uint32_t *last_crc);
+/* start a new slab; the duplicate test keeps comparing with the last accepted frame */
+SMHV_API int smhv_ingest_reset(smhv_ingest *q);
+SMHV_API int smhv_ingest_counts(smhv_ingest *q, uint64_t *n_new, uint64_t *n_dup);
+/* CRC-32/IEEE of nbytes (multiple of 4) of device memory; == crc32fast::hash / zlib crc32 of the same bytes */
+SMHV_API int smhv_crc32_device(smhv_ctx *ctx, const void *d_data, uint64_t nbytes, uint32_t *crc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,10 @@ def lib():
         L.orc_marker_angle.restype = C.c_float
         L.orc_marker_angle.argtypes = [f32p]
         L.orc_find_minimap.argtypes = [u8p, C.c_uint32, C.c_uint32, u32p]
+        L.orc_crc32.restype = C.c_uint32
+        L.orc_crc32.argtypes = [u8p, C.c_uint64]
+        L.orc_capture_dedupe.restype = C.c_uint32
+        L.orc_capture_dedupe.argtypes = [u32p, C.c_uint32, u32p, u8p]
         L.orc_process_frame.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                         C.c_uint32, C.POINTER(FrameResult), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_process_batch.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -231,6 +235,21 @@ def find_minimap(frame_bgra):
     if rc < 0:
         raise ValueError("geometry")
     return tuple(int(v) for v in rect) if rc == 1 else None
+
+
+def crc32(data):
+    """crc32fast::hash of the capture thread (src/capture.rs:44)."""
+    a = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data.reshape(-1).view(np.uint8))
+    return int(lib().orc_crc32(a, a.size))
+
+
+def capture_dedupe(crcs, last=0):
+    """Which frames the capture loop delivers (src/capture.rs:34,44-47): (keep mask, final last_frame_crc32)."""
+    c = np.ascontiguousarray(crcs, dtype=np.uint32)
+    keep = np.zeros(len(c), np.uint8)
+    lst = np.array([last], np.uint32)
+    lib().orc_capture_dedupe(c, len(c), lst, keep)
+    return keep.astype(bool), int(lst[0])
 
 
 def marker_new(line, ratio):

@@ -698,3 +698,29 @@ ORC_API int orc_process_batch(const uint8_t *frames, uint32_t n, uint32_t W, uin
 	}
 	return 0;
 }
+
+/* ---- capture hand-off (src/capture.rs:33-63) ----------------------------------------------------------------
+ * `crc32fast::hash(&frame)` (capture.rs:44): crc32fast 1.3.2 is a crates.io dependency (Cargo.lock:621-622), not vendored
+ * under /root/reference.  It implements the standard CRC-32/IEEE 802.3 (reflected polynomial 0xEDB88320, init and
+ * final xor 0xFFFFFFFF; check value crc("123456789") = 0xCBF43926) -- the same function as zlib's crc32, which the
+ * tests use as the second opinion.  Restated here bit by bit. */
+ORC_API uint32_t orc_crc32(const uint8_t *data, uint64_t n) {
+	uint32_t c = 0xFFFFFFFFu;
+	for (uint64_t i = 0; i < n; ++i) {
+		c ^= data[i];
+		for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+	}
+	return c ^ 0xFFFFFFFFu;
+}
+
+/* The capture loop's duplicate rule (capture.rs:34,44-47): `last_frame_crc32` starts at 0; a frame is delivered iff its
+ * CRC differs from last_frame_crc32, which then takes its value.  keep[i] = 1 for delivered frames; returns their count
+ * and leaves the final last_frame_crc32 in *last (in: initial value). */
+ORC_API uint32_t orc_capture_dedupe(const uint32_t *crcs, uint32_t n, uint32_t *last, uint8_t *keep) {
+	uint32_t kept = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		keep[i] = crcs[i] != *last;
+		if (keep[i]) { *last = crcs[i]; ++kept; }
+	}
+	return kept;
+}

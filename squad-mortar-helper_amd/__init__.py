@@ -8,3 +8,4 @@ from . import _lib  # noqa: F401
 from ._lib import VisionError, STAGE_ALL, STAGE_EXACT_STATS, STAGE_MARKERS, STAGE_MINIMAP, STAGE_OCR, STAGE_SCALES, STAGE_UI_MAP  # noqa: F401
 from .vision import DebugView, HipVision, VisionResults, VisionState, button_bounds, map_bounds, parse_ocr_labels  # noqa: F401
 from .batch import FrameBatch, make_anchors, results_to_dicts  # noqa: F401
+from .ingest import IngestQueue, crc32_device  # noqa: F401

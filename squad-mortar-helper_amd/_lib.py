@@ -88,6 +88,15 @@ SIGNATURES = {
     "smhv_batch_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "smhv_batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "smhv_ingest_destroy": (None, [C.c_void_p]),
+    "smhv_ingest_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "smhv_ingest_commit": (C.c_int, [C.c_void_p]),
+    "smhv_ingest_push": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "smhv_ingest_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "smhv_ingest_reset": (C.c_int, [C.c_void_p]),
+    "smhv_ingest_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "smhv_crc32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
 }
 
 

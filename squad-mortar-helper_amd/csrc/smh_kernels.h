@@ -76,5 +76,14 @@ hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, in
 hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
 size_t lsd_lds_bytes();
+// CRC-32 of n_dwords 32-bit words at d_msg, xor-ed into *d_acc (zero it first) WITHOUT the init / final-xor terms:
+//   crc = *d_acc ^ crc32_mul(crc32_xpow(32 * n_dwords), 0xFFFFFFFF) ^ 0xFFFFFFFF.
+// wgs workgroups of SMH_CRC_BS threads, rounds * wgs * SMH_CRC_BS * 4 >= n_dwords; x_skip = x^(128 (G - 1)),
+// d_x_local[t] = x^(128 (SMH_CRC_BS - 1 - t)), d_x_wg[g] = x^(128 SMH_CRC_BS (wgs - 1 - g)), G = wgs * SMH_CRC_BS.
+#define SMH_CRC_BS 1024
+hipError_t launch_crc32(const void *d_msg, uint64_t n_dwords, uint32_t wgs, uint32_t rounds, uint32_t x_skip, const uint32_t *d_x_local,
+                        const uint32_t *d_x_wg, uint32_t *d_acc, hipStream_t s);
+uint32_t crc32_xpow(uint64_t n);                 // x^n mod P (reflected representation, x^0 = 0x80000000)
+uint32_t crc32_mul(uint32_t a, uint32_t b);      // a * b mod P
 
 }  // namespace smh

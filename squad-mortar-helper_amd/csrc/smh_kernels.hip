@@ -1652,4 +1652,103 @@ hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s) {
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_crc32: CRC-32 (IEEE 802.3, reflected polynomial 0xEDB88320) of a frame in HBM -- the value the
+// reference's capture thread computes with crc32fast::hash to drop duplicate captures
+// (src/capture.rs:44-47).  CRC without its init / final xor is linear over GF(2):
+//     R(A || B) = R(A) * x^(8|B|) mod P  xor  R(B)
+// so the frame is cut into 16-byte groups dealt round-robin to every thread of the grid; a thread
+// folds its groups with the usual slice-by-4 table step (tables in LDS) and a multiplication by
+// x^(128 (G - 1)) between rounds (G = threads in the grid), then aligns its remainder to the end of
+// the message with one multiplication by x^(128 (G - 1 - T)) and all remainders are xor-ed together
+// (DPP within the wave, LDS across waves, one atomicXor per workgroup).  Leading zero padding does
+// not change R, so the message is right-aligned in the last round; the init / final-xor terms
+// depend on the length only and are applied by the host (smh_runtime.cpp: crc32_finish).
+// HBM-bound: 1 byte read per byte; ~30 VALU + 16 LDS lookups per 16 bytes.
+// ------------------------------------------------------------------------------------------------
+#define CRC_POLY 0xEDB88320u
+#define CRC_BS 1024
+
+// a * b mod P in the reflected representation (x^0 = 0x80000000)
+__host__ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
+	uint32_t p = 0;
+	for (int i = 0; i < 32; ++i) {
+		p ^= (a & 0x80000000u) ? b : 0u;
+		a <<= 1;
+		b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+	}
+	return p;
+}
+
+__device__ __forceinline__ uint32_t wave_xor32_dpp(uint32_t v) {
+	v ^= SMH_DPP(v, 0xB1);
+	v ^= SMH_DPP(v, 0x4E);
+	v ^= SMH_DPP(v, 0x141);
+	v ^= SMH_DPP(v, 0x140);
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^
+	       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// n_dwords: message length in 32-bit words; rounds * gridDim.x * CRC_BS * 4 >= n_dwords.
+// x_skip = x^(128 (G - 1)); x_local[t] = x^(128 (CRC_BS - 1 - t)); x_wg[g] = x^(128 CRC_BS (gridDim.x - 1 - g)).
+__global__ void __launch_bounds__(CRC_BS) k_crc32(const uint32_t *msg, uint64_t n_dwords, uint32_t rounds, uint32_t x_skip,
+                                                 const uint32_t *x_local, const uint32_t *x_wg, uint32_t *acc) {
+	__shared__ uint32_t tab[4][256];
+	__shared__ uint32_t wsum[CRC_BS / 64];
+	const uint32_t tid = threadIdx.x;
+	if (tid < 256u) {
+		uint32_t c = tid;
+		for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+		tab[0][tid] = c;
+	}
+	__syncthreads();
+	if (tid < 256u) {
+		uint32_t c = tab[0][tid];
+		for (int k = 1; k < 4; ++k) { c = (c >> 8) ^ tab[0][c & 255u]; tab[k][tid] = c; }
+	}
+	__syncthreads();
+	const uint64_t G = (uint64_t)gridDim.x * CRC_BS, T = (uint64_t)blockIdx.x * CRC_BS + tid;
+	const uint64_t pad = (uint64_t)rounds * G * 4u - n_dwords;        // virtual leading zero words
+	uint32_t v = 0;
+	for (uint32_t r = 0; r < rounds; ++r) {
+		const uint64_t vi = ((uint64_t)r * G + T) * 4u;                 // virtual index of this thread's group
+		uint32_t d[4] = {0u, 0u, 0u, 0u};
+		if (vi >= pad && ((vi - pad) & 3u) == 0u && (((uintptr_t)msg) & 15u) == 0u) {
+			const uint4 q = *(const uint4 *)(msg + (vi - pad));
+			d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) if (vi + j >= pad) d[j] = msg[vi + j - pad];
+		}
+		if (r) v = gf2_mulmod(v, x_skip);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t c = v ^ d[j];
+			v = tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24];
+		}
+	}
+	v = gf2_mulmod(v, x_local[tid]);
+	v = wave_xor32_dpp(v);
+	if ((tid & 63u) == 0u) wsum[tid >> 6] = v;
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t w = 0;
+		for (int k = 0; k < CRC_BS / 64; ++k) w ^= wsum[k];
+		atomicXor(acc, gf2_mulmod(w, x_wg[blockIdx.x]));
+	}
+}
+
+uint32_t crc32_xpow(uint64_t n) {                             // x^n mod P
+	uint32_t r = 0x80000000u, b = 0x40000000u;                // x^0, x^1
+	for (; n; n >>= 1) { if (n & 1u) r = gf2_mulmod(r, b); b = gf2_mulmod(b, b); }
+	return r;
+}
+uint32_t crc32_mul(uint32_t a, uint32_t b) { return gf2_mulmod(a, b); }
+
+hipError_t launch_crc32(const void *d_msg, uint64_t n_dwords, uint32_t wgs, uint32_t rounds, uint32_t x_skip, const uint32_t *d_x_local,
+                        const uint32_t *d_x_wg, uint32_t *d_acc, hipStream_t s) {
+	hipLaunchKernelGGL(k_crc32, dim3(wgs), dim3(CRC_BS), 0, s, (const uint32_t *)d_msg, n_dwords, rounds, x_skip, d_x_local, d_x_wg, d_acc);
+	return hipGetLastError();
+}
+
 }  // namespace smh

@@ -843,3 +843,209 @@ extern "C" SMHV_API int smhv_debug_marker_table(smhv_ctx *c, uint32_t *bits) {
 	if (e != hipSuccess) return fail(SMHV_E_HIP, "marker table: %s", hipGetErrorString(e));
 	return SMHV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ingest queue: the step in front of load_frame.  The reference's capture thread
+// (src/capture.rs:33-63) hashes every captured frame with crc32fast and hands it on only when the CRC
+// differs from the previous capture's; here the capture source writes into pinned staging buffers, each
+// frame is uploaded with an asynchronous copy on the queue's own stream (so uploads overlap the batch
+// compute of earlier frames), its CRC-32 is computed on the device (k_crc32), and frames whose CRC
+// differs from the last accepted one are appended to a device-resident slab that smhv_batch_run takes.
+// ------------------------------------------------------------------------------------------------
+struct smhv_ingest {
+	smhv_ctx *ctx = nullptr;
+	uint32_t W = 0, H = 0, slots = 0, capacity = 0;
+	size_t frame_bytes = 0;
+	hipStream_t s = nullptr;
+	std::vector<uint8_t *> h_stage, d_stage;
+	std::vector<hipEvent_t> done;
+	uint32_t *d_acc = nullptr, *h_acc = nullptr;            // one CRC accumulator per slot (device / pinned host)
+	uint32_t *d_x_local = nullptr, *d_x_wg = nullptr;
+	uint32_t wgs = 0, rounds = 0, x_skip = 0, len_term = 0;
+	uint64_t head = 0, tail = 0;                             // frames acquired / resolved (slot = index % slots)
+	bool acquired = false;
+	uint8_t *d_slab = nullptr;
+	uint32_t count = 0, last_crc = 0;                        // capture.rs:34 `let mut last_frame_crc32 = 0;`
+	uint64_t n_new = 0, n_dup = 0;
+};
+
+// crc = raw remainder ^ (init 0xFFFFFFFF carried over the whole message) ^ final xor
+static uint32_t crc32_len_term(uint64_t n_dwords) { return crc32_mul(crc32_xpow(32u * n_dwords), 0xFFFFFFFFu) ^ 0xFFFFFFFFu; }
+
+struct CrcPlan { uint32_t wgs, rounds, x_skip; std::vector<uint32_t> x_local, x_wg; };
+static CrcPlan crc_plan(uint64_t n_dwords) {
+	CrcPlan p;
+	const uint64_t groups = (n_dwords + 3) / 4;               // 16-byte groups
+	uint64_t wgs = (groups + SMH_CRC_BS - 1) / SMH_CRC_BS;
+	if (wgs > 1024) wgs = 1024;                               // 4 workgroups per CU; larger messages take more rounds
+	if (wgs == 0) wgs = 1;
+	p.wgs = (uint32_t)wgs;
+	const uint64_t G = wgs * SMH_CRC_BS;
+	p.rounds = (uint32_t)((groups + G - 1) / G);
+	if (p.rounds == 0) p.rounds = 1;
+	p.x_skip = crc32_xpow(128u * (G - 1));
+	p.x_local.resize(SMH_CRC_BS);
+	for (uint32_t t = 0; t < SMH_CRC_BS; ++t) p.x_local[t] = crc32_xpow(128u * (uint64_t)(SMH_CRC_BS - 1 - t));
+	p.x_wg.resize(wgs);
+	const uint32_t step = crc32_xpow(128u * (uint64_t)SMH_CRC_BS);
+	uint32_t acc = 0x80000000u;                               // x^0
+	for (uint64_t g = wgs; g-- > 0;) { p.x_wg[g] = acc; acc = crc32_mul(acc, step); }
+	return p;
+}
+
+extern "C" SMHV_API int smhv_crc32_device(smhv_ctx *c, const void *d_data, uint64_t nbytes, uint32_t *crc) {
+	if (!c || !crc || (nbytes && !d_data) || (nbytes & 3u)) return fail(SMHV_E_INVALID, "crc32: null argument or length not a multiple of 4");
+	HIPCHK(hipSetDevice(c->device));
+	if (nbytes == 0) { *crc = 0; return SMHV_OK; }
+	const uint64_t nd = nbytes / 4;
+	const CrcPlan p = crc_plan(nd);
+	uint32_t *d = nullptr;
+	HIPCHK(hipMalloc((void **)&d, sizeof(uint32_t) * (1 + SMH_CRC_BS + p.wgs)));
+	hipStream_t s = c->s_main;
+	uint32_t raw = 0;
+	hipError_t e = hipMemsetAsync(d, 0, sizeof(uint32_t), s);
+	if (e == hipSuccess) e = hipMemcpyAsync(d + 1, p.x_local.data(), sizeof(uint32_t) * SMH_CRC_BS, hipMemcpyHostToDevice, s);
+	if (e == hipSuccess) e = hipMemcpyAsync(d + 1 + SMH_CRC_BS, p.x_wg.data(), sizeof(uint32_t) * p.wgs, hipMemcpyHostToDevice, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);         // the plan vectors are pageable host memory
+	if (e == hipSuccess) e = launch_crc32(d_data, nd, p.wgs, p.rounds, p.x_skip, d + 1, d + 1 + SMH_CRC_BS, d, s);
+	if (e == hipSuccess) e = hipMemcpyAsync(&raw, d, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	(void)hipFree(d);
+	if (e != hipSuccess) return fail(SMHV_E_HIP, "crc32: %s", hipGetErrorString(e));
+	*crc = raw ^ crc32_len_term(nd);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
+	if (!q) return;
+	(void)hipSetDevice(q->ctx->device);
+	if (q->s) (void)hipStreamSynchronize(q->s);
+	for (auto p : q->h_stage) if (p) (void)hipHostFree(p);
+	for (auto p : q->d_stage) if (p) (void)hipFree(p);
+	for (auto ev : q->done) if (ev) (void)hipEventDestroy(ev);
+	if (q->d_acc) (void)hipFree(q->d_acc);
+	if (q->h_acc) (void)hipHostFree(q->h_acc);
+	if (q->d_x_local) (void)hipFree(q->d_x_local);
+	if (q->d_x_wg) (void)hipFree(q->d_x_wg);
+	if (q->d_slab) (void)hipFree(q->d_slab);
+	if (q->s) (void)hipStreamDestroy(q->s);
+	delete q;
+}
+
+static int ingest_setup(smhv_ingest *q) {
+	HIPCHK(hipStreamCreateWithFlags(&q->s, hipStreamNonBlocking));
+	q->h_stage.assign(q->slots, nullptr); q->d_stage.assign(q->slots, nullptr); q->done.assign(q->slots, nullptr);
+	for (uint32_t i = 0; i < q->slots; ++i) {
+		HIPCHK(hipHostMalloc((void **)&q->h_stage[i], q->frame_bytes, hipHostMallocDefault));
+		HIPCHK(hipMalloc((void **)&q->d_stage[i], q->frame_bytes));
+		HIPCHK(hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming));
+	}
+	HIPCHK(hipMalloc((void **)&q->d_acc, sizeof(uint32_t) * q->slots));
+	HIPCHK(hipHostMalloc((void **)&q->h_acc, sizeof(uint32_t) * q->slots, hipHostMallocDefault));
+	const uint64_t nd = q->frame_bytes / 4;
+	const CrcPlan p = crc_plan(nd);
+	q->wgs = p.wgs; q->rounds = p.rounds; q->x_skip = p.x_skip; q->len_term = crc32_len_term(nd);
+	HIPCHK(hipMalloc((void **)&q->d_x_local, sizeof(uint32_t) * SMH_CRC_BS));
+	HIPCHK(hipMalloc((void **)&q->d_x_wg, sizeof(uint32_t) * p.wgs));
+	HIPCHK(hipMemcpy(q->d_x_local, p.x_local.data(), sizeof(uint32_t) * SMH_CRC_BS, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(q->d_x_wg, p.x_wg.data(), sizeof(uint32_t) * p.wgs, hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc((void **)&q->d_slab, q->frame_bytes * q->capacity));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_ingest_create(smhv_ctx *c, uint32_t w, uint32_t h, uint32_t slots, uint32_t capacity, smhv_ingest **out) {
+	if (!c || !out || w == 0 || h == 0 || slots < 2 || slots > 64 || capacity == 0) return fail(SMHV_E_INVALID, "ingest_create: bad arguments");
+	*out = nullptr;
+	Geom g;
+	int rc = compute_geom(w, h, &g);                          // same frame-size rules as load_frame
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(c->device));
+	smhv_ingest *q = new (std::nothrow) smhv_ingest();
+	if (!q) return fail(SMHV_E_INVALID, "out of memory");
+	q->ctx = c; q->W = w; q->H = h; q->slots = slots; q->capacity = capacity; q->frame_bytes = (size_t)w * h * 4;
+	rc = ingest_setup(q);
+	if (rc) { smhv_ingest_destroy(q); return rc; }
+	*out = q;
+	return SMHV_OK;
+}
+
+// Resolve the oldest in-flight frame: wait for its upload + CRC, apply the reference's duplicate rule
+// (capture.rs:44-47) and append it to the slab when it is new.
+static int ingest_resolve_one(smhv_ingest *q) {
+	const uint32_t slot = (uint32_t)(q->tail % q->slots);
+	HIPCHK(hipEventSynchronize(q->done[slot]));
+	const uint32_t crc = q->h_acc[slot] ^ q->len_term;
+	if (crc == q->last_crc) { q->tail++; q->n_dup++; return SMHV_OK; }
+	if (q->count == q->capacity)                              // the frame stays queued: take the slab, reset, continue
+		return fail(SMHV_E_STATE, "ingest: the batch slab is full (%u frames); take it with smhv_ingest_batch and reset", q->capacity);
+	q->last_crc = crc;
+	HIPCHK(hipMemcpyAsync(q->d_slab + (size_t)q->count * q->frame_bytes, q->d_stage[slot], q->frame_bytes, hipMemcpyDeviceToDevice, q->s));
+	q->tail++; q->count++; q->n_new++;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra) {
+	if (!q || !host_bgra) return fail(SMHV_E_INVALID, "ingest_acquire: null argument");
+	if (q->acquired) return fail(SMHV_E_INVALID, "ingest_acquire: the previous buffer was not committed");
+	HIPCHK(hipSetDevice(q->ctx->device));
+	while (q->head - q->tail >= q->slots) {                   // every staging slot is in flight: retire the oldest
+		int rc = ingest_resolve_one(q);
+		if (rc) return rc;
+	}
+	const uint32_t slot = (uint32_t)(q->head % q->slots);
+	// the slot's previous device copy may still be the source of a slab append on q->s: stream order covers it
+	*host_bgra = q->h_stage[slot];
+	q->acquired = true;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_ingest_commit(smhv_ingest *q) {
+	if (!q || !q->acquired) return fail(SMHV_E_INVALID, "ingest_commit: nothing acquired");
+	HIPCHK(hipSetDevice(q->ctx->device));
+	const uint32_t slot = (uint32_t)(q->head % q->slots);
+	HIPCHK(hipMemcpyAsync(q->d_stage[slot], q->h_stage[slot], q->frame_bytes, hipMemcpyHostToDevice, q->s));
+	HIPCHK(hipMemsetAsync(q->d_acc + slot, 0, sizeof(uint32_t), q->s));
+	HIPCHK(launch_crc32(q->d_stage[slot], q->frame_bytes / 4, q->wgs, q->rounds, q->x_skip, q->d_x_local, q->d_x_wg, q->d_acc + slot, q->s));
+	HIPCHK(hipMemcpyAsync(q->h_acc + slot, q->d_acc + slot, sizeof(uint32_t), hipMemcpyDeviceToHost, q->s));
+	HIPCHK(hipEventRecord(q->done[slot], q->s));
+	q->head++;
+	q->acquired = false;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_ingest_push(smhv_ingest *q, const uint8_t *bgra) {
+	if (!q || !bgra) return fail(SMHV_E_INVALID, "ingest_push: null argument");
+	uint8_t *dst = nullptr;
+	int rc = smhv_ingest_acquire(q, &dst);
+	if (rc) return rc;
+	memcpy(dst, bgra, q->frame_bytes);
+	return smhv_ingest_commit(q);
+}
+
+extern "C" SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames, uint32_t *n, uint32_t *last_crc) {
+	if (!q || !d_frames || !n) return fail(SMHV_E_INVALID, "ingest_batch: null argument");
+	if (q->acquired) return fail(SMHV_E_INVALID, "ingest_batch: a staging buffer is acquired but not committed");
+	HIPCHK(hipSetDevice(q->ctx->device));
+	while (q->tail < q->head) {
+		int rc = ingest_resolve_one(q);
+		if (rc) return rc;
+	}
+	HIPCHK(hipStreamSynchronize(q->s));                       // slab appends done: any stream may read it now
+	*d_frames = q->d_slab; *n = q->count;
+	if (last_crc) *last_crc = q->last_crc;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_ingest_reset(smhv_ingest *q) {
+	if (!q) return fail(SMHV_E_INVALID, "ingest_reset: null argument");
+	if (q->tail != q->head || q->acquired) return fail(SMHV_E_INVALID, "ingest_reset: frames still in flight (call smhv_ingest_batch first)");
+	q->count = 0;                                             // last_crc is kept: dedupe continues across batches
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_ingest_counts(smhv_ingest *q, uint64_t *n_new, uint64_t *n_dup) {
+	if (!q) return fail(SMHV_E_INVALID, "ingest_counts: null argument");
+	if (n_new) *n_new = q->n_new;
+	if (n_dup) *n_dup = q->n_dup;
+	return SMHV_OK;
+}

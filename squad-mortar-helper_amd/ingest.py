@@ -1,0 +1,74 @@
+"""Capture hand-off in front of load_frame: mirror of the reference's capture
+thread contract, src/capture.rs:33-63 -- every captured BGRA frame is hashed (crc32fast::hash, i.e.
+CRC-32/IEEE) and dropped when the CRC equals the previous capture's.  Here the frame is uploaded
+from pinned staging memory, hashed on the device and appended to a device-resident slab that
+FrameBatch.run / HipVision.load_frame_device consume.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def crc32_device(vision, device_ptr, nbytes):
+    """CRC-32/IEEE of `nbytes` (multiple of 4) of device memory; equals zlib.crc32 of the same bytes."""
+    out = C.c_uint32(0)
+    check(_lib.load().smhv_crc32_device(vision._ctx, C.c_void_p(int(device_ptr)), C.c_uint64(int(nbytes)), C.byref(out)))
+    return int(out.value)
+
+
+class IngestQueue:
+    """`slots` pinned staging buffers + one device slab of `capacity` frames of w x h BGRA."""
+
+    def __init__(self, vision, w, h, slots=4, capacity=256):
+        self._lib = _lib.load()
+        self._q = C.c_void_p()
+        self.w, self.h, self.capacity = int(w), int(h), int(capacity)
+        self.frame_bytes = self.w * self.h * 4
+        self._vision = vision                                   # keeps the context alive
+        check(self._lib.smhv_ingest_create(vision._ctx, self.w, self.h, int(slots), self.capacity, C.byref(self._q)))
+
+    def close(self):
+        if self._q:
+            self._lib.smhv_ingest_destroy(self._q)
+            self._q = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def acquire(self):
+        """Next pinned staging buffer as an (h, w, 4) uint8 array to capture into; then commit()."""
+        p = C.c_void_p()
+        check(self._lib.smhv_ingest_acquire(self._q, C.byref(p)))
+        buf = (C.c_uint8 * self.frame_bytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.h, self.w, 4)
+
+    def commit(self):
+        check(self._lib.smhv_ingest_commit(self._q))
+
+    def push(self, frame):
+        """Frame in ordinary host memory: one extra host copy into the staging buffer."""
+        a = np.ascontiguousarray(frame, dtype=np.uint8)
+        if a.shape != (self.h, self.w, 4):
+            raise ValueError("frame must be (%d, %d, 4) BGRA" % (self.h, self.w))
+        check(self._lib.smhv_ingest_push(self._q, a.ctypes.data_as(C.c_void_p)))
+
+    def batch(self):
+        """Wait for everything committed: (device pointer of the slab, accepted frames in it, CRC of the last one)."""
+        p, n, crc = C.c_void_p(), C.c_uint32(0), C.c_uint32(0)
+        check(self._lib.smhv_ingest_batch(self._q, C.byref(p), C.byref(n), C.byref(crc)))
+        return int(p.value or 0), int(n.value), int(crc.value)
+
+    def reset(self):
+        check(self._lib.smhv_ingest_reset(self._q))
+
+    def counts(self):
+        """(frames accepted, duplicates dropped) since creation."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._lib.smhv_ingest_counts(self._q, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)

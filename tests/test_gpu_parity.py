@@ -614,3 +614,103 @@ def test_stress_checkerboard_of_blobs(vision):
             frame[y + by:y + by + 3, x + bx:x + bx + 3] = PURPLE
     ref = _check_markers(vision, frame)
     assert ref["n_lines"] == 32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_gap", [3, 15, 30, 49])
+def test_stress_segments_around_the_acceptance_length(vision, max_gap):
+    """Sector culling (k_lsd casts only the 64-ray sectors that see a white pixel 50 - T .. 50 steps away) must
+    never lose a line: a grid of short segments whose lengths straddle the len^2 > 2500 acceptance threshold, at
+    all angles, solid and dashed with gaps of max_gap - 1 .. max_gap + 1 pixels."""
+    W, H = 1920, 1080
+    frame, (x, y, rw, rh) = _blank(W, H, 40 + max_gap)
+    roi = frame[y:y + rh, x:x + rw]
+    rng = np.random.default_rng(1000 + max_gap)
+    cell = 130
+    k = 0
+    for gy in range(rh // cell):
+        for gx in range(rw // cell):
+            cx, cy = gx * cell + cell // 2, gy * cell + cell // 2
+            L = 43.0 + (k % 16)                                  # 43 .. 58 px before dilation
+            ang = rng.uniform(0, np.pi)
+            gap = max(int(max_gap) - 1 + (k % 3), 0) if (k % 4) == 3 else 0   # every fourth one dashed
+            t = np.arange(0.0, L, 0.5)
+            on = np.ones_like(t, dtype=bool)
+            if gap and L / 2 + gap < L:
+                on[(t >= L / 2 - gap / 2.0) & (t < L / 2 + gap / 2.0)] = False
+            px = np.rint(cx - L / 2 * np.cos(ang) + t * np.cos(ang)).astype(int)
+            py = np.rint(cy - L / 2 * np.sin(ang) + t * np.sin(ang)).astype(int)
+            roi[py[on], px[on]] = GREEN if k % 2 else PURPLE
+            k += 1
+    ref = _check_markers(vision, frame, max_gap=max_gap)
+    assert 0 < len(ref["lines"]) <= 32
+
+
+# ---------------------------------------------------------------------------------------------------
+# ingest queue + device CRC-32 (the capture hand-off in front of load_frame; SURVEY 8(f) row f4)
+# ---------------------------------------------------------------------------------------------------
+def test_crc32_device_matches_zlib_and_oracle(vision):
+    import zlib
+    import torch
+    import squad_mortar_helper_amd as smh
+    rng = np.random.default_rng(21)
+    # 4 B .. 40 MB: single group, ragged tails (scalar path), one full round of 1024 workgroups, several rounds
+    for nbytes in (4, 8, 12, 16, 20, 4092, 4096, 65540, 1920 * 1080 * 4, 16 * 1024 * 1024, 16 * 1024 * 1024 + 4, 40 * 1000 * 1000):
+        buf = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        d = torch.from_numpy(buf).cuda()
+        got = smh.crc32_device(vision, d.data_ptr(), nbytes)
+        assert got == zlib.crc32(buf.tobytes()), nbytes
+        if nbytes <= 65540:
+            assert got == o.crc32(buf)
+    # misaligned device pointer (dword aligned only) takes the scalar load path
+    buf = rng.integers(0, 256, 1 << 20, dtype=np.uint8)
+    d = torch.from_numpy(buf).cuda()
+    assert smh.crc32_device(vision, d.data_ptr() + 4, (1 << 20) - 8) == zlib.crc32(buf[4:-4].tobytes())
+    # all-zero and all-ones messages (the init / final-xor terms are applied on the host)
+    z = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    assert smh.crc32_device(vision, z.data_ptr(), 1 << 16) == zlib.crc32(bytes(1 << 16))
+    with pytest.raises(smh.VisionError):
+        smh.crc32_device(vision, z.data_ptr(), 7)
+
+
+def test_ingest_queue_dedupes_like_the_capture_thread_and_feeds_the_batch(vision):
+    import zlib
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H = 1280, 1024
+    A, ia = synth.make_frame(W, H, 1, n_lines=2)
+    B, ib = synth.make_frame(W, H, 2, n_lines=1)
+    Cc, ic = synth.make_frame(W, H, 3, n_lines=3)
+    seq = [A, A, B, B, B, A, Cc, Cc]
+    crcs = [zlib.crc32(f.tobytes()) for f in seq]
+    keep, last = o.capture_dedupe(crcs)
+    q = smh.IngestQueue(vision, W, H, slots=3, capacity=4)
+    for k, f in enumerate(seq):
+        if k % 2:
+            q.push(f)                                      # pageable source
+        else:
+            buf = q.acquire()                              # capture straight into pinned staging
+            buf[...] = f
+            q.commit()
+    ptr, n, crc = q.batch()
+    assert n == int(keep.sum()) == 4 and crc == last and q.counts() == (4, 4)
+    nb = W * H * 4
+    fb = smh.FrameBatch(vision, W, H, n)
+    fb.run(ptr, n, stages=0x3)
+    recs = fb.read_results(0, n)
+    want = [f for f, k in zip(seq, keep) if k]
+    for r, f in zip(recs, want):
+        ref = o.process_frame(f, stages=0x3)
+        lines = np.array([[l.x0, l.y0, l.x1, l.y1] for l in r.lines[:r.n_lines]], np.float32).reshape(-1, 4)
+        assert r.map_open == 1 and np.array_equal(lines, ref["lines"])
+    for i, f in enumerate(want):
+        assert smh.crc32_device(vision, ptr + i * nb, nb) == zlib.crc32(f.tobytes())
+    # next slab: dedupe continues against the last accepted frame (C), and the capacity limit is an error, not a drop
+    q.reset()
+    for f in (Cc, A, B, A, B):
+        q.push(f)
+    assert q.batch()[1] == 4 and q.counts() == (8, 5)
+    q.push(A)
+    with pytest.raises(smh.VisionError):
+        q.batch()
+    q.close()

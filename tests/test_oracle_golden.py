@@ -261,3 +261,19 @@ def test_find_minimap_hand_made():
     band = frame.copy()
     band[y + h // 2 - 5:y + h // 2 + 5, x + 70:x + 290, :3] = 90
     assert o.find_minimap(band)[:2] == (l - 1, r)
+
+
+def test_crc32_restatement_and_capture_dedupe_rule():
+    """src/capture.rs:34,44-47: crc32fast::hash == CRC-32/IEEE (zlib's crc32 is the independent second opinion),
+    and the capture loop delivers a frame iff its CRC differs from the previous capture's (initial value 0)."""
+    import zlib
+    assert o.crc32(b"123456789") == 0xCBF43926            # the catalogue check value of CRC-32/ISO-HDLC
+    assert o.crc32(b"") == 0
+    rng = np.random.default_rng(11)
+    for n in (1, 3, 4, 5, 63, 64, 65, 4096, 100001):
+        buf = rng.integers(0, 256, n, dtype=np.uint8)
+        assert o.crc32(buf) == zlib.crc32(buf.tobytes()), n
+    keep, last = o.capture_dedupe([5, 5, 7, 7, 5, 0, 0, 9])
+    assert keep.tolist() == [True, False, True, False, True, True, False, True] and last == 9
+    keep, last = o.capture_dedupe([0, 0, 3])                # a first frame whose CRC is 0 is dropped (initial value 0)
+    assert keep.tolist() == [False, False, True] and last == 3
