@@ -290,11 +290,7 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 
 	// ---- outputs: u8 mask rows and bit-packed rows ----
 	const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
-#ifdef EXP_NO_PHASE3
-	if (q < quads_padded && D[0] == 0x123456789ull) {
-#else
 	if (q < quads_padded) {
-#endif
 		uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
 		uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
 		for (int row = r0; row < r1; ++row) {
@@ -303,13 +299,11 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 			                     ((uint32_t)((D[2] >> bit) & 1ull) << 2) | ((uint32_t)((D[3] >> bit) & 1ull) << 3);
 			*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;
 			// gather 8 lanes' nibbles into one dword of the bit-packed row (lane l supplies bits 4(l%8)..)
-#ifndef EXP_NO_BITS
 			uint32_t v = nib;
 			v |= __shfl_down(v, 1) << 4;
 			v |= __shfl_down(v, 2) << 8;
 			v |= __shfl_down(v, 4) << 16;
 			if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
-#endif
 		}
 	}
 	// ---- bounding box + population count of the set bits (drives the LDS window of k_lsd) ----
