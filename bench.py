@@ -281,7 +281,7 @@ def main():
     if args.ingest_frames > 0 and world == 1:
         out["ingest"] = ingest_leg(smh, vision, fbs, frames_host.numpy(), anchors, args, W, H, n)
 
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and world == 1:
         from oracle import oracle as orc   # CPU baseline leg only (checker, never the product path)
         k = min(args.cpu_sample, n)
         cores = min(os.cpu_count() or 1, k)              # threads actually used: one frame per thread at a time

@@ -66,8 +66,14 @@ enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
 hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s);
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
+// k_lsd is three kernels, one per mask residency mode, each over all frames (a workgroup whose frame needs another mode
+// exits at once).  When the whole ROI fits the LDS window (<= 1080p) every frame is a ROWS frame and only that kernel is
+// launched; otherwise the three run concurrently on s, fk->s1 and fk->s2 (fork / join with the events), or back to back
+// on s when fk is null.
+struct LsdFork { hipStream_t s1, s2; hipEvent_t fork, join1, join2; };
+bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame: find_lines launches one kernel
 // mode 0: find_lines (whole frame); mode 1: one find_longest_line round from (px,py), result in results[f].lines[0], len^2 in length_px[0]
-hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s);
+hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk);
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);
 hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s);

@@ -491,6 +491,7 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 #define LSD_LIST_CAP 2048u
 #define LSD_QCAP 2048u
 #define LSD_QPT (LSD_QCAP / LSD_BS)                   // queue entries per thread in phase B
+#define LSD_CACHE_MARGIN 72                         // rows around a candidate kept in the GLOBAL mode's LDS row cache (pass 1 walks 64 samples)
 #define LSD_A_BATCHES 2u                            // 32-sample batches walked in phase A before a ray is queued
 #define LSD_WIN_WORDS_CAP 27400u                   // 1080p whole ROI in ROWS mode = 824 rows x 33 words + 4 = 27196 words;
 // the rest of the 160 KB holds the candidate list, the ray queue, LsdShared and the sector culling table (12.7 KB).
@@ -512,6 +513,11 @@ struct Win {
 	// LSD_MODE_ROWS only: whole (bit-realigned: bit x of a row = pixel x) rows of the window in LDS
 	const char *rows0;                // address of bit 0 of image row 0 (may lie before the buffer)
 	float ylo_f, yhi_f;               // the two zero border rows, as floats
+	// LSD_MODE_GLOBAL only: LDS copy of mask rows [c_y0, c_y0 + c_rows) in the global layout (same word columns);
+	// every read tries it first.  The rows around the candidates being cast are kept resident (lsd_frame), so only
+	// the long rays of phase B ever fall through to global memory.  c_rows == 0: no cache.
+	const uint32_t *c_p;
+	uint32_t c_y0, c_rows, c_pitch4;
 };
 
 // Mask residency modes of k_lsd, chosen per frame from the bounding box of the set bits:
@@ -520,28 +526,37 @@ struct Win {
 //          the two words in front of / behind the block absorb that; out-of-window rows are clamped (in
 //          the float domain, one v_med3_f32) onto the zero border rows.
 //   XWIN   bounding box (+ zero border) in LDS, coordinates clamped into it (narrow, tall boxes)
-//   GLOBAL the whole bit-packed mask in global memory (box larger than LDS)
+//   GLOBAL the whole bit-packed mask in global memory (box larger than LDS: 1440p, 4K), with a sliding cache of as
+//          many whole rows as LDS holds around the candidates in flight (they come in raster order)
 enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2 };
 
 // One sample.  Coordinates below/left of the window wrap to huge unsigned values and clamp to the far
 // (zero) border just like coordinates beyond it, so each axis costs one v_min_u32.  24-bit multiply:
 // rows * pitch4 < 2^24 for any supported frame.
+template <bool CACHED = false>
 __device__ __forceinline__ uint32_t win_raw(const Win &m, int xi, int yi) {   // bit 0 = the pixel, upper bits garbage
 	const uint32_t ry = min((uint32_t)(yi - m.y_lo), m.rows_hi);
 	const int X = xi + m.xbias;
 	const uint32_t rc = min((uint32_t)(X >> 5), m.cols_hi);
-	const char *row = (const char *)m.p + __umul24(ry, m.pitch4);
-	const uint32_t word = *(const uint32_t *)(row + (rc << 2));
+	uint32_t word;
+	const uint32_t cr = ry - m.c_y0;                       // GLOBAL: y_lo = 0, ry is the image row
+	if (CACHED && cr < m.c_rows) word = *(const uint32_t *)((const char *)m.c_p + __umul24(cr, m.c_pitch4) + (rc << 2));
+	else word = *(const uint32_t *)((const char *)m.p + __umul24(ry, m.pitch4) + (rc << 2));
 	return word >> ((uint32_t)X & 31u);
 }
-__device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) { return win_raw(m, xi, yi) & 1u; }
+// (not on the hot path: the cache test is a run-time one here)
+__device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) { return (m.c_rows ? win_raw<true>(m, xi, yi) : win_raw<false>(m, xi, yi)) & 1u; }
 
 // The 32 mask bits of word `wq` (in the view's own bit coordinate B = x + xbias) of image row yi; 0 outside the
 // window / image.  Works for all three residency modes (ROWS: xbias = 0).
 __device__ __forceinline__ uint32_t win_word(const Win &m, int wq, int yi) {
 	const uint32_t ry = (uint32_t)(yi - m.y_lo), rc = (uint32_t)wq;
 	uint32_t v = 0;
-	if (ry <= m.rows_hi && rc <= m.cols_hi) v = *(const uint32_t *)((const char *)m.p + __umul24(ry, m.pitch4) + (rc << 2));
+	if (ry <= m.rows_hi && rc <= m.cols_hi) {
+		const uint32_t cr = ry - m.c_y0;
+		if (cr < m.c_rows) v = *(const uint32_t *)((const char *)m.c_p + __umul24(cr, m.c_pitch4) + (rc << 2));
+		else v = *(const uint32_t *)((const char *)m.p + __umul24(ry, m.pitch4) + (rc << 2));
+	}
 	return v;
 }
 
@@ -612,7 +627,7 @@ __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float
 			x = xo + xs; y = yo + ys;                   // x = x_offset + x_start
 			// shifts in bit 0 of its first operand
 			if (MODE == LSD_MODE_ROWS) Wm = __builtin_amdgcn_alignbit(win_raw_rows(m, x, y), Wm, 1);
-			else Wm = __builtin_amdgcn_alignbit(win_raw(m, (int)x, (int)y), Wm, 1);
+			else Wm = __builtin_amdgcn_alignbit(win_raw<MODE == LSD_MODE_GLOBAL>(m, (int)x, (int)y), Wm, 1);
 			xo += dx; yo += dy;                         // x_offset += dx
 		}
 		taken += 8u;
@@ -995,6 +1010,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	Win m;
 	m.w = g.rw; m.h = g.rh; m.wf = (float)g.rw; m.hf = (float)g.rh;
 	m.rows0 = nullptr; m.ylo_f = 0.0f; m.yhi_f = 0.0f;
+	m.c_p = smem; m.c_y0 = 0u; m.c_rows = 0u; m.c_pitch4 = 0u;
 	uint32_t *list, *queue;
 	// compaction domain: wrows x wwords words; word (r, c) holds pixels x = xorg + 32 c + [0,32) of image row wy0 + r
 	uint32_t wy0, wrows, wwords;
@@ -1044,8 +1060,23 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		m.p = gbits; m.pitch4 = g.bits_pitch_w * 4u;
 		m.y_lo = 0; m.rows_hi = g.rh - 1u;
 		m.xbias = (int)g.m_xoff; m.cols_hi = g.bits_pitch_w - 1u;
-		list = smem;
+		list = smem + LSD_WIN_WORDS_CAP;
 	}
+	// GLOBAL: (re)load the row cache so that it covers rows [lo, hi] (a uniform decision; hi - lo < rows that fit)
+	const uint32_t c_pitch = g.bits_pitch_w | 1u, c_cap_rows = min(g.rh, LSD_WIN_WORDS_CAP / c_pitch);
+	auto cache_cover = [&](int lo, int hi) {
+		if (MODE != LSD_MODE_GLOBAL) return;
+		lo = max(lo, 0); hi = min(hi, (int)g.rh - 1);
+		if (m.c_rows && lo >= (int)m.c_y0 && hi < (int)(m.c_y0 + m.c_rows)) return;
+		__syncthreads();                                   // nobody still reads the old rows
+		const uint32_t y0 = (uint32_t)min(lo, (int)(g.rh - c_cap_rows));
+		for (uint32_t idx = tid; idx < c_cap_rows * c_pitch; idx += LSD_BS) {
+			const uint32_t r = idx / c_pitch, c = idx - r * c_pitch;
+			smem[idx] = c < g.bits_pitch_w ? gbits[(size_t)(y0 + r) * g.bits_pitch_w + c] : 0u;
+		}
+		m.c_y0 = y0; m.c_rows = c_cap_rows; m.c_pitch4 = c_pitch * 4u;
+		__syncthreads();
+	};
 	queue = list + LSD_LIST_CAP;
 	const uint32_t WT = wrows * wwords;   // word index wi -> row wi / wwords, column wi % wwords
 	__syncthreads();
@@ -1058,6 +1089,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 
 	if (mode == 1) {   // Vision::find_longest_line on an arbitrary point
 		if (tid < LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; }
+		cache_cover((int)spy - (int)(c_cap_rows / 2u), (int)spy - (int)(c_cap_rows / 2u) + (int)c_cap_rows - 1);
 		if (tid == 0) { sh.live[0] = ~0ull; sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
 		__syncthreads();
 		ray_engine<MODE>(m, sh, queue, 1u, max_gap, true PROF_ARG);
@@ -1135,7 +1167,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 #pragma unroll
 				for (int k = 0; k < LSD_NW; ++k) { const uint32_t s = sh.scan[k]; if ((uint32_t)k < wave) wp += s; tot += s; }
 				if (tot == 0u) break;
-				const uint32_t nc = min(tot, cmax);
+				uint32_t nc = min(tot, cmax);
 				uint32_t rank = wp + pin - pc;
 				while (surv && rank < cmax) {
 					const uint32_t bit = __builtin_ctz(surv);
@@ -1147,6 +1179,20 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; sh.live[tid] = cull ? 0ull : ~0ull; }
 				if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; }
 				__syncthreads();
+				if (MODE == LSD_MODE_GLOBAL) {
+					// Keep the mask rows every candidate of this group can reach in pass 1 (64 samples), the culling scan and
+					// get_centre inside the LDS row cache; candidates (in raster order) that would not fit are handed back.
+					auto cand_row = [&](uint32_t c) { return (int)(wy0 + list[cbase + (sh.cand_key[c] >> 5)] / wwords); };
+					const int lo = max(cand_row(0) - LSD_CACHE_MARGIN, 0);
+					uint32_t nce = 1;
+					while (nce < nc && cand_row(nce) + LSD_CACHE_MARGIN - lo < (int)c_cap_rows) ++nce;
+					for (uint32_t c = nce; c < nc; ++c) {
+						const uint32_t key = sh.cand_key[c];
+						if ((key >> 5) == tid) surv |= 1u << (key & 31u);
+					}
+					nc = nce;
+					cache_cover(lo, cand_row(nc - 1) + LSD_CACHE_MARGIN);
+				}
 				if (tid < nc * 32u) {
 					// get_centre (lsd.rs:5-44) of the nc integer pixel positions, 32 lanes per candidate: lane (dir, k)
 					// evaluates the k-th loop condition of direction dir (left, right, up, down); the walk length is the
@@ -1598,18 +1644,40 @@ hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 
 size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 
-hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s) {
+bool lsd_rows_only(const Geom &g) { return (g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP; }
+
+hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk) {
 	static bool attr_set = false;
-	const unsigned lds_full = LSD_DYN_LDS_BYTES, lds_global = (LSD_LIST_CAP + 2u * LSD_QCAP) * 4u;
+	const unsigned lds_full = LSD_DYN_LDS_BYTES;
 	if (!attr_set) {
 		hipError_t e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_GLOBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
+	// every non-empty frame of this size is a ROWS frame (lsd_mode_for): the other two kernels would only exit
+	const bool rows_only = mode == 0 && lsd_rows_only(g);
+	hipStream_t s1 = s, s2 = s;
+	if (!rows_only && fk) {
+		hipError_t e = hipEventRecord(fk->fork, s);
+		if (e == hipSuccess) e = hipStreamWaitEvent(fk->s1, fk->fork, 0);
+		if (e == hipSuccess) e = hipStreamWaitEvent(fk->s2, fk->fork, 0);
+		if (e != hipSuccess) return e;
+		s1 = fk->s1; s2 = fk->s2;
+	}
 	hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py);
-	hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py);
-	hipLaunchKernelGGL(k_lsd<LSD_MODE_GLOBAL>, dim3(n), dim3(LSD_BS), lds_global, s, g, b, max_gap, mode, px, py);
+	if (!rows_only) {
+		hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py);
+		hipLaunchKernelGGL(k_lsd<LSD_MODE_GLOBAL>, dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py);
+		if (fk) {
+			hipError_t e = hipEventRecord(fk->join1, s1);
+			if (e == hipSuccess) e = hipEventRecord(fk->join2, s2);
+			if (e == hipSuccess) e = hipStreamWaitEvent(s, fk->join1, 0);
+			if (e == hipSuccess) e = hipStreamWaitEvent(s, fk->join2, 0);
+			if (e != hipSuccess) return e;
+		}
+	}
 	return hipGetLastError();
 }
 

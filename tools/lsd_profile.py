@@ -6,7 +6,8 @@ import numpy as np, torch
 import squad_mortar_helper_amd as smh
 from squad_mortar_helper_amd import synth
 
-W, H, N = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
 _, infos = synth.make_batch(W, H, N, out=host.numpy())
 d = host.cuda()
