@@ -1,5 +1,5 @@
 // smh_kernels.h -- launch interface between the host runtime (smh_runtime.cpp) and the gfx950
-// kernels (smh_kernels.hip).  Internal; the public boundary is include/smh_vision_hip.h.
+// kernels (smh_stream.hip, smh_lsd.hip, smh_misc.hip).  Internal; the public boundary is include/smh_vision_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,454 +1,14 @@
-// smh_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the squad-mortar-helper vision
-// hot path.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
+// smh_lsd.hip -- k_lsd: lsd::find_lines::<32> incl. find_longest_line, one workgroup per frame (gfx950, wave64):
+// speculative candidate groups, sector culling, batched ray walking, mask window resident in LDS
+// (vision-common/src/lsd.rs:5-107, vision-cpu/src/lib.rs:387-449); k_build_sector_table.
+//
+// Build with -ffp-contract=off and correctly rounded f32 division: several results are truncated to integers
+// right at a threshold, so the reference's scalar f32 operation order (no FMA contraction, IEEE divide) is
+// part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
 // structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
-//
-// Build with -ffp-contract=off and correctly rounded f32 division: several results are
-// truncated to integers right at a threshold, so the reference's scalar f32 operation order
-// (no FMA contraction, IEEE divide) is part of the contract.
-//
-// Kernels
-//   k_button      red "Close Deployment" pixel count -> map_open           (lib.rs:116-133)
-//   k_map_pass    one streaming pass over the map ROI: ui_map RGBA + marker colour predicate +
-//                 L1 radius-1 dilation -> u8 mask + bit-packed mask + bbox   (lib.rs:137-171,253-280,357-375)
-//   k_brq_pass    bottom-right quadrant: ocr_preprocess + find_scales_preprocess (lib.rs:173-251)
-//   k_lsd         lsd::find_lines::<32> incl. find_longest_line, one workgroup per frame, speculative
-//                 candidate groups, batched ray walking,
-//                 mask window resident in LDS                                (lsd.rs:5-107, lib.rs:387-449)
-//   k_scale_ratio calc_meters_to_px_ratio / find_scale_width                 (src/vision/mpx_ratio.rs:3-134)
-//   k_find_minimap find_minimap (the caller's next step)                      (src/vision/find_minimap.rs)
-//   k_finalize    derived marker outputs                                     (src/ui/mod.rs:131-140, markers.rs:98)
-#include "smh_kernels.h"
-#include "smh_consts.h"
+#include "smh_device.h"
 
 namespace smh {
-
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-// Rust `f32 as u32`: truncate toward zero, saturate, NaN -> 0.
-__device__ __forceinline__ uint32_t f2u(float v) {
-	return (v >= 0.0f) ? ((v >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t)v) : 0u;
-}
-
-// image 0.23.14 rgb_to_luma: (0.2126 r + 0.7152 g) + 0.0722 b in f32, truncated to u8.
-__device__ __forceinline__ uint32_t luma8(uint32_t r, uint32_t g, uint32_t b) {
-	float l = SMH_LUMA_R * (float)r + SMH_LUMA_G * (float)g + SMH_LUMA_B * (float)b;
-	uint32_t u = (uint32_t)l;   // l is in [0, 255.0001]
-	return u > 255u ? 255u : u;
-}
-
-__device__ __forceinline__ uint32_t absdiff(uint32_t a, uint32_t b) { return a > b ? a - b : b - a; }
-
-// util/src/image.rs:159-187 hsv() + vision-common/src/markers/mod.rs:17-19,40-54, evaluated exactly
-// as the reference does (f32, same operation order).  Two identities remove the fmodf calls:
-//   ((g-b)/delta) % 6.0   : |(g-b)/delta| <= 1 < 6, so fmodf returns its argument unchanged;
-//   modulo(h, 360.0)      : h is in [-60, 300], so fmodf(h,360) == h and only the `+ 360` applies.
-// tests/test_gpu_parity.py checks the device predicate against the oracle on all 2^24 colours.
-__device__ bool marker_exact(uint32_t r8, uint32_t g8, uint32_t b8) {
-	const float r = (float)r8 / 255.0f, g = (float)g8 / 255.0f, b = (float)b8 / 255.0f;
-	const float mx = fmaxf(r, fmaxf(g, b));
-	const float mn = fminf(r, fminf(g, b));
-	const float delta = mx - mn;
-	float h;
-	if (mx == mn) h = 0.0f;
-	else if (mx == r) h = 60.0f * ((g - b) / delta);
-	else if (mx == g) h = 60.0f * (((b - r) / delta) + 2.0f);
-	else h = 60.0f * (((r - g) / delta) + 4.0f);
-	if (h < 0.0f) h = h + 360.0f;
-	const float sf = (100.0f * delta) / mx;     // NaN when mx == 0 -> 0
-	const float vf = 100.0f * mx;
-	const uint32_t hu = f2u(h);
-	uint32_t su = f2u(sf); su = su > 255u ? 255u : su;
-	uint32_t vu = f2u(vf); vu = vu > 255u ? 255u : vu;
-	if (su < SMH_HSV_MIN_SAT) return false;
-	bool any = false;
-#define SMH_TEAM(MH, MS, MV)                                                                              \
-	any = any || (absdiff(MH, hu) <= SMH_HSV_HUE_TOLERANCE &&                                             \
-	              (absdiff(MS, su) <= SMH_HSV_SAT_TOLERANCE ||                                            \
-	               (uint32_t)abs((int)su - ((int)(MS) - SMH_PLAYER_DIR_ARC_SAT)) <= SMH_HSV_SAT_TOLERANCE) && \
-	              absdiff(MV, vu) <= SMH_HSV_VIB_TOLERANCE)
-	SMH_TEAM(SMH_ALPHA_H, SMH_ALPHA_S, SMH_ALPHA_V);
-	SMH_TEAM(SMH_BRAVO_H, SMH_BRAVO_S, SMH_BRAVO_V);
-	SMH_TEAM(SMH_CHARLIE_H, SMH_CHARLIE_S, SMH_CHARLIE_V);
-#undef SMH_TEAM
-	return any;
-}
-
-// Cheap integer necessary condition in front of the exact float path (most map terrain fails it,
-// so whole waves skip the divisions):  s >= 35 needs 100*d/m >= 34.99 (the f32 result is within
-// 1e-4 of the rational), and every team window needs v >= 70, i.e. max channel >= 178.
-__device__ __forceinline__ bool marker_prefilter(uint32_t bgra) {
-	const uint32_t b8 = bgra & 255u, g8 = (bgra >> 8) & 255u, r8 = (bgra >> 16) & 255u;
-	const uint32_t m = max(r8, max(g8, b8)), n = min(r8, min(g8, b8)), d = m - n;
-	return (uint32_t)(m >= 178u) & (uint32_t)(d * 10000u >= 3499u * m);
-}
-__device__ __forceinline__ bool is_marker(uint32_t r8, uint32_t g8, uint32_t b8) {
-	bool res = false;
-	if (marker_prefilter(b8 | (g8 << 8) | (r8 << 16))) res = marker_exact(r8, g8, b8);
-	return res;
-}
-
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-	for (int o = 32; o; o >>= 1) v |= __shfl_xor(v, o);
-	return v;
-}
-__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
-	for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-	return v;
-}
-__device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
-	for (int o = 32; o; o >>= 1) { uint64_t t = __shfl_xor(v, o); v = t > v ? t : v; }
-	return v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_button: one workgroup per frame.  Also resets the per-frame scratch for the later passes.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_open) {
-	const uint32_t f = blockIdx.x;
-	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes;
-	__shared__ uint32_t s_cnt;
-	if (threadIdx.x == 0) s_cnt = 0;
-	__syncthreads();
-	uint32_t cnt = 0;
-	const uint32_t npx = g.bw * g.bh;
-	for (uint32_t i = threadIdx.x; i < npx; i += blockDim.x) {
-		const uint32_t y = i / g.bw, x = i - y * g.bw;
-		const uint32_t p = *(const uint32_t *)(fp + ((size_t)(g.by + y) * g.W + g.bx + x) * 4);   // B | G<<8 | R<<16 | A<<24
-		const uint32_t bb = p & 255u, gg = (p >> 8) & 255u, rr = (p >> 16) & 255u;
-		cnt += (absdiff(SMH_BUTTON_R, rr) <= SMH_BUTTON_TOLERANCE && absdiff(SMH_BUTTON_G, gg) <= SMH_BUTTON_TOLERANCE &&
-		        absdiff(SMH_BUTTON_B, bb) <= SMH_BUTTON_TOLERANCE) ? 1u : 0u;
-	}
-	cnt = wave_sum32(cnt);
-	if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, cnt);
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		const uint32_t red = s_cnt;
-		// `red_pixels as f32 / (w * h) as f32 < 0.65` => Ok(None)   (vision-cpu/src/lib.rs:130-133)
-		const float ratio = (float)red / (float)npx;
-		FrameAux a;
-		a.open = (force_open || !(ratio < SMH_BUTTON_RED_PIXEL_THRESHOLD)) ? 1u : 0u;
-		a.red = red; a.n_mask_px = 0;
-		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.pad = 0;
-		b.aux[f] = a;
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_map_pass
-//
-// grid = (row bands, frames); block = one thread per quad (4 pixels, 16-byte BGRA load) across the
-// whole ROI width, so the waves of a workgroup sit side by side on the same rows.
-// Each thread marches down its quad column over the band's rows (+1 halo row above and below) and
-// keeps the marker predicate as four 64-bit column masks (bit = row).  In that form
-//   vertical dilation   = p | p<<1 | p>>1            (all rows of the band at once)
-//   horizontal dilation = neighbouring column masks  (own registers, lane+-1 via DPP shuffles,
-//                                                      wave edges via 16 B of LDS per wave)
-// so the 3x3-cross dilation of the reference (imageproc dilate_mut(L1,1)) costs a dozen
-// instructions per band instead of a second pass over an intermediate image.  ui_map is written
-// straight from the loaded registers; the frame is read exactly once (+2 halo rows per band).
-// ------------------------------------------------------------------------------------------------
-#define MAP_RB_MAX 62
-
-template <bool GRAY>
-__global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t flags, uint32_t RB) {
-	const uint32_t f = blockIdx.y;
-	if (!b.aux[f].open) return;
-	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
-	const int r0 = (int)(blockIdx.x * RB);
-	const int r1 = min(r0 + (int)RB, (int)g.rh);
-	const bool qact = q < g.m_quads;
-	uint32_t vmask = 0;
-#pragma unroll
-	for (int c = 0; c < 4; ++c)
-		if ((uint32_t)(4 * q + c - g.m_xoff) < g.rw) vmask |= 1u << c;
-	if (!qact) vmask = 0;
-
-	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax + 4 * q) * 4;
-	uint8_t *uip = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
-	const size_t row_bytes = (size_t)g.W * 4;
-
-	uint64_t P[4] = {0, 0, 0, 0};
-	const int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
-	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
-
-	// Software pipeline: the loads of the next four rows are issued before the current four are
-	// processed, so they fly under the compute and the stores (vmcnt is in-order: a load issued after
-	// the stores would also wait for them).  Inactive lanes re-read quad 0 (no divergent load).
-	const uint8_t *lp = qact ? fp : fp - (size_t)q * 16;
-	uint4 nx[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
-	__shared__ uint32_t s_hit_px[16][64], s_hit_res[16][64];
-	__shared__ unsigned short s_hit_id[16][64];
-	for (int r = rs; r <= re; r += 4) {
-		uint4 px[4];
-		uint32_t prehits = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) px[k] = nx[k];
-		if (r + 4 <= re) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(r + 4 + k, re) * row_bytes);
-		}
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int row = r + k;
-			if (row > re) break;
-			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
-			if (do_ui && row >= r0 && row < r1 && qact) {
-				uint4 o;
-				uint32_t ov[4];
-#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
-					if (GRAY) ov[c] = luma8(rr8, gg, bb) * 0x00010101u | 0xFF000000u;   // Bgra::to_luma -> (l,l,l,255)
-					else ov[c] = rr8 | (gg << 8) | (bb << 16) | 0xFF000000u;           // (r,g,b,255)
-				}
-				o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
-				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
-			}
-			if (do_mask) {
-				// branch-free integer pre-filter; hits of the four rows are collected (bit 4k+c)
-				uint32_t pre = 0;
-#pragma unroll
-				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
-				prehits |= (pre & vmask) << (4 * k);
-			}
-		}
-		// ---- exact f32 HSV test for the pre-filter hits of this wave, one hit per lane ----
-		// A marker line crosses most rows of a band but only a few pixels of each, so testing hits where
-		// they sit would run the (long, divergent) exact test several times per row for two or three
-		// active lanes.  Instead the hit pixels of the whole wave and of all four rows are compacted into
-		// a 64-entry LDS list, every lane tests one of them, and the verdicts are scattered back with
-		// LDS atomic ORs.  (This path used to be 40 % of the kernel's time.)
-		if (do_mask && __any(prehits != 0u)) {
-			uint32_t *hpx = s_hit_px[wave];
-			uint32_t *hres = s_hit_res[wave];
-			unsigned short *hid = s_hit_id[wave];
-			const uint32_t cnt = (uint32_t)__popc(prehits);
-			uint32_t incl = cnt;
-			for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
-			const uint32_t total = __shfl(incl, 63);
-			const uint32_t off = incl - cnt;
-			hres[lane] = 0u;
-			for (uint32_t base = 0; base < total; base += 64u) {
-				uint32_t o = off - base;                           // may wrap: compared unsigned below
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const uint32_t pk[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
-#pragma unroll
-					for (int c = 0; c < 4; ++c)
-						if ((prehits >> (4 * k + c)) & 1u) {
-							if (o < 64u) { hpx[o] = pk[c]; hid[o] = (unsigned short)((lane << 4) | (uint32_t)(4 * k + c)); }
-							++o;
-						}
-				}
-				__builtin_amdgcn_wave_barrier();
-				const uint32_t e = base + lane;
-				if (e < total) {
-					const uint32_t p = hpx[lane];
-					if (marker_exact((p >> 16) & 255u, (p >> 8) & 255u, p & 255u)) {
-						const uint32_t id = hid[lane];
-						atomicOr(&hres[id >> 4], 1u << (id & 15u));
-					}
-				}
-				__builtin_amdgcn_wave_barrier();
-			}
-			const uint32_t res = hres[lane];                       // bit 4k+c: pixel c of row r+k is a marker colour
-			if (res) {
-				const int sh = r - (r0 - 1);
-#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					uint32_t y = (res >> c) & 0x1111u;                 // rows k = 0..3 at bits 0,4,8,12
-					y = (y | (y >> 3) | (y >> 6) | (y >> 9)) & 0xFu;   // -> bits 0..3
-					P[c] |= (uint64_t)y << sh;
-				}
-			}
-		}
-	}
-	if (!do_mask) return;
-
-	// ---- dilation on the column masks ----
-	__shared__ uint64_t s_edge_first[16], s_edge_last[16];
-	if (lane == 0) s_edge_first[wave] = P[0];
-	if (lane == 63) s_edge_last[wave] = P[3];
-	__syncthreads();
-	uint64_t left = __shfl_up(P[3], 1), right = __shfl_down(P[0], 1);
-	if (lane == 0) left = wave > 0 ? s_edge_last[wave - 1] : 0ull;
-	if (lane == 63) right = wave + 1 < nwave ? s_edge_first[wave + 1] : 0ull;
-	const int nrows = r1 - r0;
-	const uint64_t rowmask = ((nrows >= 63 ? ~0ull : ((1ull << nrows) - 1ull)) << 1);   // bits 1..nrows
-	uint64_t D[4];
-#define SMH_VERT(p) ((p) | ((p) << 1) | ((p) >> 1))
-	D[0] = SMH_VERT(P[0]) | left | P[1];
-	D[1] = SMH_VERT(P[1]) | P[0] | P[2];
-	D[2] = SMH_VERT(P[2]) | P[1] | P[3];
-	D[3] = SMH_VERT(P[3]) | P[2] | right;
-#undef SMH_VERT
-#pragma unroll
-	for (int c = 0; c < 4; ++c) D[c] = ((vmask >> c) & 1u) ? (D[c] & rowmask) : 0ull;
-
-	// ---- outputs: u8 mask rows and bit-packed rows ----
-	const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
-	if (q < quads_padded) {
-		uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
-		uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
-		for (int row = r0; row < r1; ++row) {
-			const int bit = row - r0 + 1;
-			const uint32_t nib = (uint32_t)((D[0] >> bit) & 1ull) | ((uint32_t)((D[1] >> bit) & 1ull) << 1) |
-			                     ((uint32_t)((D[2] >> bit) & 1ull) << 2) | ((uint32_t)((D[3] >> bit) & 1ull) << 3);
-			*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;
-			// gather 8 lanes' nibbles into one dword of the bit-packed row (lane l supplies bits 4(l%8)..)
-			uint32_t v = nib;
-			v |= __shfl_down(v, 1) << 4;
-			v |= __shfl_down(v, 2) << 8;
-			v |= __shfl_down(v, 4) << 16;
-			if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
-		}
-	}
-	// ---- bounding box + population count of the set bits (drives the LDS window of k_lsd) ----
-	const uint64_t any = D[0] | D[1] | D[2] | D[3];
-	const uint64_t lanes_set = __ballot(any != 0ull);
-	if (lanes_set) {
-		const uint64_t rows_set = wave_or64(any);
-		const uint32_t cnt = wave_sum32(__popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]));
-		if (lane == 0) {
-			FrameAux *a = &b.aux[f];
-			atomicMin(&a->y_min, (uint32_t)(r0 - 1 + __builtin_ctzll(rows_set)));
-			atomicMax(&a->y_max, (uint32_t)(r0 - 1 + 63 - __builtin_clzll(rows_set)));
-			atomicMin(&a->w_min, (wave * 64u + (uint32_t)__builtin_ctzll(lanes_set)) >> 3);
-			atomicMax(&a->w_max, (wave * 64u + 63u - (uint32_t)__builtin_clzll(lanes_set)) >> 3);
-			atomicAdd(&a->n_mask_px, cnt);
-		}
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_brq_pass: ocr_preprocess (lib.rs:173-231) + find_scales_preprocess (lib.rs:233-251) over the
-// bottom-right quadrant, same column-mask technique with a 3-row halo.
-//   monochromaticy = sum over ordered pairs |ci-cj| = 4*(max-min)
-//     "<= 3"  <=> r == g == b            "<= 48" <=> max-min <= 12
-//   keep(x,y) = W(x,y) || (E(x,y) && exists W in [x-3, min(x+3, w-3)] x [y-3, min(y+3, h-3)])
-//     W = r==g==b && all >= 200,  E = max-min <= 12 && all >= 130
-// ------------------------------------------------------------------------------------------------
-#define BRQ_RB 58
-
-__global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start) {
-	const uint32_t f = blockIdx.y;
-	if (!b.aux[f].open) return;
-	uint32_t start_y = fixed_start_y;
-	bool do_scales = (flags & BRQ_SCALES) != 0;
-	if (use_anchor_start) {
-		const smhv_anchors an = b.anchors[f];
-		start_y = an.scales_start_y;
-		// src/vision/mod.rs:196-198: no labels => the scales branch returns before find_scales_preprocess
-		if (an.n == 0 || start_y > g.qh) do_scales = false;
-	}
-	const bool do_ocr = (flags & BRQ_OCR) != 0;
-	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
-	const int r0 = (int)(blockIdx.x * BRQ_RB);
-	const int r1 = min(r0 + BRQ_RB, (int)g.qh);
-	const bool qact = q < g.q_quads;
-	uint32_t vmask = 0, wmask = 0;   // valid pixel / pixel allowed as a "white neighbour" (x <= w-3)
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		const uint32_t x = 4 * q + c - g.q_xoff;
-		if (x < g.qw) vmask |= 1u << c;
-		if (x + SMH_OCR_DILATE_RADIUS <= g.qw) wmask |= 1u << c;   // x <= w - 3
-	}
-	if (!qact) { vmask = 0; wmask = 0; }
-	wmask &= vmask;
-
-	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.qy * g.W + g.q_ax + 4 * q) * 4;
-	const size_t row_bytes = (size_t)g.W * 4;
-	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride + (size_t)q * 4;
-	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride + (size_t)q * 4;
-
-	uint64_t Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
-	const int rs = max(r0 - 3, 0), re = min(r1 + 2, (int)g.qh - 1);
-	for (int r = rs; r <= re; r += 4) {
-		uint4 px[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int rr = min(r + k, re);
-			px[k] = qact ? *(const uint4 *)(fp + (size_t)rr * row_bytes) : make_uint4(0, 0, 0, 0);
-		}
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int row = r + k;
-			if (row > re) break;
-			const int bit = row - (r0 - 3);
-			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
-			const bool out_row = row >= r0 && row < r1;
-			const bool nb_row = (uint32_t)row + SMH_OCR_DILATE_RADIUS <= g.qh;   // y <= h - 3
-			uint32_t ocr_w = 0, sc_w = 0;
-#pragma unroll
-			for (int c = 0; c < 4; ++c) {
-				const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
-				const uint32_t mx = max(rr8, max(gg, bb)), mn = min(rr8, min(gg, bb));
-				const bool w = (mx == mn) && mn >= SMH_OCR_BRIGHTNESS_THRESHOLD;
-				const bool e = (4u * (mx - mn) <= SMH_OCR_SIMILARITY_EDGE_THRESHOLD) && mn >= SMH_OCR_BRIGHTNESS_EDGE_THRESHOLD && !w;
-				const bool valid = (vmask >> c) & 1u;
-				Wb[c] |= (uint64_t)((w && nb_row && ((wmask >> c) & 1u)) ? 1u : 0u) << bit;
-				Eb[c] |= (uint64_t)((e && valid && out_row) ? 1u : 0u) << bit;
-				const uint32_t l = luma8(rr8, gg, bb);
-				ocr_w |= ((w && valid) ? (255u - l) : 255u) << (8 * c);
-				sc_w |= (l != 0u ? 255u : 0u) << (8 * c);
-			}
-			if (out_row && qact) {
-				if (do_ocr) *(uint32_t *)(op + (size_t)row * g.ocr_pitch) = ocr_w;
-				if (do_scales && (uint32_t)row >= start_y) *(uint32_t *)(sp + (size_t)row * g.ocr_pitch) = sc_w;
-			}
-		}
-	}
-	if (!do_ocr) return;
-
-	// ---- 7x7 "white neighbour" dilation on the column masks ----
-	uint64_t V[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		const uint64_t w = Wb[c];
-		V[c] = w | (w << 1) | (w << 2) | (w << 3) | (w >> 1) | (w >> 2) | (w >> 3);
-	}
-	__shared__ uint64_t s_first[16][4], s_last[16][4];
-	if (lane == 0) { s_first[wave][0] = V[0]; s_first[wave][1] = V[1]; s_first[wave][2] = V[2]; s_first[wave][3] = V[3]; }
-	if (lane == 63) { s_last[wave][0] = V[0]; s_last[wave][1] = V[1]; s_last[wave][2] = V[2]; s_last[wave][3] = V[3]; }
-	__syncthreads();
-	uint64_t X[12];   // columns -4..7 relative to this quad
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		uint64_t l = __shfl_up(V[c], 1), r = __shfl_down(V[c], 1);
-		if (lane == 0) l = wave > 0 ? s_last[wave - 1][c] : 0ull;
-		if (lane == 63) r = wave + 1 < nwave ? s_first[wave + 1][c] : 0ull;
-		X[c] = l; X[4 + c] = V[c]; X[8 + c] = r;
-	}
-	bool any_patch = false;
-	uint64_t K[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		uint64_t d = 0;
-#pragma unroll
-		for (int k = -3; k <= 3; ++k) d |= X[4 + c + k];
-		K[c] = Eb[c] & d;
-		any_patch = any_patch || K[c] != 0ull;
-	}
-	// Pixels kept only because of a white neighbour are rare (anti-aliased glyph edges): re-read
-	// just those pixels for their luma and patch the byte written above (same thread => ordered).
-	if (any_patch) {
-#pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			uint64_t k = K[c];
-			while (k) {
-				const int bit = __builtin_ctzll(k);
-				k &= k - 1;
-				const int row = r0 - 3 + bit;
-				const uint32_t p = *(const uint32_t *)(fp + (size_t)row * row_bytes + 4 * c);
-				const uint32_t l = luma8((p >> 16) & 255u, (p >> 8) & 255u, p & 255u);
-				op[(size_t)row * g.ocr_pitch + c] = (uint8_t)(255u - l);
-			}
-		}
-	}
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_lsd: lsd::find_lines::<32> (vision-common/src/lsd.rs:60-107) with find_longest_line
@@ -776,34 +336,6 @@ struct LsdShared {
 	unsigned long long live[LSD_C];          // units (64-ray sectors) of each candidate that have to be cast
 	float lines[SMH_LSD_MAX_LINES][4];
 };
-
-// Wave-wide reductions on DPP lane permutes (no LDS round trips): butterflies inside each 16-lane row,
-// then the four row results are combined on the scalar unit.  All 64 lanes must be active.
-#define SMH_DPP(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))
-__device__ __forceinline__ uint32_t wave_max32_dpp(uint32_t v) {
-	v = max(v, SMH_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
-	v = max(v, SMH_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
-	v = max(v, SMH_DPP(v, 0x141));   // row_half_mirror
-	v = max(v, SMH_DPP(v, 0x140));   // row_mirror
-	return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
-	           max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
-}
-__device__ __forceinline__ uint32_t wave_or32_dpp(uint32_t v) {
-	v |= SMH_DPP(v, 0xB1);
-	v |= SMH_DPP(v, 0x4E);
-	v |= SMH_DPP(v, 0x141);
-	v |= SMH_DPP(v, 0x140);
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
-	       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
-__device__ __forceinline__ uint32_t wave_sum32_dpp(uint32_t v) {
-	v += SMH_DPP(v, 0xB1);
-	v += SMH_DPP(v, 0x4E);
-	v += SMH_DPP(v, 0x141);
-	v += SMH_DPP(v, 0x140);
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
-	       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
 
 // find_longest_line for nc candidates at once (start points in sh.cand_pt).  On return (after a
 // barrier) sh.cand_best / cand_end / cand_steps hold, per candidate, the winning key, its end point
@@ -1379,269 +911,8 @@ __global__ void k_build_sector_table(unsigned long long *tab, uint32_t T) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scale_ratio: src/vision/mpx_ratio.rs.  One wave per OCR label anchor (<= 3 per frame).  The scan
-// order of the reference is kept (rows downwards from the anchor; first tick column to the right,
-// then to the left), but each "first column whose 4 pixels below are all 0" search tests 64 columns
-// per step and takes the first hit with a ballot.  Pixels below the image count as non-zero
-// (reference: unchecked read).
-// ------------------------------------------------------------------------------------------------
-__device__ bool find_scale_width(const uint8_t *img, size_t pitch, uint32_t w, uint32_t h, uint32_t meters, uint32_t x, uint32_t y, double *ratio,
-                                 uint32_t bar[3]) {
-	const uint32_t lane = threadIdx.x & 63u;
-	if (y < SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT || x >= w) return false;
-	// ((20.0 / 640.0) * w as f64).round(): 0.03125*w has at most 5 fractional bits, so t + 0.5 is exact
-	// and floor(t + 0.5) is round-half-away-from-zero for t >= 0
-	const double t = (20.0 / 640.0) * (double)w;
-	const uint32_t max_off = (uint32_t)floor(t + 0.5);
-	const uint32_t y_end = min(h, y + max_off);
-	auto tick = [&](uint32_t xx, uint32_t yy) -> bool {    // rows yy..yy+3 of column xx all 0
-		bool all0 = true;
-		for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty) all0 = all0 && ty < h && img[(size_t)ty * pitch + xx] == 0;
-		return all0;
-	};
-	for (uint32_t yy = y; yy < y_end; ++yy) {
-		if (img[(size_t)yy * pitch + x] != 0) continue;      // wave-uniform
-		uint32_t right = 0;
-		for (uint32_t base = x; base < w; base += 64u) {     // Go right...
-			const uint32_t xx = base + lane;
-			const uint64_t hit = __ballot(xx < w && tick(xx, yy));
-			if (hit) { right = base + (uint32_t)__builtin_ctzll(hit); break; }
-		}
-		if (right == 0) continue;
-		right -= 1;
-		uint32_t left = 0;
-		bool found = false;
-		for (uint32_t base = 0; base < x; base += 64u) {     // Go left... (columns x-1, x-2, ...)
-			const uint32_t off = base + lane;
-			const uint64_t hit = __ballot(off < x && tick(x - 1u - off, yy));
-			if (hit) { left = x - 1u - (base + (uint32_t)__builtin_ctzll(hit)); found = true; break; }
-		}
-		(void)found;
-		if (left == 0) continue;
-		left += 1;
-		const uint32_t width = right - left;   // wraps like release Rust (mpx_ratio.rs:58)
-		if (width < SMH_MIN_SCALE_WIDTH) continue;
-		bar[0] = left; bar[1] = yy; bar[2] = right;
-		*ratio = (double)meters / (double)width;
-		return true;
-	}
-	return false;
-}
-
-__global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) {
-	const uint32_t f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	__shared__ double s_ratio[SMHV_MAX_SCALES];
-	__shared__ uint32_t s_ok[SMHV_MAX_SCALES];
-	smhv_frame_result *res = &b.results[f];
-	const bool open = b.aux[f].open != 0;
-	const smhv_anchors an = b.anchors[f];
-	const uint32_t n = open ? min(an.n, (uint32_t)SMHV_MAX_SCALES) : 0u;
-	const bool valid = an.scales_start_y <= g.qh;
-	{
-		double r = 0.0;
-		uint32_t bar[3] = {0, 0, 0};
-		bool ok = false;
-		if (wave < n && valid) {                               // wave-uniform
-			const uint8_t *img = b.scales + (size_t)f * g.ocr_stride + g.q_xoff;
-			ok = find_scale_width(img, g.ocr_pitch, g.qw, g.qh, an.scales[wave][0], an.scales[wave][1], an.scales[wave][2], &r, bar);
-		}
-		if (lane == 0) {
-			s_ratio[wave] = r; s_ok[wave] = ok ? 1u : 0u;
-			if (bars) {
-				uint32_t *o = bars + ((size_t)f * SMHV_MAX_SCALES + wave) * 4;
-				o[0] = bar[0]; o[1] = bar[1]; o[2] = bar[2]; o[3] = ok ? 1u : 0u;
-			}
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		// the "Rayon ladder" (mpx_ratio.rs:93-125): mean of the successes, summed in index order
-		double sum = 0.0; uint32_t k = 0;
-		for (uint32_t i = 0; i < SMHV_MAX_SCALES; ++i)
-			if (s_ok[i]) { sum = k ? sum + s_ratio[i] : s_ratio[i]; ++k; }
-		res->has_mpx = k ? 1u : 0u;
-		res->mpx = k == 0 ? 0.0 : (k == 1 ? sum : sum / (double)k);
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_find_minimap: src/vision/find_minimap.rs (the caller's step right after crop_to_map).
-// One wave per direction (Left, Right, Up, Down), four waves per frame.  The reference walks pixel by
-// pixel from the ROI centre and, at every pixel whose "edginess" is <= 0.01, tries a perpendicular run of
-// min_line_length equally flat pixels.  Here 64 steps of the main walk are tested at once (ballot, handled
-// in walk order) and the perpendicular run is tested 64 pixels per step; the result is the reference's.
-// edginess = max over the 8 neighbours of |dB|+|dG|+|dR|, as f32 / 765.0 <= 0.01  <=>  that max <= 7
-// (7/765 = 0.00915, 8/765 = 0.01046).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool flat_pixel(const uint8_t *roi0, uint32_t W, uint32_t x, uint32_t y) {
-	const uint32_t *p = (const uint32_t *)(roi0 + ((size_t)y * W + x) * 4);
-	const int Wi = (int)W;
-	const uint32_t c = p[0] & 0x00FFFFFFu;
-	uint32_t mx = 0;
-#pragma unroll
-	for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-		for (int dx = -1; dx <= 1; ++dx)
-			if (dx != 0 || dy != 0) mx = max(mx, (uint32_t)__builtin_amdgcn_sad_u8(c, p[dy * Wi + dx] & 0x00FFFFFFu, 0u));
-	return (float)mx / 765.0f <= 0.01f;
-}
-
-__device__ uint32_t find_edge(const uint8_t *roi0, uint32_t W, uint32_t w, uint32_t h, uint32_t x0, uint32_t y0, int dir) {
-	const uint32_t lane = threadIdx.x & 63u;
-	const bool vertical = dir < 2;                         // Up, Down move y; Left, Right move x
-	uint32_t c_max = vertical ? h : w, oc_max = vertical ? w : h;
-	const int cod = (dir == 0 || dir == 2) ? -1 : 1;
-	const uint32_t c0 = vertical ? y0 : x0, oc0 = vertical ? x0 : y0;
-	const uint32_t d = oc_max > oc0 ? oc_max - oc0 : oc0 - oc_max;
-	const uint32_t mll = d / 2u - 1u;                      // min_line_length (wraps like release Rust; >= 0 for dims >= 3)
-	c_max -= 3u; oc_max -= 3u;
-	uint32_t cbase = c0;
-	for (;;) {
-		const uint32_t cc = (uint32_t)((int32_t)cbase + cod * (int32_t)(lane + 1u));
-		const int st = cc > c_max ? 1 : (cc < 3u ? 2 : 0);     // order of the reference's two tests
-		bool low = false;
-		if (st == 0) low = flat_pixel(roi0, W, vertical ? oc0 : cc, vertical ? cc : oc0);
-		const uint64_t term = __ballot(st != 0);
-		uint64_t lows = __ballot(low);
-		for (;;) {
-			const uint64_t both = term | lows;
-			if (!both) break;
-			const uint32_t first = (uint32_t)__builtin_ctzll(both);
-			const uint32_t fc = (uint32_t)((int32_t)cbase + cod * (int32_t)(first + 1u));
-			if ((term >> first) & 1ull) return fc > c_max ? c_max + 2u : 0u;
-			// a flat pixel: "try and find a straight line of pixels that are also under the edginess threshold"
-			bool ok = true;
-			for (uint32_t kb = 0; kb < mll && ok; kb += 64u) {
-				const uint32_t k = kb + lane + 1u;
-				bool good = true;
-				if (k <= mll) {
-					const uint32_t oc = (uint32_t)((int32_t)oc0 - cod * (int32_t)k);
-					good = !(oc < 3u || oc > oc_max) && flat_pixel(roi0, W, vertical ? oc : fc, vertical ? fc : oc);
-				}
-				ok = __all(good);
-			}
-			if (ok) return (uint32_t)((int32_t)fc - cod);
-			lows &= ~(1ull << first);
-		}
-		cbase = (uint32_t)((int32_t)cbase + cod * 64);
-	}
-}
-
-__global__ void __launch_bounds__(256) k_find_minimap(Geom g, Buffers b) {
-	const uint32_t f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	smhv_frame_result *res = &b.results[f];
-	if (!b.aux[f].open) { if (threadIdx.x < 4) res->minimap[threadIdx.x] = 0; if (threadIdx.x == 0) res->has_minimap = 0; return; }
-	const uint8_t *roi0 = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.rx) * 4;
-	// rect = {left, right, top, bottom}; reference direction order: Left, Right, Up, Down
-	const int dir = wave == 0 ? 2 : (wave == 1 ? 3 : (wave == 2 ? 0 : 1));
-	const uint32_t v = find_edge(roi0, g.W, g.rw, g.rh, g.rw / 2u, g.rh / 2u, dir);
-	if (lane == 0) res->minimap[wave] = v;
-	if (threadIdx.x == 0) res->has_minimap = 1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_finalize: per-frame record header + ui::Marker::new / angle (src/ui/mod.rs:131-140, markers.rs:98)
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t stages) {
-	const uint32_t f = blockIdx.x, l = threadIdx.x;
-	smhv_frame_result *res = &b.results[f];
-	const FrameAux aux = b.aux[f];
-	const bool open = aux.open != 0;
-	const bool markers = (stages & SMHV_STAGE_MARKERS) != 0;
-	const uint32_t n = (open && markers) ? res->n_lines : 0u;
-	const bool has_mpx = open && (stages & SMHV_STAGE_SCALES) && res->has_mpx;
-	const double mpx = has_mpx ? res->mpx : 0.0;
-	if (l < SMHV_MAX_LINES) {
-		double len = 0.0, met = 0.0;
-		float ang = 0.0f;
-		smhv_line ln = {0.0f, 0.0f, 0.0f, 0.0f};
-		if (l < n) {
-			ln = res->lines[l];
-			const double ax = (double)ln.x0 - (double)ln.x1, ay = (double)ln.y0 - (double)ln.y1;
-			len = sqrt(ax * ax + ay * ay);
-			met = has_mpx ? len * mpx : 0.0;
-			ang = atan2f(ln.y0 - ln.y1, ln.x0 - ln.x1);
-		}
-		res->lines[l] = ln;
-		res->length_px[l] = len; res->angle[l] = ang;
-#ifdef SMH_LSD_PROFILE
-		if (l < 20)
-#endif
-		res->meters[l] = met;
-	}
-	if (l == 0) {
-		res->map_open = open ? 1u : 0u;
-		res->n_lines = n;
-		res->mpx = mpx; res->has_mpx = has_mpx ? 1u : 0u;
-		res->n_mask_px = (open && markers) ? aux.n_mask_px : 0u;
-		res->red_pixels = aux.red;
-		if (!(open && markers)) { res->rounds = 0; res->ray_steps = 0; }
-		if (!(stages & SMHV_STAGE_MINIMAP)) { res->has_minimap = 0; res->minimap[0] = 0; res->minimap[1] = 0; res->minimap[2] = 0; res->minimap[3] = 0; }
-		res->reserved = 0;
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// debug views (vision-cpu/src/lib.rs:451-460) and the exhaustive colour table
-// ------------------------------------------------------------------------------------------------
-__global__ void k_debug_view(Geom g, Buffers b, uint32_t f, int which, int isolated, uint8_t *out) {
-	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
-	const uint32_t w = brq ? g.qw : g.rw, h = brq ? g.qh : g.rh;
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= w * h) return;
-	const uint32_t y = i / w, x = i - y * w;
-	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes;
-	uint32_t o;
-	if (which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT) {
-		const uint8_t *img = (which == SMHV_VIEW_OCR_INPUT ? b.ocr : b.scales) + (size_t)f * g.ocr_stride + g.q_xoff;
-		o = (uint32_t)img[(size_t)y * g.ocr_pitch + x] * 0x00010101u | 0xFF000000u;
-	} else if (which == SMHV_VIEW_LSD_INPUT) {
-		o = (uint32_t)b.mask[(size_t)f * g.mask_stride + (size_t)y * g.mask_pitch + g.m_xoff + x] * 0x00010101u | 0xFF000000u;
-	} else {
-		const uint32_t fx = brq ? g.qx + x : g.rx + x, fy = brq ? g.qy + y : g.ry + y;
-		const uint32_t p = *(const uint32_t *)(fp + ((size_t)fy * g.W + fx) * 4);
-		uint32_t bb = p & 255u, gg = (p >> 8) & 255u, rr = (p >> 16) & 255u;
-		if (which == SMHV_VIEW_LSD_PREPROCESS && isolated && !is_marker(rr, gg, bb)) { rr = 0; gg = 0; bb = 0; }
-		o = rr | (gg << 8) | (bb << 16) | 0xFF000000u;
-	}
-	((uint32_t *)out)[i] = o;
-}
-
-__global__ void k_marker_table(uint32_t *bits) {
-	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-	if (w >= (1u << 24) / 32u) return;
-	uint32_t acc = 0;
-	for (uint32_t k = 0; k < 32; ++k) {
-		const uint32_t c = w * 32u + k;
-		if (is_marker((c >> 16) & 255u, (c >> 8) & 255u, c & 255u)) acc |= 1u << k;
-	}
-	bits[w] = acc;
-}
-
-// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s) {
-	hipLaunchKernelGGL(k_button, dim3(n), dim3(256), 0, s, g, b, force_open);
-	return hipGetLastError();
-}
-
-hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s) {
-	// Few frames: shorter bands so a single frame still spreads over the chip.
-	uint32_t RB = MAP_RB_MAX;
-	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
-	const dim3 grid((g.rh + RB - 1) / RB, n);
-	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
-	else hipLaunchKernelGGL(k_map_pass<false>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
-	return hipGetLastError();
-}
-
-hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s) {
-	const dim3 grid((g.qh + BRQ_RB - 1) / BRQ_RB, n);
-	hipLaunchKernelGGL(k_brq_pass, grid, dim3(g.q_block), 0, s, g, b, flags, fixed_start_y, use_anchor_start);
-	return hipGetLastError();
-}
-
 size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 
 bool lsd_rows_only(const Geom &g) { return (g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP; }
@@ -1681,135 +952,9 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	return hipGetLastError();
 }
 
-hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s) {
-	hipLaunchKernelGGL(k_scale_ratio, dim3(n), dim3(64 * SMHV_MAX_SCALES), 0, s, g, b, d_bars);
-	return hipGetLastError();
-}
-
-hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s) {
-	hipLaunchKernelGGL(k_find_minimap, dim3(n), dim3(256), 0, s, g, b);
-	return hipGetLastError();
-}
-
-hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s) {
-	hipLaunchKernelGGL(k_finalize, dim3(n), dim3(64), 0, s, g, b, stages);
-	return hipGetLastError();
-}
-
-hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s) {
-	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
-	const uint32_t npx = brq ? g.qw * g.qh : g.rw * g.rh;
-	hipLaunchKernelGGL(k_debug_view, dim3((npx + 255) / 256), dim3(256), 0, s, g, b, frame, which, isolated, d_rgba);
-	return hipGetLastError();
-}
-
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s) {
 	static_assert(LSD_GROUPS == LSD_GROUPS_HOST && LSD_GROUPS <= 64, "sector masks are 64-bit");
 	hipLaunchKernelGGL(k_build_sector_table, dim3((SMH_SECTOR_ENTRIES + 255) / 256), dim3(256), 0, s, d_tab, T);
-	return hipGetLastError();
-}
-
-hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s) {
-	hipLaunchKernelGGL(k_marker_table, dim3(((1u << 24) / 32u + 255) / 256), dim3(256), 0, s, d_bits);
-	return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_crc32: CRC-32 (IEEE 802.3, reflected polynomial 0xEDB88320) of a frame in HBM -- the value the
-// reference's capture thread computes with crc32fast::hash to drop duplicate captures
-// (src/capture.rs:44-47).  CRC without its init / final xor is linear over GF(2):
-//     R(A || B) = R(A) * x^(8|B|) mod P  xor  R(B)
-// so the frame is cut into 16-byte groups dealt round-robin to every thread of the grid; a thread
-// folds its groups with the usual slice-by-4 table step (tables in LDS) and a multiplication by
-// x^(128 (G - 1)) between rounds (G = threads in the grid), then aligns its remainder to the end of
-// the message with one multiplication by x^(128 (G - 1 - T)) and all remainders are xor-ed together
-// (DPP within the wave, LDS across waves, one atomicXor per workgroup).  Leading zero padding does
-// not change R, so the message is right-aligned in the last round; the init / final-xor terms
-// depend on the length only and are applied by the host (smh_runtime.cpp: crc32_finish).
-// HBM-bound: 1 byte read per byte; ~30 VALU + 16 LDS lookups per 16 bytes.
-// ------------------------------------------------------------------------------------------------
-#define CRC_POLY 0xEDB88320u
-#define CRC_BS 1024
-
-// a * b mod P in the reflected representation (x^0 = 0x80000000)
-__host__ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
-	uint32_t p = 0;
-	for (int i = 0; i < 32; ++i) {
-		p ^= (a & 0x80000000u) ? b : 0u;
-		a <<= 1;
-		b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
-	}
-	return p;
-}
-
-__device__ __forceinline__ uint32_t wave_xor32_dpp(uint32_t v) {
-	v ^= SMH_DPP(v, 0xB1);
-	v ^= SMH_DPP(v, 0x4E);
-	v ^= SMH_DPP(v, 0x141);
-	v ^= SMH_DPP(v, 0x140);
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^
-	       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
-
-// n_dwords: message length in 32-bit words; rounds * gridDim.x * CRC_BS * 4 >= n_dwords.
-// x_skip = x^(128 (G - 1)); x_local[t] = x^(128 (CRC_BS - 1 - t)); x_wg[g] = x^(128 CRC_BS (gridDim.x - 1 - g)).
-__global__ void __launch_bounds__(CRC_BS) k_crc32(const uint32_t *msg, uint64_t n_dwords, uint32_t rounds, uint32_t x_skip,
-                                                 const uint32_t *x_local, const uint32_t *x_wg, uint32_t *acc) {
-	__shared__ uint32_t tab[4][256];
-	__shared__ uint32_t wsum[CRC_BS / 64];
-	const uint32_t tid = threadIdx.x;
-	if (tid < 256u) {
-		uint32_t c = tid;
-		for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
-		tab[0][tid] = c;
-	}
-	__syncthreads();
-	if (tid < 256u) {
-		uint32_t c = tab[0][tid];
-		for (int k = 1; k < 4; ++k) { c = (c >> 8) ^ tab[0][c & 255u]; tab[k][tid] = c; }
-	}
-	__syncthreads();
-	const uint64_t G = (uint64_t)gridDim.x * CRC_BS, T = (uint64_t)blockIdx.x * CRC_BS + tid;
-	const uint64_t pad = (uint64_t)rounds * G * 4u - n_dwords;        // virtual leading zero words
-	uint32_t v = 0;
-	for (uint32_t r = 0; r < rounds; ++r) {
-		const uint64_t vi = ((uint64_t)r * G + T) * 4u;                 // virtual index of this thread's group
-		uint32_t d[4] = {0u, 0u, 0u, 0u};
-		if (vi >= pad && ((vi - pad) & 3u) == 0u && (((uintptr_t)msg) & 15u) == 0u) {
-			const uint4 q = *(const uint4 *)(msg + (vi - pad));
-			d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
-		} else {
-#pragma unroll
-			for (int j = 0; j < 4; ++j) if (vi + j >= pad) d[j] = msg[vi + j - pad];
-		}
-		if (r) v = gf2_mulmod(v, x_skip);
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t c = v ^ d[j];
-			v = tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24];
-		}
-	}
-	v = gf2_mulmod(v, x_local[tid]);
-	v = wave_xor32_dpp(v);
-	if ((tid & 63u) == 0u) wsum[tid >> 6] = v;
-	__syncthreads();
-	if (tid == 0) {
-		uint32_t w = 0;
-		for (int k = 0; k < CRC_BS / 64; ++k) w ^= wsum[k];
-		atomicXor(acc, gf2_mulmod(w, x_wg[blockIdx.x]));
-	}
-}
-
-uint32_t crc32_xpow(uint64_t n) {                             // x^n mod P
-	uint32_t r = 0x80000000u, b = 0x40000000u;                // x^0, x^1
-	for (; n; n >>= 1) { if (n & 1u) r = gf2_mulmod(r, b); b = gf2_mulmod(b, b); }
-	return r;
-}
-uint32_t crc32_mul(uint32_t a, uint32_t b) { return gf2_mulmod(a, b); }
-
-hipError_t launch_crc32(const void *d_msg, uint64_t n_dwords, uint32_t wgs, uint32_t rounds, uint32_t x_skip, const uint32_t *d_x_local,
-                        const uint32_t *d_x_wg, uint32_t *d_acc, hipStream_t s) {
-	hipLaunchKernelGGL(k_crc32, dim3(wgs), dim3(CRC_BS), 0, s, (const uint32_t *)d_msg, n_dwords, rounds, x_skip, d_x_local, d_x_wg, d_acc);
 	return hipGetLastError();
 }
 

@@ -1,0 +1,377 @@
+// smh_misc.hip -- the small kernels around the hot path (gfx950, wave64).
+//   k_scale_ratio  calc_meters_to_px_ratio / find_scale_width                 (src/vision/mpx_ratio.rs:3-134)
+//   k_find_minimap find_minimap (the caller's next step)                      (src/vision/find_minimap.rs)
+//   k_finalize     derived marker outputs                                     (src/ui/mod.rs:131-140, markers.rs:98)
+//   k_debug_view   DebugView images                                           (vision-cpu/src/lib.rs:451-460)
+//   k_marker_table exhaustive colour-predicate table (test support)
+//   k_crc32        CRC-32 of a frame in HBM for the capture hand-off          (src/capture.rs:44-47)
+//
+// Build with -ffp-contract=off and correctly rounded f32 division: several results are truncated to integers
+// right at a threshold, so the reference's scalar f32 operation order (no FMA contraction, IEEE divide) is
+// part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
+// structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
+#include "smh_device.h"
+
+namespace smh {
+
+// ------------------------------------------------------------------------------------------------
+// k_scale_ratio: src/vision/mpx_ratio.rs.  One wave per OCR label anchor (<= 3 per frame).  The scan
+// order of the reference is kept (rows downwards from the anchor; first tick column to the right,
+// then to the left), but each "first column whose 4 pixels below are all 0" search tests 64 columns
+// per step and takes the first hit with a ballot.  Pixels below the image count as non-zero
+// (reference: unchecked read).
+// ------------------------------------------------------------------------------------------------
+__device__ bool find_scale_width(const uint8_t *img, size_t pitch, uint32_t w, uint32_t h, uint32_t meters, uint32_t x, uint32_t y, double *ratio,
+                                 uint32_t bar[3]) {
+	const uint32_t lane = threadIdx.x & 63u;
+	if (y < SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT || x >= w) return false;
+	// ((20.0 / 640.0) * w as f64).round(): 0.03125*w has at most 5 fractional bits, so t + 0.5 is exact
+	// and floor(t + 0.5) is round-half-away-from-zero for t >= 0
+	const double t = (20.0 / 640.0) * (double)w;
+	const uint32_t max_off = (uint32_t)floor(t + 0.5);
+	const uint32_t y_end = min(h, y + max_off);
+	auto tick = [&](uint32_t xx, uint32_t yy) -> bool {    // rows yy..yy+3 of column xx all 0
+		bool all0 = true;
+		for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty) all0 = all0 && ty < h && img[(size_t)ty * pitch + xx] == 0;
+		return all0;
+	};
+	for (uint32_t yy = y; yy < y_end; ++yy) {
+		if (img[(size_t)yy * pitch + x] != 0) continue;      // wave-uniform
+		uint32_t right = 0;
+		for (uint32_t base = x; base < w; base += 64u) {     // Go right...
+			const uint32_t xx = base + lane;
+			const uint64_t hit = __ballot(xx < w && tick(xx, yy));
+			if (hit) { right = base + (uint32_t)__builtin_ctzll(hit); break; }
+		}
+		if (right == 0) continue;
+		right -= 1;
+		uint32_t left = 0;
+		bool found = false;
+		for (uint32_t base = 0; base < x; base += 64u) {     // Go left... (columns x-1, x-2, ...)
+			const uint32_t off = base + lane;
+			const uint64_t hit = __ballot(off < x && tick(x - 1u - off, yy));
+			if (hit) { left = x - 1u - (base + (uint32_t)__builtin_ctzll(hit)); found = true; break; }
+		}
+		(void)found;
+		if (left == 0) continue;
+		left += 1;
+		const uint32_t width = right - left;   // wraps like release Rust (mpx_ratio.rs:58)
+		if (width < SMH_MIN_SCALE_WIDTH) continue;
+		bar[0] = left; bar[1] = yy; bar[2] = right;
+		*ratio = (double)meters / (double)width;
+		return true;
+	}
+	return false;
+}
+
+__global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) {
+	const uint32_t f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	__shared__ double s_ratio[SMHV_MAX_SCALES];
+	__shared__ uint32_t s_ok[SMHV_MAX_SCALES];
+	smhv_frame_result *res = &b.results[f];
+	const bool open = b.aux[f].open != 0;
+	const smhv_anchors an = b.anchors[f];
+	const uint32_t n = open ? min(an.n, (uint32_t)SMHV_MAX_SCALES) : 0u;
+	const bool valid = an.scales_start_y <= g.qh;
+	{
+		double r = 0.0;
+		uint32_t bar[3] = {0, 0, 0};
+		bool ok = false;
+		if (wave < n && valid) {                               // wave-uniform
+			const uint8_t *img = b.scales + (size_t)f * g.ocr_stride + g.q_xoff;
+			ok = find_scale_width(img, g.ocr_pitch, g.qw, g.qh, an.scales[wave][0], an.scales[wave][1], an.scales[wave][2], &r, bar);
+		}
+		if (lane == 0) {
+			s_ratio[wave] = r; s_ok[wave] = ok ? 1u : 0u;
+			if (bars) {
+				uint32_t *o = bars + ((size_t)f * SMHV_MAX_SCALES + wave) * 4;
+				o[0] = bar[0]; o[1] = bar[1]; o[2] = bar[2]; o[3] = ok ? 1u : 0u;
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		// the "Rayon ladder" (mpx_ratio.rs:93-125): mean of the successes, summed in index order
+		double sum = 0.0; uint32_t k = 0;
+		for (uint32_t i = 0; i < SMHV_MAX_SCALES; ++i)
+			if (s_ok[i]) { sum = k ? sum + s_ratio[i] : s_ratio[i]; ++k; }
+		res->has_mpx = k ? 1u : 0u;
+		res->mpx = k == 0 ? 0.0 : (k == 1 ? sum : sum / (double)k);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_find_minimap: src/vision/find_minimap.rs (the caller's step right after crop_to_map).
+// One wave per direction (Left, Right, Up, Down), four waves per frame.  The reference walks pixel by
+// pixel from the ROI centre and, at every pixel whose "edginess" is <= 0.01, tries a perpendicular run of
+// min_line_length equally flat pixels.  Here 64 steps of the main walk are tested at once (ballot, handled
+// in walk order) and the perpendicular run is tested 64 pixels per step; the result is the reference's.
+// edginess = max over the 8 neighbours of |dB|+|dG|+|dR|, as f32 / 765.0 <= 0.01  <=>  that max <= 7
+// (7/765 = 0.00915, 8/765 = 0.01046).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool flat_pixel(const uint8_t *roi0, uint32_t W, uint32_t x, uint32_t y) {
+	const uint32_t *p = (const uint32_t *)(roi0 + ((size_t)y * W + x) * 4);
+	const int Wi = (int)W;
+	const uint32_t c = p[0] & 0x00FFFFFFu;
+	uint32_t mx = 0;
+#pragma unroll
+	for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+		for (int dx = -1; dx <= 1; ++dx)
+			if (dx != 0 || dy != 0) mx = max(mx, (uint32_t)__builtin_amdgcn_sad_u8(c, p[dy * Wi + dx] & 0x00FFFFFFu, 0u));
+	return (float)mx / 765.0f <= 0.01f;
+}
+
+__device__ uint32_t find_edge(const uint8_t *roi0, uint32_t W, uint32_t w, uint32_t h, uint32_t x0, uint32_t y0, int dir) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool vertical = dir < 2;                         // Up, Down move y; Left, Right move x
+	uint32_t c_max = vertical ? h : w, oc_max = vertical ? w : h;
+	const int cod = (dir == 0 || dir == 2) ? -1 : 1;
+	const uint32_t c0 = vertical ? y0 : x0, oc0 = vertical ? x0 : y0;
+	const uint32_t d = oc_max > oc0 ? oc_max - oc0 : oc0 - oc_max;
+	const uint32_t mll = d / 2u - 1u;                      // min_line_length (wraps like release Rust; >= 0 for dims >= 3)
+	c_max -= 3u; oc_max -= 3u;
+	uint32_t cbase = c0;
+	for (;;) {
+		const uint32_t cc = (uint32_t)((int32_t)cbase + cod * (int32_t)(lane + 1u));
+		const int st = cc > c_max ? 1 : (cc < 3u ? 2 : 0);     // order of the reference's two tests
+		bool low = false;
+		if (st == 0) low = flat_pixel(roi0, W, vertical ? oc0 : cc, vertical ? cc : oc0);
+		const uint64_t term = __ballot(st != 0);
+		uint64_t lows = __ballot(low);
+		for (;;) {
+			const uint64_t both = term | lows;
+			if (!both) break;
+			const uint32_t first = (uint32_t)__builtin_ctzll(both);
+			const uint32_t fc = (uint32_t)((int32_t)cbase + cod * (int32_t)(first + 1u));
+			if ((term >> first) & 1ull) return fc > c_max ? c_max + 2u : 0u;
+			// a flat pixel: "try and find a straight line of pixels that are also under the edginess threshold"
+			bool ok = true;
+			for (uint32_t kb = 0; kb < mll && ok; kb += 64u) {
+				const uint32_t k = kb + lane + 1u;
+				bool good = true;
+				if (k <= mll) {
+					const uint32_t oc = (uint32_t)((int32_t)oc0 - cod * (int32_t)k);
+					good = !(oc < 3u || oc > oc_max) && flat_pixel(roi0, W, vertical ? oc : fc, vertical ? fc : oc);
+				}
+				ok = __all(good);
+			}
+			if (ok) return (uint32_t)((int32_t)fc - cod);
+			lows &= ~(1ull << first);
+		}
+		cbase = (uint32_t)((int32_t)cbase + cod * 64);
+	}
+}
+
+__global__ void __launch_bounds__(256) k_find_minimap(Geom g, Buffers b) {
+	const uint32_t f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	smhv_frame_result *res = &b.results[f];
+	if (!b.aux[f].open) { if (threadIdx.x < 4) res->minimap[threadIdx.x] = 0; if (threadIdx.x == 0) res->has_minimap = 0; return; }
+	const uint8_t *roi0 = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.rx) * 4;
+	// rect = {left, right, top, bottom}; reference direction order: Left, Right, Up, Down
+	const int dir = wave == 0 ? 2 : (wave == 1 ? 3 : (wave == 2 ? 0 : 1));
+	const uint32_t v = find_edge(roi0, g.W, g.rw, g.rh, g.rw / 2u, g.rh / 2u, dir);
+	if (lane == 0) res->minimap[wave] = v;
+	if (threadIdx.x == 0) res->has_minimap = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finalize: per-frame record header + ui::Marker::new / angle (src/ui/mod.rs:131-140, markers.rs:98)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t stages) {
+	const uint32_t f = blockIdx.x, l = threadIdx.x;
+	smhv_frame_result *res = &b.results[f];
+	const FrameAux aux = b.aux[f];
+	const bool open = aux.open != 0;
+	const bool markers = (stages & SMHV_STAGE_MARKERS) != 0;
+	const uint32_t n = (open && markers) ? res->n_lines : 0u;
+	const bool has_mpx = open && (stages & SMHV_STAGE_SCALES) && res->has_mpx;
+	const double mpx = has_mpx ? res->mpx : 0.0;
+	if (l < SMHV_MAX_LINES) {
+		double len = 0.0, met = 0.0;
+		float ang = 0.0f;
+		smhv_line ln = {0.0f, 0.0f, 0.0f, 0.0f};
+		if (l < n) {
+			ln = res->lines[l];
+			const double ax = (double)ln.x0 - (double)ln.x1, ay = (double)ln.y0 - (double)ln.y1;
+			len = sqrt(ax * ax + ay * ay);
+			met = has_mpx ? len * mpx : 0.0;
+			ang = atan2f(ln.y0 - ln.y1, ln.x0 - ln.x1);
+		}
+		res->lines[l] = ln;
+		res->length_px[l] = len; res->angle[l] = ang;
+#ifdef SMH_LSD_PROFILE
+		if (l < 20)
+#endif
+		res->meters[l] = met;
+	}
+	if (l == 0) {
+		res->map_open = open ? 1u : 0u;
+		res->n_lines = n;
+		res->mpx = mpx; res->has_mpx = has_mpx ? 1u : 0u;
+		res->n_mask_px = (open && markers) ? aux.n_mask_px : 0u;
+		res->red_pixels = aux.red;
+		if (!(open && markers)) { res->rounds = 0; res->ray_steps = 0; }
+		if (!(stages & SMHV_STAGE_MINIMAP)) { res->has_minimap = 0; res->minimap[0] = 0; res->minimap[1] = 0; res->minimap[2] = 0; res->minimap[3] = 0; }
+		res->reserved = 0;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug views (vision-cpu/src/lib.rs:451-460) and the exhaustive colour table
+// ------------------------------------------------------------------------------------------------
+__global__ void k_debug_view(Geom g, Buffers b, uint32_t f, int which, int isolated, uint8_t *out) {
+	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
+	const uint32_t w = brq ? g.qw : g.rw, h = brq ? g.qh : g.rh;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= w * h) return;
+	const uint32_t y = i / w, x = i - y * w;
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes;
+	uint32_t o;
+	if (which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT) {
+		const uint8_t *img = (which == SMHV_VIEW_OCR_INPUT ? b.ocr : b.scales) + (size_t)f * g.ocr_stride + g.q_xoff;
+		o = (uint32_t)img[(size_t)y * g.ocr_pitch + x] * 0x00010101u | 0xFF000000u;
+	} else if (which == SMHV_VIEW_LSD_INPUT) {
+		o = (uint32_t)b.mask[(size_t)f * g.mask_stride + (size_t)y * g.mask_pitch + g.m_xoff + x] * 0x00010101u | 0xFF000000u;
+	} else {
+		const uint32_t fx = brq ? g.qx + x : g.rx + x, fy = brq ? g.qy + y : g.ry + y;
+		const uint32_t p = *(const uint32_t *)(fp + ((size_t)fy * g.W + fx) * 4);
+		uint32_t bb = p & 255u, gg = (p >> 8) & 255u, rr = (p >> 16) & 255u;
+		if (which == SMHV_VIEW_LSD_PREPROCESS && isolated && !is_marker(rr, gg, bb)) { rr = 0; gg = 0; bb = 0; }
+		o = rr | (gg << 8) | (bb << 16) | 0xFF000000u;
+	}
+	((uint32_t *)out)[i] = o;
+}
+
+__global__ void k_marker_table(uint32_t *bits) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= (1u << 24) / 32u) return;
+	uint32_t acc = 0;
+	for (uint32_t k = 0; k < 32; ++k) {
+		const uint32_t c = w * 32u + k;
+		if (is_marker((c >> 16) & 255u, (c >> 8) & 255u, c & 255u)) acc |= 1u << k;
+	}
+	bits[w] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s) {
+	hipLaunchKernelGGL(k_scale_ratio, dim3(n), dim3(64 * SMHV_MAX_SCALES), 0, s, g, b, d_bars);
+	return hipGetLastError();
+}
+
+hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s) {
+	hipLaunchKernelGGL(k_find_minimap, dim3(n), dim3(256), 0, s, g, b);
+	return hipGetLastError();
+}
+
+hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s) {
+	hipLaunchKernelGGL(k_finalize, dim3(n), dim3(64), 0, s, g, b, stages);
+	return hipGetLastError();
+}
+
+hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s) {
+	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
+	const uint32_t npx = brq ? g.qw * g.qh : g.rw * g.rh;
+	hipLaunchKernelGGL(k_debug_view, dim3((npx + 255) / 256), dim3(256), 0, s, g, b, frame, which, isolated, d_rgba);
+	return hipGetLastError();
+}
+
+hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s) {
+	hipLaunchKernelGGL(k_marker_table, dim3(((1u << 24) / 32u + 255) / 256), dim3(256), 0, s, d_bits);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_crc32: CRC-32 (IEEE 802.3, reflected polynomial 0xEDB88320) of a frame in HBM -- the value the
+// reference's capture thread computes with crc32fast::hash to drop duplicate captures
+// (src/capture.rs:44-47).  CRC without its init / final xor is linear over GF(2):
+//     R(A || B) = R(A) * x^(8|B|) mod P  xor  R(B)
+// so the frame is cut into 16-byte groups dealt round-robin to every thread of the grid; a thread
+// folds its groups with the usual slice-by-4 table step (tables in LDS) and a multiplication by
+// x^(128 (G - 1)) between rounds (G = threads in the grid), then aligns its remainder to the end of
+// the message with one multiplication by x^(128 (G - 1 - T)) and all remainders are xor-ed together
+// (DPP within the wave, LDS across waves, one atomicXor per workgroup).  Leading zero padding does
+// not change R, so the message is right-aligned in the last round; the init / final-xor terms
+// depend on the length only and are applied by the host (smh_runtime.cpp: crc32_finish).
+// HBM-bound: 1 byte read per byte; ~30 VALU + 16 LDS lookups per 16 bytes.
+// ------------------------------------------------------------------------------------------------
+#define CRC_POLY 0xEDB88320u
+#define CRC_BS 1024
+
+// a * b mod P in the reflected representation (x^0 = 0x80000000)
+__host__ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
+	uint32_t p = 0;
+	for (int i = 0; i < 32; ++i) {
+		p ^= (a & 0x80000000u) ? b : 0u;
+		a <<= 1;
+		b = (b >> 1) ^ ((b & 1u) ? CRC_POLY : 0u);
+	}
+	return p;
+}
+
+// n_dwords: message length in 32-bit words; rounds * gridDim.x * CRC_BS * 4 >= n_dwords.
+// x_skip = x^(128 (G - 1)); x_local[t] = x^(128 (CRC_BS - 1 - t)); x_wg[g] = x^(128 CRC_BS (gridDim.x - 1 - g)).
+__global__ void __launch_bounds__(CRC_BS) k_crc32(const uint32_t *msg, uint64_t n_dwords, uint32_t rounds, uint32_t x_skip,
+                                                 const uint32_t *x_local, const uint32_t *x_wg, uint32_t *acc) {
+	__shared__ uint32_t tab[4][256];
+	__shared__ uint32_t wsum[CRC_BS / 64];
+	const uint32_t tid = threadIdx.x;
+	if (tid < 256u) {
+		uint32_t c = tid;
+		for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+		tab[0][tid] = c;
+	}
+	__syncthreads();
+	if (tid < 256u) {
+		uint32_t c = tab[0][tid];
+		for (int k = 1; k < 4; ++k) { c = (c >> 8) ^ tab[0][c & 255u]; tab[k][tid] = c; }
+	}
+	__syncthreads();
+	const uint64_t G = (uint64_t)gridDim.x * CRC_BS, T = (uint64_t)blockIdx.x * CRC_BS + tid;
+	const uint64_t pad = (uint64_t)rounds * G * 4u - n_dwords;        // virtual leading zero words
+	uint32_t v = 0;
+	for (uint32_t r = 0; r < rounds; ++r) {
+		const uint64_t vi = ((uint64_t)r * G + T) * 4u;                 // virtual index of this thread's group
+		uint32_t d[4] = {0u, 0u, 0u, 0u};
+		if (vi >= pad && ((vi - pad) & 3u) == 0u && (((uintptr_t)msg) & 15u) == 0u) {
+			const uint4 q = *(const uint4 *)(msg + (vi - pad));
+			d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) if (vi + j >= pad) d[j] = msg[vi + j - pad];
+		}
+		if (r) v = gf2_mulmod(v, x_skip);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t c = v ^ d[j];
+			v = tab[3][c & 255u] ^ tab[2][(c >> 8) & 255u] ^ tab[1][(c >> 16) & 255u] ^ tab[0][c >> 24];
+		}
+	}
+	v = gf2_mulmod(v, x_local[tid]);
+	v = wave_xor32_dpp(v);
+	if ((tid & 63u) == 0u) wsum[tid >> 6] = v;
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t w = 0;
+		for (int k = 0; k < CRC_BS / 64; ++k) w ^= wsum[k];
+		atomicXor(acc, gf2_mulmod(w, x_wg[blockIdx.x]));
+	}
+}
+
+uint32_t crc32_xpow(uint64_t n) {                             // x^n mod P
+	uint32_t r = 0x80000000u, b = 0x40000000u;                // x^0, x^1
+	for (; n; n >>= 1) { if (n & 1u) r = gf2_mulmod(r, b); b = gf2_mulmod(b, b); }
+	return r;
+}
+uint32_t crc32_mul(uint32_t a, uint32_t b) { return gf2_mulmod(a, b); }
+
+hipError_t launch_crc32(const void *d_msg, uint64_t n_dwords, uint32_t wgs, uint32_t rounds, uint32_t x_skip, const uint32_t *d_x_local,
+                        const uint32_t *d_x_wg, uint32_t *d_acc, hipStream_t s) {
+	hipLaunchKernelGGL(k_crc32, dim3(wgs), dim3(CRC_BS), 0, s, (const uint32_t *)d_msg, n_dwords, rounds, x_skip, d_x_local, d_x_wg, d_acc);
+	return hipGetLastError();
+}
+
+}  // namespace smh

@@ -1,0 +1,388 @@
+// smh_stream.hip -- the HBM-bound streaming kernels of the vision hot path (gfx950, wave64).
+//   k_button      red "Close Deployment" pixel count -> map_open           (lib.rs:116-133)
+//   k_map_pass    one streaming pass over the map ROI: ui_map RGBA + marker colour predicate +
+//                 L1 radius-1 dilation -> u8 mask + bit-packed mask + bbox   (lib.rs:137-171,253-280,357-375)
+//   k_brq_pass    bottom-right quadrant: ocr_preprocess + find_scales_preprocess (lib.rs:173-251)
+//
+// Build with -ffp-contract=off and correctly rounded f32 division: several results are truncated to integers
+// right at a threshold, so the reference's scalar f32 operation order (no FMA contraction, IEEE divide) is
+// part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
+// structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
+#include "smh_device.h"
+
+namespace smh {
+
+// ------------------------------------------------------------------------------------------------
+// k_button: one workgroup per frame.  Also resets the per-frame scratch for the later passes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_open) {
+	const uint32_t f = blockIdx.x;
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes;
+	__shared__ uint32_t s_cnt;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
+	uint32_t cnt = 0;
+	const uint32_t npx = g.bw * g.bh;
+	for (uint32_t i = threadIdx.x; i < npx; i += blockDim.x) {
+		const uint32_t y = i / g.bw, x = i - y * g.bw;
+		const uint32_t p = *(const uint32_t *)(fp + ((size_t)(g.by + y) * g.W + g.bx + x) * 4);   // B | G<<8 | R<<16 | A<<24
+		const uint32_t bb = p & 255u, gg = (p >> 8) & 255u, rr = (p >> 16) & 255u;
+		cnt += (absdiff(SMH_BUTTON_R, rr) <= SMH_BUTTON_TOLERANCE && absdiff(SMH_BUTTON_G, gg) <= SMH_BUTTON_TOLERANCE &&
+		        absdiff(SMH_BUTTON_B, bb) <= SMH_BUTTON_TOLERANCE) ? 1u : 0u;
+	}
+	cnt = wave_sum32(cnt);
+	if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, cnt);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const uint32_t red = s_cnt;
+		// `red_pixels as f32 / (w * h) as f32 < 0.65` => Ok(None)   (vision-cpu/src/lib.rs:130-133)
+		const float ratio = (float)red / (float)npx;
+		FrameAux a;
+		a.open = (force_open || !(ratio < SMH_BUTTON_RED_PIXEL_THRESHOLD)) ? 1u : 0u;
+		a.red = red; a.n_mask_px = 0;
+		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.pad = 0;
+		b.aux[f] = a;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_map_pass
+//
+// grid = (row bands, frames); block = one thread per quad (4 pixels, 16-byte BGRA load) across the
+// whole ROI width, so the waves of a workgroup sit side by side on the same rows.
+// Each thread marches down its quad column over the band's rows (+1 halo row above and below) and
+// keeps the marker predicate as four 64-bit column masks (bit = row).  In that form
+//   vertical dilation   = p | p<<1 | p>>1            (all rows of the band at once)
+//   horizontal dilation = neighbouring column masks  (own registers, lane+-1 via DPP shuffles,
+//                                                      wave edges via 16 B of LDS per wave)
+// so the 3x3-cross dilation of the reference (imageproc dilate_mut(L1,1)) costs a dozen
+// instructions per band instead of a second pass over an intermediate image.  ui_map is written
+// straight from the loaded registers; the frame is read exactly once (+2 halo rows per band).
+// ------------------------------------------------------------------------------------------------
+#define MAP_RB_MAX 62
+
+template <bool GRAY>
+__global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t flags, uint32_t RB) {
+	const uint32_t f = blockIdx.y;
+	if (!b.aux[f].open) return;
+	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
+	const int r0 = (int)(blockIdx.x * RB);
+	const int r1 = min(r0 + (int)RB, (int)g.rh);
+	const bool qact = q < g.m_quads;
+	uint32_t vmask = 0;
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		if ((uint32_t)(4 * q + c - g.m_xoff) < g.rw) vmask |= 1u << c;
+	if (!qact) vmask = 0;
+
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax + 4 * q) * 4;
+	uint8_t *uip = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
+	const size_t row_bytes = (size_t)g.W * 4;
+
+	uint64_t P[4] = {0, 0, 0, 0};
+	const int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
+	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
+
+	// Software pipeline: the loads of the next four rows are issued before the current four are
+	// processed, so they fly under the compute and the stores (vmcnt is in-order: a load issued after
+	// the stores would also wait for them).  Inactive lanes re-read quad 0 (no divergent load).
+	const uint8_t *lp = qact ? fp : fp - (size_t)q * 16;
+	uint4 nx[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
+	__shared__ uint32_t s_hit_px[16][64], s_hit_res[16][64];
+	__shared__ unsigned short s_hit_id[16][64];
+	for (int r = rs; r <= re; r += 4) {
+		uint4 px[4];
+		uint32_t prehits = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) px[k] = nx[k];
+		if (r + 4 <= re) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(r + 4 + k, re) * row_bytes);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int row = r + k;
+			if (row > re) break;
+			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+			if (do_ui && row >= r0 && row < r1 && qact) {
+				uint4 o;
+				uint32_t ov[4];
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+					if (GRAY) ov[c] = luma8(rr8, gg, bb) * 0x00010101u | 0xFF000000u;   // Bgra::to_luma -> (l,l,l,255)
+					else ov[c] = rr8 | (gg << 8) | (bb << 16) | 0xFF000000u;           // (r,g,b,255)
+				}
+				o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
+				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
+			}
+			if (do_mask) {
+				// branch-free integer pre-filter; hits of the four rows are collected (bit 4k+c)
+				uint32_t pre = 0;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
+				prehits |= (pre & vmask) << (4 * k);
+			}
+		}
+		// ---- exact f32 HSV test for the pre-filter hits of this wave, one hit per lane ----
+		// A marker line crosses most rows of a band but only a few pixels of each, so testing hits where
+		// they sit would run the (long, divergent) exact test several times per row for two or three
+		// active lanes.  Instead the hit pixels of the whole wave and of all four rows are compacted into
+		// a 64-entry LDS list, every lane tests one of them, and the verdicts are scattered back with
+		// LDS atomic ORs.  (This path used to be 40 % of the kernel's time.)
+		if (do_mask && __any(prehits != 0u)) {
+			uint32_t *hpx = s_hit_px[wave];
+			uint32_t *hres = s_hit_res[wave];
+			unsigned short *hid = s_hit_id[wave];
+			const uint32_t cnt = (uint32_t)__popc(prehits);
+			uint32_t incl = cnt;
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
+			const uint32_t total = __shfl(incl, 63);
+			const uint32_t off = incl - cnt;
+			hres[lane] = 0u;
+			for (uint32_t base = 0; base < total; base += 64u) {
+				uint32_t o = off - base;                           // may wrap: compared unsigned below
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const uint32_t pk[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+					for (int c = 0; c < 4; ++c)
+						if ((prehits >> (4 * k + c)) & 1u) {
+							if (o < 64u) { hpx[o] = pk[c]; hid[o] = (unsigned short)((lane << 4) | (uint32_t)(4 * k + c)); }
+							++o;
+						}
+				}
+				__builtin_amdgcn_wave_barrier();
+				const uint32_t e = base + lane;
+				if (e < total) {
+					const uint32_t p = hpx[lane];
+					if (marker_exact((p >> 16) & 255u, (p >> 8) & 255u, p & 255u)) {
+						const uint32_t id = hid[lane];
+						atomicOr(&hres[id >> 4], 1u << (id & 15u));
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			const uint32_t res = hres[lane];                       // bit 4k+c: pixel c of row r+k is a marker colour
+			if (res) {
+				const int sh = r - (r0 - 1);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					uint32_t y = (res >> c) & 0x1111u;                 // rows k = 0..3 at bits 0,4,8,12
+					y = (y | (y >> 3) | (y >> 6) | (y >> 9)) & 0xFu;   // -> bits 0..3
+					P[c] |= (uint64_t)y << sh;
+				}
+			}
+		}
+	}
+	if (!do_mask) return;
+
+	// ---- dilation on the column masks ----
+	__shared__ uint64_t s_edge_first[16], s_edge_last[16];
+	if (lane == 0) s_edge_first[wave] = P[0];
+	if (lane == 63) s_edge_last[wave] = P[3];
+	__syncthreads();
+	uint64_t left = __shfl_up(P[3], 1), right = __shfl_down(P[0], 1);
+	if (lane == 0) left = wave > 0 ? s_edge_last[wave - 1] : 0ull;
+	if (lane == 63) right = wave + 1 < nwave ? s_edge_first[wave + 1] : 0ull;
+	const int nrows = r1 - r0;
+	const uint64_t rowmask = ((nrows >= 63 ? ~0ull : ((1ull << nrows) - 1ull)) << 1);   // bits 1..nrows
+	uint64_t D[4];
+#define SMH_VERT(p) ((p) | ((p) << 1) | ((p) >> 1))
+	D[0] = SMH_VERT(P[0]) | left | P[1];
+	D[1] = SMH_VERT(P[1]) | P[0] | P[2];
+	D[2] = SMH_VERT(P[2]) | P[1] | P[3];
+	D[3] = SMH_VERT(P[3]) | P[2] | right;
+#undef SMH_VERT
+#pragma unroll
+	for (int c = 0; c < 4; ++c) D[c] = ((vmask >> c) & 1u) ? (D[c] & rowmask) : 0ull;
+
+	// ---- outputs: u8 mask rows and bit-packed rows ----
+	const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
+	if (q < quads_padded) {
+		uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
+		uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
+		for (int row = r0; row < r1; ++row) {
+			const int bit = row - r0 + 1;
+			const uint32_t nib = (uint32_t)((D[0] >> bit) & 1ull) | ((uint32_t)((D[1] >> bit) & 1ull) << 1) |
+			                     ((uint32_t)((D[2] >> bit) & 1ull) << 2) | ((uint32_t)((D[3] >> bit) & 1ull) << 3);
+			*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;
+			// gather 8 lanes' nibbles into one dword of the bit-packed row (lane l supplies bits 4(l%8)..)
+			uint32_t v = nib;
+			v |= __shfl_down(v, 1) << 4;
+			v |= __shfl_down(v, 2) << 8;
+			v |= __shfl_down(v, 4) << 16;
+			if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
+		}
+	}
+	// ---- bounding box + population count of the set bits (drives the LDS window of k_lsd) ----
+	const uint64_t any = D[0] | D[1] | D[2] | D[3];
+	const uint64_t lanes_set = __ballot(any != 0ull);
+	if (lanes_set) {
+		const uint64_t rows_set = wave_or64(any);
+		const uint32_t cnt = wave_sum32(__popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]));
+		if (lane == 0) {
+			FrameAux *a = &b.aux[f];
+			atomicMin(&a->y_min, (uint32_t)(r0 - 1 + __builtin_ctzll(rows_set)));
+			atomicMax(&a->y_max, (uint32_t)(r0 - 1 + 63 - __builtin_clzll(rows_set)));
+			atomicMin(&a->w_min, (wave * 64u + (uint32_t)__builtin_ctzll(lanes_set)) >> 3);
+			atomicMax(&a->w_max, (wave * 64u + 63u - (uint32_t)__builtin_clzll(lanes_set)) >> 3);
+			atomicAdd(&a->n_mask_px, cnt);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_brq_pass: ocr_preprocess (lib.rs:173-231) + find_scales_preprocess (lib.rs:233-251) over the
+// bottom-right quadrant, same column-mask technique with a 3-row halo.
+//   monochromaticy = sum over ordered pairs |ci-cj| = 4*(max-min)
+//     "<= 3"  <=> r == g == b            "<= 48" <=> max-min <= 12
+//   keep(x,y) = W(x,y) || (E(x,y) && exists W in [x-3, min(x+3, w-3)] x [y-3, min(y+3, h-3)])
+//     W = r==g==b && all >= 200,  E = max-min <= 12 && all >= 130
+// ------------------------------------------------------------------------------------------------
+#define BRQ_RB 58
+
+__global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start) {
+	const uint32_t f = blockIdx.y;
+	if (!b.aux[f].open) return;
+	uint32_t start_y = fixed_start_y;
+	bool do_scales = (flags & BRQ_SCALES) != 0;
+	if (use_anchor_start) {
+		const smhv_anchors an = b.anchors[f];
+		start_y = an.scales_start_y;
+		// src/vision/mod.rs:196-198: no labels => the scales branch returns before find_scales_preprocess
+		if (an.n == 0 || start_y > g.qh) do_scales = false;
+	}
+	const bool do_ocr = (flags & BRQ_OCR) != 0;
+	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
+	const int r0 = (int)(blockIdx.x * BRQ_RB);
+	const int r1 = min(r0 + BRQ_RB, (int)g.qh);
+	const bool qact = q < g.q_quads;
+	uint32_t vmask = 0, wmask = 0;   // valid pixel / pixel allowed as a "white neighbour" (x <= w-3)
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint32_t x = 4 * q + c - g.q_xoff;
+		if (x < g.qw) vmask |= 1u << c;
+		if (x + SMH_OCR_DILATE_RADIUS <= g.qw) wmask |= 1u << c;   // x <= w - 3
+	}
+	if (!qact) { vmask = 0; wmask = 0; }
+	wmask &= vmask;
+
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.qy * g.W + g.q_ax + 4 * q) * 4;
+	const size_t row_bytes = (size_t)g.W * 4;
+	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride + (size_t)q * 4;
+	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride + (size_t)q * 4;
+
+	uint64_t Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
+	const int rs = max(r0 - 3, 0), re = min(r1 + 2, (int)g.qh - 1);
+	for (int r = rs; r <= re; r += 4) {
+		uint4 px[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int rr = min(r + k, re);
+			px[k] = qact ? *(const uint4 *)(fp + (size_t)rr * row_bytes) : make_uint4(0, 0, 0, 0);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int row = r + k;
+			if (row > re) break;
+			const int bit = row - (r0 - 3);
+			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+			const bool out_row = row >= r0 && row < r1;
+			const bool nb_row = (uint32_t)row + SMH_OCR_DILATE_RADIUS <= g.qh;   // y <= h - 3
+			uint32_t ocr_w = 0, sc_w = 0;
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+				const uint32_t mx = max(rr8, max(gg, bb)), mn = min(rr8, min(gg, bb));
+				const bool w = (mx == mn) && mn >= SMH_OCR_BRIGHTNESS_THRESHOLD;
+				const bool e = (4u * (mx - mn) <= SMH_OCR_SIMILARITY_EDGE_THRESHOLD) && mn >= SMH_OCR_BRIGHTNESS_EDGE_THRESHOLD && !w;
+				const bool valid = (vmask >> c) & 1u;
+				Wb[c] |= (uint64_t)((w && nb_row && ((wmask >> c) & 1u)) ? 1u : 0u) << bit;
+				Eb[c] |= (uint64_t)((e && valid && out_row) ? 1u : 0u) << bit;
+				const uint32_t l = luma8(rr8, gg, bb);
+				ocr_w |= ((w && valid) ? (255u - l) : 255u) << (8 * c);
+				sc_w |= (l != 0u ? 255u : 0u) << (8 * c);
+			}
+			if (out_row && qact) {
+				if (do_ocr) *(uint32_t *)(op + (size_t)row * g.ocr_pitch) = ocr_w;
+				if (do_scales && (uint32_t)row >= start_y) *(uint32_t *)(sp + (size_t)row * g.ocr_pitch) = sc_w;
+			}
+		}
+	}
+	if (!do_ocr) return;
+
+	// ---- 7x7 "white neighbour" dilation on the column masks ----
+	uint64_t V[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint64_t w = Wb[c];
+		V[c] = w | (w << 1) | (w << 2) | (w << 3) | (w >> 1) | (w >> 2) | (w >> 3);
+	}
+	__shared__ uint64_t s_first[16][4], s_last[16][4];
+	if (lane == 0) { s_first[wave][0] = V[0]; s_first[wave][1] = V[1]; s_first[wave][2] = V[2]; s_first[wave][3] = V[3]; }
+	if (lane == 63) { s_last[wave][0] = V[0]; s_last[wave][1] = V[1]; s_last[wave][2] = V[2]; s_last[wave][3] = V[3]; }
+	__syncthreads();
+	uint64_t X[12];   // columns -4..7 relative to this quad
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		uint64_t l = __shfl_up(V[c], 1), r = __shfl_down(V[c], 1);
+		if (lane == 0) l = wave > 0 ? s_last[wave - 1][c] : 0ull;
+		if (lane == 63) r = wave + 1 < nwave ? s_first[wave + 1][c] : 0ull;
+		X[c] = l; X[4 + c] = V[c]; X[8 + c] = r;
+	}
+	bool any_patch = false;
+	uint64_t K[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		uint64_t d = 0;
+#pragma unroll
+		for (int k = -3; k <= 3; ++k) d |= X[4 + c + k];
+		K[c] = Eb[c] & d;
+		any_patch = any_patch || K[c] != 0ull;
+	}
+	// Pixels kept only because of a white neighbour are rare (anti-aliased glyph edges): re-read
+	// just those pixels for their luma and patch the byte written above (same thread => ordered).
+	if (any_patch) {
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			uint64_t k = K[c];
+			while (k) {
+				const int bit = __builtin_ctzll(k);
+				k &= k - 1;
+				const int row = r0 - 3 + bit;
+				const uint32_t p = *(const uint32_t *)(fp + (size_t)row * row_bytes + 4 * c);
+				const uint32_t l = luma8((p >> 16) & 255u, (p >> 8) & 255u, p & 255u);
+				op[(size_t)row * g.ocr_pitch + c] = (uint8_t)(255u - l);
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s) {
+	hipLaunchKernelGGL(k_button, dim3(n), dim3(256), 0, s, g, b, force_open);
+	return hipGetLastError();
+}
+
+hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s) {
+	// Few frames: shorter bands so a single frame still spreads over the chip.
+	uint32_t RB = MAP_RB_MAX;
+	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
+	const dim3 grid((g.rh + RB - 1) / RB, n);
+	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
+	else hipLaunchKernelGGL(k_map_pass<false>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
+	return hipGetLastError();
+}
+
+hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s) {
+	const dim3 grid((g.qh + BRQ_RB - 1) / BRQ_RB, n);
+	hipLaunchKernelGGL(k_brq_pass, grid, dim3(g.q_block), 0, s, g, b, flags, fixed_start_y, use_anchor_start);
+	return hipGetLastError();
+}
+
+}  // namespace smh
