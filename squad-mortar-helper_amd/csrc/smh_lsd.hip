@@ -63,6 +63,9 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 // Window of the bit-packed mask.  In LDS it is the bounding box of the set bits plus a one-word /
 // one-row border of zeros, and coordinates are clamped into it, so any read outside the box yields
 // 0 without a branch.  In the global-memory fallback (box larger than LDS) it is the whole mask.
+typedef __attribute__((address_space(3))) uint32_t LdsWord;
+typedef __attribute__((address_space(3))) char LdsByte;
+
 struct Win {
 	const uint32_t *p;
 	uint32_t pitch4;                  // row pitch in BYTES
@@ -76,7 +79,7 @@ struct Win {
 	// LSD_MODE_GLOBAL only: LDS copy of mask rows [c_y0, c_y0 + c_rows) in the global layout (same word columns);
 	// every read tries it first.  The rows around the candidates being cast are kept resident (lsd_frame), so only
 	// the long rays of phase B ever fall through to global memory.  c_rows == 0: no cache.
-	const uint32_t *c_p;
+	const LdsWord *c_p;               // explicitly an LDS pointer: its reads must stay ds_read, apart from the global ones
 	uint32_t c_y0, c_rows, c_pitch4;
 };
 
@@ -100,7 +103,7 @@ __device__ __forceinline__ uint32_t win_raw(const Win &m, int xi, int yi) {   //
 	const uint32_t rc = min((uint32_t)(X >> 5), m.cols_hi);
 	uint32_t word;
 	const uint32_t cr = ry - m.c_y0;                       // GLOBAL: y_lo = 0, ry is the image row
-	if (CACHED && cr < m.c_rows) word = *(const uint32_t *)((const char *)m.c_p + __umul24(cr, m.c_pitch4) + (rc << 2));
+	if (CACHED && cr < m.c_rows) word = *(const LdsWord *)((const LdsByte *)m.c_p + __umul24(cr, m.c_pitch4) + (rc << 2));
 	else word = *(const uint32_t *)((const char *)m.p + __umul24(ry, m.pitch4) + (rc << 2));
 	return word >> ((uint32_t)X & 31u);
 }
@@ -114,7 +117,7 @@ __device__ __forceinline__ uint32_t win_word(const Win &m, int wq, int yi) {
 	uint32_t v = 0;
 	if (ry <= m.rows_hi && rc <= m.cols_hi) {
 		const uint32_t cr = ry - m.c_y0;
-		if (cr < m.c_rows) v = *(const uint32_t *)((const char *)m.c_p + __umul24(cr, m.c_pitch4) + (rc << 2));
+		if (cr < m.c_rows) v = *(const LdsWord *)((const LdsByte *)m.c_p + __umul24(cr, m.c_pitch4) + (rc << 2));
 		else v = *(const uint32_t *)((const char *)m.p + __umul24(ry, m.pitch4) + (rc << 2));
 	}
 	return v;
@@ -542,7 +545,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	Win m;
 	m.w = g.rw; m.h = g.rh; m.wf = (float)g.rw; m.hf = (float)g.rh;
 	m.rows0 = nullptr; m.ylo_f = 0.0f; m.yhi_f = 0.0f;
-	m.c_p = smem; m.c_y0 = 0u; m.c_rows = 0u; m.c_pitch4 = 0u;
+	m.c_p = (const LdsWord *)smem; m.c_y0 = 0u; m.c_rows = 0u; m.c_pitch4 = 0u;
 	uint32_t *list, *queue;
 	// compaction domain: wrows x wwords words; word (r, c) holds pixels x = xorg + 32 c + [0,32) of image row wy0 + r
 	uint32_t wy0, wrows, wwords;
@@ -596,7 +599,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	}
 	// GLOBAL: (re)load the row cache so that it covers rows [lo, hi] (a uniform decision; hi - lo < rows that fit)
 	const uint32_t c_pitch = g.bits_pitch_w | 1u, c_cap_rows = min(g.rh, LSD_WIN_WORDS_CAP / c_pitch);
-	auto cache_cover = [&](int lo, int hi) {
+	auto cache_cover = [&](int lo, int hi) __attribute__((always_inline)) {
 		if (MODE != LSD_MODE_GLOBAL) return;
 		lo = max(lo, 0); hi = min(hi, (int)g.rh - 1);
 		if (m.c_rows && lo >= (int)m.c_y0 && hi < (int)(m.c_y0 + m.c_rows)) return;

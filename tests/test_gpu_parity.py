@@ -714,3 +714,25 @@ def test_ingest_queue_dedupes_like_the_capture_thread_and_feeds_the_batch(vision
     with pytest.raises(smh.VisionError):
         q.batch()
     q.close()
+
+
+def test_stress_4k_sparse_candidates_exceed_the_row_cache(vision):
+    """3840x2160: the mask does not fit LDS, k_lsd keeps a sliding cache of 434 rows.  Isolated marker pixels every
+    ~90 rows make a speculative group of 8 candidates span more rows than the cache (the group is cut short and
+    the rest handed back), and two long lines run the whole height (their long rays read outside the cache)."""
+    W, H = 3840, 2160
+    frame, (x, y, rw, rh) = _blank(W, H, 61)
+    rng = np.random.default_rng(61)
+    for k, yy in enumerate(range(30, rh - 30, 90)):
+        frame[y + yy, x + 40 + int(rng.integers(0, rw - 80))] = GREEN if k % 2 else PURPLE
+    for k in range(rh - 200):                                  # two steep lines, 3 px wide
+        frame[y + 100 + k, x + 300 + k // 7:x + 303 + k // 7] = GREEN
+        frame[y + 100 + k, x + rw - 300 - k // 5:x + rw - 297 - k // 5] = PURPLE
+    ref = _check_markers(vision, frame)
+    assert len(ref["lines"]) >= 2 and ref["rounds"] > 20
+    # Vision::find_longest_line from points far apart in y (the cache is re-centred per call)
+    lsd = vision.lsd_image()
+    for p in [(303.0, 110.0), (float(rw - 301), 105.0), (300.0 + (rh - 300) // 7, float(rh - 120)), (50.0, 50.0)]:
+        line, ln = vision.find_longest_line(p, 15.0)
+        rl, rn = o.find_longest_line(lsd, p[0], p[1], 15.0)
+        assert np.array_equal(line, rl) and ln == rn, (p, line, rl)
