@@ -1,0 +1,61 @@
+"""Throughput on the reference's own sample screenshots (tests/golden fixtures rebuilt into 2560x1440 frames), next
+to the synthetic workload of bench.py: a batch of 128 frames cycling the open-map 1440p fixtures, full marker pipeline
+(button, ui_map, mask + dilation, LSD); GPU results are checked against the C oracle on every distinct frame."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import fixtures as fx
+import squad_mortar_helper_amd as smh
+from oracle import oracle as orc   # checker + CPU timing only
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    frames, stems = [], []
+    for stem in fx.OPEN_STEMS:
+        f, e, g = fx.load_fixture(stem)
+        if f.shape[:2] == (1440, 2560):
+            frames.append(f); stems.append(stem)
+    k = len(frames)
+    batch = np.stack([frames[i % k] for i in range(n)])
+    vision = smh.HipVision.init(0)
+    fbs = [smh.FrameBatch(vision, 2560, 1440, n) for _ in range(2)]
+    d = torch.from_numpy(batch).cuda()
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    streams[1].wait_stream(streams[0])
+    def step(i):
+        with torch.cuda.stream(streams[i % 2]):
+            fbs[i % 2].run(d.data_ptr(), n, stages=0x3, max_gap=15, stream=streams[i % 2].cuda_stream)
+    for i in range(4):
+        step(i)
+    torch.cuda.synchronize()
+    steps = 40
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    got = smh.results_to_dicts(fbs[0].read_results(0, n))
+    t1 = time.perf_counter()
+    ref = orc.process_batch(np.stack(frames), min(os.cpu_count() or 1, k), stages=0x3, max_gap=15)
+    cdt = time.perf_counter() - t1
+    ok = True
+    for i in range(n):
+        r = ref[i % k]
+        rl = np.array([[r.lines[a][b] for b in range(4)] for a in range(r.n_lines)], np.float32).reshape(-1, 4)
+        ok = ok and got[i]["n_lines"] == r.n_lines and np.array_equal(got[i]["lines"], rl) and got[i]["rounds"] == r.rounds
+    print("%d distinct 2560x1440 sample frames (%s ...), batch %d, stages ui_map+markers" % (k, ", ".join(stems[:3]), n))
+    print("rounds per frame: %s" % [int(r.rounds) for r in ref])
+    print("GPU: %.0f frames/s (%.3f ms per %d-frame step, two steps in flight); lines + rounds equal to the oracle: %s" % (n * steps / dt, dt / steps * 1e3, n, ok))
+    print("CPU oracle: %.1f frames/s on %d threads (%.2f s for %d frames)" % (k / cdt, min(os.cpu_count() or 1, k), cdt, k))
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

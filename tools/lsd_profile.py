@@ -6,10 +6,19 @@ import numpy as np, torch
 import squad_mortar_helper_amd as smh
 from squad_mortar_helper_amd import synth
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+SAMPLES = len(sys.argv) > 1 and sys.argv[1] == "samples"   # the reference's 2560x1440 sample screenshots instead of synthetic frames
+N = 128 if SAMPLES else (int(sys.argv[1]) if len(sys.argv) > 1 else 256)
+W, H = (2560, 1440) if SAMPLES else ((int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080))
 host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
-_, infos = synth.make_batch(W, H, N, out=host.numpy())
+if SAMPLES:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import fixtures as fx
+    fr = [f for f in (fx.load_fixture(s)[0] for s in fx.OPEN_STEMS) if f.shape[:2] == (H, W)]
+    for i in range(N):
+        host.numpy()[i] = fr[i % len(fr)]
+    infos = [dict(scales_start_y=0, anchors=[]) for _ in range(N)]
+else:
+    _, infos = synth.make_batch(W, H, N, out=host.numpy())
 d = host.cuda()
 v = smh.HipVision.init(0)
 fb = smh.FrameBatch(v, W, H, N)
