@@ -6,6 +6,8 @@
 // right at a threshold, so the reference's scalar f32 operation order (no FMA contraction, IEEE divide) is
 // part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
 // structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
+#include <atomic>
+
 #include "smh_device.h"
 
 namespace smh {
@@ -921,14 +923,18 @@ size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 bool lsd_rows_only(const Geom &g) { return (g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP; }
 
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk) {
-	static bool attr_set = false;
 	const unsigned lds_full = LSD_DYN_LDS_BYTES;
-	if (!attr_set) {
+	// more than 64 KB of dynamic LDS has to be allowed per function and per device
+	static std::atomic<uint64_t> attr_devices{0};
+	int dev = 0;
+	hipError_t e0 = hipGetDevice(&dev);
+	if (e0 != hipSuccess) return e0;
+	if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
 		hipError_t e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_GLOBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e != hipSuccess) return e;
-		attr_set = true;
+		if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 	}
 	// every non-empty frame of this size is a ROWS frame (lsd_mode_for): the other two kernels would only exit
 	const bool rows_only = mode == 0 && lsd_rows_only(g);
