@@ -338,8 +338,13 @@ struct LsdShared {
 	uint32_t cand_key[LSD_C];
 	uint32_t scan[LSD_NW];
 	uint32_t qtail, segnext, unit_next;
+	uint32_t nlive;                          // live units of the group, listed (in no particular order) in ulist
+	unsigned short ulist[LSD_UNITS];
 	unsigned long long live[LSD_C];          // units (64-ray sectors) of each candidate that have to be cast
 	float lines[SMH_LSD_MAX_LINES][4];
+#ifdef SMH_LSD_PROFILE
+	uint32_t exp_far, exp_units;
+#endif
 };
 
 // find_longest_line for nc candidates at once (start points in sh.cand_pt).  On return (after a
@@ -361,28 +366,29 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 #endif
 	const bool fast_gap = max_gap > 0.0f && max_gap <= 60000.0f;
 	const uint32_t T = fast_gap ? (uint32_t)ceilf(max_gap) : 0u;
-	const uint32_t nunits = nc * LSD_GROUPS;
+	const uint32_t nunits = nc * LSD_GROUPS, nlive = sh.nlive;
 
-	// ---- pass 1: first LSD_A_BATCHES x 32 samples of every ray; unit = (candidate, 64 consecutive angles).
+	// ---- pass 1: first LSD_A_BATCHES x 32 samples of every ray of the live units; unit = (candidate, 64 consecutive angles).
 	// Units cost one or two batches depending on the scene, so waves pull them from a shared counter
 	// (the next unit and its ray directions are fetched while the current one is walked).
-	uint32_t u = wave;                                     // first unit is static; sh.unit_next starts at LSD_NW
-	uint32_t un = 0;
-	if (lane == 0) un = atomicAdd(&sh.unit_next, 1u);
-	un = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
+	uint32_t pos = wave;                                   // first unit is static; sh.unit_next starts at LSD_NW
+	uint32_t pn = 0;
+	if (lane == 0) pn = atomicAdd(&sh.unit_next, 1u);
+	pn = (uint32_t)__builtin_amdgcn_readfirstlane((int)pn);
+	uint32_t u = pos < nlive ? sh.ulist[pos] : 0u;
 	RayDir nd = g_ray_table[min((u % LSD_GROUPS) * 64u + lane, (uint32_t)SMH_LSD_RAYS - 1u)];
-	for (; u < nunits; ) {
+	for (; pos < nlive; ) {
 		const uint32_t c = u / LSD_GROUPS, i = (u - c * LSD_GROUPS) * 64u + lane;
 		const bool valid = i < SMH_LSD_RAYS;
 		const float dx = __uint_as_float(nd.dx), dy = __uint_as_float(nd.dy);
 		const uint32_t ucur = u;
-		u = un;
-		if (u < nunits) {
+		pos = pn;
+		if (pos < nlive) {
+			u = sh.ulist[pos];
 			nd = g_ray_table[min((u % LSD_GROUPS) * 64u + lane, (uint32_t)SMH_LSD_RAYS - 1u)];
-			if (lane == 0) un = atomicAdd(&sh.unit_next, 1u);
-			un = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
+			if (lane == 0) pn = atomicAdd(&sh.unit_next, 1u);
+			pn = (uint32_t)__builtin_amdgcn_readfirstlane((int)pn);
 		}
-		if (!((sh.live[c] >> (ucur - c * LSD_GROUPS)) & 1ull)) continue;   // sector culling: this unit cannot hold an acceptable ray
 		const float xs = sh.cand_pt[c][0], ys = sh.cand_pt[c][1];
 		// the batched walker needs a start inside the image (always true for find_lines candidates)
 		const bool fast = fast_gap && in_image(m, xs, ys);
@@ -437,6 +443,10 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 		if (lane == 0) { sh.unit_kmax[ucur] = Kw; atomicMax(&sh.cand_kmax[c], Kw); atomicAdd(&sh.cand_steps[c], wsteps); }
 #ifdef SMH_LSD_PROFILE
 		if (prof_t) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[1] += _n - prof_last; prof_last = _n; }
+		{   // experiment: how many rays of the live units get anywhere near the acceptance length?
+			const uint32_t far = (uint32_t)__popcll(__ballot(valid && (status == RAY_CONTINUE || s.gk0 + s.gj >= 35u || steps >= 36u)));
+			if (lane == 0) { atomicAdd(&sh.exp_far, far); atomicAdd(&sh.exp_units, 1u); }
+		}
 #endif
 	}
 	__syncthreads();
@@ -445,7 +455,7 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 	// ---- phase B: the few long rays, packed 64 to a wave; always exact ----
 	const uint32_t Q = min(sh.qtail, LSD_QCAP);
 #ifdef SMH_LSD_PROFILE
-	if (prof_t) { prof_t[6] += sh.qtail; prof_t[7] += 1; }
+	if (prof_t) { prof_t[6] += sh.exp_far; prof_t[7] += sh.exp_units; }
 #endif
 	unsigned long long bkey[LSD_QPT];
 	float bxe[LSD_QPT], bye[LSD_QPT];
@@ -487,8 +497,8 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 
 	// ---- pass 2: exact end points for the units that can still hold the winner ----
 	if (fast_gap) {
-		for (uint32_t u2 = wave; u2 < nunits; u2 += LSD_NW) {
-			const uint32_t c = u2 / LSD_GROUPS;
+		for (uint32_t p2 = wave; p2 < nlive; p2 += LSD_NW) {
+			const uint32_t u2 = sh.ulist[p2], c = u2 / LSD_GROUPS;
 			const uint32_t kbar = sh.cand_kmax[c];
 			if (sh.unit_kmax[u2] + 2u < kbar) continue;        // wave-uniform
 			// find_lines only keeps a candidate whose best ray has len^2 > 2500 (lsd.rs:94).  With every
@@ -625,9 +635,9 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	};
 
 	if (mode == 1) {   // Vision::find_longest_line on an arbitrary point
-		if (tid < LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; }
+		if (tid < LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; sh.ulist[tid] = (unsigned short)tid; }
 		cache_cover((int)spy - (int)(c_cap_rows / 2u), (int)spy - (int)(c_cap_rows / 2u) + (int)c_cap_rows - 1);
-		if (tid == 0) { sh.live[0] = ~0ull; sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
+		if (tid == 0) { sh.live[0] = ~0ull; sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.nlive = LSD_GROUPS; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
 		__syncthreads();
 		ray_engine<MODE>(m, sh, queue, 1u, max_gap, true PROF_ARG);
 		if (tid == 0) {
@@ -714,7 +724,11 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				}
 				if (tid < nc * LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; }
 				if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; sh.live[tid] = cull ? 0ull : ~0ull; }
-				if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; }
+				if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; sh.nlive = 0u;
+#ifdef SMH_LSD_PROFILE
+					sh.exp_far = 0u; sh.exp_units = 0u;
+#endif
+				}
 				__syncthreads();
 				if (MODE == LSD_MODE_GLOBAL) {
 					// Keep the mask rows every candidate of this group can reach in pass 1 (64 samples), the culling scan and
@@ -782,6 +796,11 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					}
 					__syncthreads();
 				}
+				if (tid < nc * LSD_GROUPS) {                    // list the units that have to be cast
+					const uint32_t c = tid / LSD_GROUPS;
+					if ((sh.live[c] >> (tid - c * LSD_GROUPS)) & 1ull) sh.ulist[atomicAdd(&sh.nlive, 1u)] = (unsigned short)tid;
+				}
+				__syncthreads();
 				PROF_MARK(11);  // sector culling scan
 				ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);
 #ifdef SMH_LSD_PROFILE

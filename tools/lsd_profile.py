@@ -41,7 +41,7 @@ for r in recs:
     tot += p
 cyc = tot[TIMED].sum()
 print("sum over frames: " + ", ".join("%s %.1f%%" % (n, 100 * t / cyc) for n, t in ((names[i], tot[i]) for i in TIMED)))
-print("queued rays per group: %.1f, groups per frame %.1f" % (tot[6] / max(tot[7], 1), tot[7] / N))
+print("far rays per live unit: %.1f of 64 (live units per frame %.1f)" % (tot[6] / max(tot[7], 1), tot[7] / N))
 rows.sort(key=lambda x: -x[1][TIMED].sum())
 for rounds, p in rows[:5]:
     print("rounds %d total Mcycles(100MHz ticks?) %.2f " % (rounds, p[TIMED].sum() / 1e6), ["%.2f" % (x / 1e6) for x in p[TIMED]], "queued/group %.0f groups %d" % (p[6] / max(p[7], 1), p[7]))
