@@ -802,7 +802,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				}
 				__syncthreads();
 				PROF_MARK(11);  // sector culling scan
-				ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);
+				if (sh.nlive != 0u) ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);   // else every candidate of the group is rejected: cand_best = 0
 #ifdef SMH_LSD_PROFILE
 				prof_last = __builtin_amdgcn_s_memtime();
 #endif
