@@ -159,6 +159,9 @@ struct smhv_ctx {
 	smhv_batch *fb = nullptr;          // single-frame buffer set
 	// pinned staging
 	uint8_t *h_ocr = nullptr, *h_scales = nullptr;
+	// pinned staging for pitched device images (one per concurrent branch + one for the batch read-back, see copy_image_d2h)
+	uint8_t *h_stage[3] = {nullptr, nullptr, nullptr};
+	size_t h_stage_cap[3] = {0, 0, 0};
 	smhv_frame_result *h_res = nullptr;
 	FrameAux *h_aux = nullptr;
 	uint32_t *h_bars = nullptr;
@@ -286,6 +289,7 @@ extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
 	if (c->d_frame) (void)hipFree(c->d_frame);
 	if (c->h_ocr) (void)hipHostFree(c->h_ocr);
 	if (c->h_scales) (void)hipHostFree(c->h_scales);
+	for (int i = 0; i < 3; ++i) if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
 	if (c->h_res) (void)hipHostFree(c->h_res);
 	if (c->h_aux) (void)hipHostFree(c->h_aux);
 	if (c->h_bars) (void)hipHostFree(c->h_bars);
@@ -516,6 +520,22 @@ extern "C" SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, u
 	return SMHV_OK;
 }
 
+// Tight host copy (rows x width bytes) of a pitched device image.  hipMemcpy2D turns into one small transfer per row
+// when the row width is not a multiple of 4 bytes (measured: 4 ms for the 657 x 548 ocr image, 10 us per row), so the
+// padded rows come over in ONE transfer into pinned staging `slot` and are repacked on the host.
+static int copy_image_d2h(smhv_ctx *c, int slot, uint8_t *dst, const uint8_t *d_rows, size_t pitch, size_t xoff, size_t width, size_t rows, hipStream_t s) {
+	const size_t bytes = pitch * rows;
+	if (c->h_stage_cap[slot] < bytes) {
+		if (c->h_stage[slot]) { (void)hipHostFree(c->h_stage[slot]); c->h_stage[slot] = nullptr; c->h_stage_cap[slot] = 0; }
+		HIPCHK(hipHostMalloc((void **)&c->h_stage[slot], bytes, hipHostMallocDefault));
+		c->h_stage_cap[slot] = bytes;
+	}
+	HIPCHK(hipMemcpyAsync(c->h_stage[slot], d_rows, bytes, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	for (size_t r = 0; r < rows; ++r) memcpy(dst + r * width, c->h_stage[slot] + r * pitch + xoff, width);
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t frame, uint8_t *out) {
 	if (!b || !out || frame >= b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
 	const Geom &g = b->g;
@@ -525,15 +545,18 @@ extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t
 	case 100:
 		HIPCHK(hipMemcpy2D(out, (size_t)g.rw * 4, b->d_ui + frame * g.ui_stride + (size_t)g.m_xoff * 4, g.ui_pitch, (size_t)g.rw * 4, g.rh, hipMemcpyDeviceToHost));
 		break;
-	case SMHV_VIEW_LSD_INPUT:
-		HIPCHK(hipMemcpy2D(out, g.rw, b->d_mask + frame * g.mask_stride + g.m_xoff, g.mask_pitch, g.rw, g.rh, hipMemcpyDeviceToHost));
-		break;
-	case SMHV_VIEW_OCR_INPUT:
-		HIPCHK(hipMemcpy2D(out, g.qw, b->d_ocr + frame * g.ocr_stride + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost));
-		break;
-	case SMHV_VIEW_FIND_SCALES_INPUT:
-		HIPCHK(hipMemcpy2D(out, g.qw, b->d_scales + frame * g.ocr_stride + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost));
-		break;
+	case SMHV_VIEW_LSD_INPUT: {
+		std::lock_guard<std::mutex> lk(b->ctx->mu);
+		return copy_image_d2h(b->ctx, 2, out, b->d_mask + frame * g.mask_stride, g.mask_pitch, g.m_xoff, g.rw, g.rh, b->ctx->s_main);
+	}
+	case SMHV_VIEW_OCR_INPUT: {
+		std::lock_guard<std::mutex> lk(b->ctx->mu);
+		return copy_image_d2h(b->ctx, 2, out, b->d_ocr + frame * g.ocr_stride, g.ocr_pitch, g.q_xoff, g.qw, g.qh, b->ctx->s_main);
+	}
+	case SMHV_VIEW_FIND_SCALES_INPUT: {
+		std::lock_guard<std::mutex> lk(b->ctx->mu);
+		return copy_image_d2h(b->ctx, 2, out, b->d_scales + frame * g.ocr_stride, g.ocr_pitch, g.q_xoff, g.qw, g.qh, b->ctx->s_main);
+	}
 	default:
 		return fail(SMHV_E_INVALID, "unsupported image id %d", which);
 	}
@@ -656,8 +679,8 @@ extern "C" SMHV_API int smhv_ocr_preprocess(smhv_ctx *c, const uint8_t **out, si
 	Buffers bf = make_buffers(b, c->frame_ptr, 1);
 	hipStream_t s = c->s_scales;
 	HIPCHK(launch_brq_pass(g, bf, 1, BRQ_OCR, 0, 0, s));
-	HIPCHK(hipMemcpy2DAsync(c->h_ocr, g.qw, b->d_ocr + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	rc = copy_image_d2h(c, 1, c->h_ocr, b->d_ocr, g.ocr_pitch, g.q_xoff, g.qw, g.qh, s);
+	if (rc) return rc;
 	*out = c->h_ocr; *len = (size_t)g.qw * g.qh;
 	return SMHV_OK;
 }
@@ -672,8 +695,8 @@ extern "C" SMHV_API int smhv_find_scales_preprocess(smhv_ctx *c, uint32_t scales
 	Buffers bf = make_buffers(b, c->frame_ptr, 1);
 	hipStream_t s = c->s_scales;
 	HIPCHK(launch_brq_pass(g, bf, 1, BRQ_SCALES, scales_start_y, 0, s));
-	HIPCHK(hipMemcpy2DAsync(c->h_scales, g.qw, b->d_scales + g.q_xoff, g.ocr_pitch, g.qw, g.qh, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	rc = copy_image_d2h(c, 1, c->h_scales, b->d_scales, g.ocr_pitch, g.q_xoff, g.qw, g.qh, s);
+	if (rc) return rc;
 	c->scales_valid = true;
 	if (out) *out = c->h_scales;
 	if (w) *w = g.qw;
@@ -718,8 +741,8 @@ extern "C" SMHV_API int smhv_get_lsd_image(smhv_ctx *c, uint8_t *out, uint32_t *
 	if (w) *w = g.rw;
 	if (h) *h = g.rh;
 	if (out) {
-		HIPCHK(hipMemcpy2DAsync(out, g.rw, c->fb->d_mask + g.m_xoff, g.mask_pitch, g.rw, g.rh, hipMemcpyDeviceToHost, c->s_markers));
-		HIPCHK(hipStreamSynchronize(c->s_markers));
+		rc = copy_image_d2h(c, 0, out, c->fb->d_mask, g.mask_pitch, g.m_xoff, g.rw, g.rh, c->s_markers);
+		if (rc) return rc;
 	}
 	return SMHV_OK;
 }

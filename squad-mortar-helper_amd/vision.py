@@ -42,6 +42,7 @@ class HipVision:
         L.check(self._lib.smhv_init(device, self._log_cb, C.byref(ctx)))
         self._ctx = ctx
         self._frame = None
+        self._size = None
         self._roi = None
 
     # -- trait: init / thread_ctx / shutdown --------------------------------------------------
@@ -72,19 +73,22 @@ class HipVision:
         h, w, _ = image.shape
         L.check(self._lib.smhv_load_frame(self._ctx, image.ctypes.data, w, h))
         self._frame = image
+        self._size = (w, h)
 
     def load_frame_device(self, data_ptr, w, h):
+        """Frame already in HBM (e.g. a slab frame of IngestQueue.batch()); get_cpu_frame() is then None."""
         L.check(self._lib.smhv_load_frame_device(self._ctx, C.c_void_p(data_ptr), w, h))
         self._frame = None
+        self._size = (int(w), int(h))
 
     def get_cpu_frame(self):
         return self._frame
 
     def crop_to_map(self, grayscale=True):
         """-> None when the map is closed, else (ui_map uint8[h,w,4] RGBA, [x,y,w,h])."""
-        if self._frame is None:
+        if getattr(self, "_size", None) is None:
             raise L.VisionError(L.E_INVALID, "crop_to_map called before load_frame")
-        h, w, _ = self._frame.shape
+        w, h = self._size
         _, _, rw, rh = map_bounds(w, h)
         ui = np.empty((rh, rw, 4), np.uint8)
         is_open = C.c_int()

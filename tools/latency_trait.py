@@ -1,0 +1,40 @@
+"""Per-frame latency of the drop-in (trait) path: VisionState.process on the reference's 2560x1440 sample screenshots,
+one frame at a time as the reference's vision thread runs it (src/vision/mod.rs:36-240), next to the C oracle."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import fixtures as fx
+import squad_mortar_helper_amd as smh
+from oracle import oracle as orc   # CPU timing only
+
+
+def main():
+    vision = smh.HipVision.init(0)
+    state = smh.VisionState()
+    rows = []
+    for stem in ("point_intersect_png", "points_intersect_png", "snowpoints_png", "fullmap_jpg", "whiteout_png"):
+        frame, e, g = fx.load_fixture(stem)
+        labels = [(300, 594, 433), (900, 594, 465)]                    # label anchors as OCR would deliver them
+        for _ in range(3):
+            state.process(vision, frame, ocr_labels=labels)
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            res = state.process(vision, frame, ocr_labels=labels)
+        gpu_ms = (time.perf_counter() - t0) / n * 1e3
+        t0 = time.perf_counter()
+        ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=433)
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        same = res is not None and np.array_equal(res.markers, ref["lines"])
+        rows.append((stem, frame.shape[1], frame.shape[0], ref["rounds"], ref["n_lines"], gpu_ms, cpu_ms, same))
+    for r in rows:
+        print("%-22s %dx%d rounds %4d lines %2d  trait path %.2f ms/frame  C oracle (1 thread) %.1f ms  lines equal: %s" % r)
+
+
+if __name__ == "__main__":
+    main()
