@@ -705,6 +705,13 @@ def test_ingest_queue_dedupes_like_the_capture_thread_and_feeds_the_batch(vision
         assert r.map_open == 1 and np.array_equal(lines, ref["lines"])
     for i, f in enumerate(want):
         assert smh.crc32_device(vision, ptr + i * nb, nb) == zlib.crc32(f.tobytes())
+    # a slab frame feeds the per-call trait path without a host copy (capture.rs hand-off -> load_frame_device)
+    vision.load_frame_device(ptr + 1 * nb, W, H)
+    ui, roi = vision.crop_to_map(True)
+    vision.isolate_map_markers(); vision.mask_marker_lines()
+    refb = o.process_frame(want[1], stages=0x3, want_images=True)
+    assert np.array_equal(ui, refb["ui_map"]) and np.array_equal(vision.find_marker_lines(15), refb["lines"])
+    assert vision.get_cpu_frame() is None
     # next slab: dedupe continues against the last accepted frame (C), and the capacity limit is an error, not a drop
     q.reset()
     for f in (Cc, A, B, A, B):
