@@ -863,9 +863,10 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	PROF_STORE(res);
 }
 
-// One kernel per mask residency mode, launched back to back over all frames: a workgroup whose frame
-// needs another mode exits at once.  Split this way the common ROWS kernel carries no call to the rarely
-// used variants, needs 104 VGPRs and no scratch (the three-in-one kernel needed 128 and spilled at its call sites).
+// One kernel per mask residency mode, each over all frames: a workgroup whose frame needs another mode exits at
+// once (launch_lsd runs them side by side, or only the ROWS one when the frame size guarantees it).  Split this way
+// the common ROWS kernel carries no call to the rarely used variants: 113 VGPRs and no scratch, where a kernel
+// holding all three needed 128 and spilled at its call sites.
 __device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux) {
 	int lmode = LSD_MODE_GLOBAL;                           // also the empty-mask single-round case
 	if (aux.n_mask_px != 0) {
