@@ -5,7 +5,7 @@
  * and bench.py's `cpu_baseline` leg may load it; the product (libsmh_vision_hip.so) never
  * links, loads or falls back to anything in oracle/.
  *
- * Parity status: the reference ships NO asserting tests / golden vectors for this path
+ * Parity status: PARITY UNPINNED by the reference -- it ships NO asserting tests / golden vectors for this path
  * (SURVEY.md section 4), and its Rust sources cannot be compiled here (no rustc/cargo).
  * The restatement is therefore pinned by (a) the expected ROI geometry / workload counts /
  * line lists recorded by an independent numpy probe in SURVEY.md Appendix B, and (b) the
