@@ -277,3 +277,68 @@ def test_crc32_restatement_and_capture_dedupe_rule():
     assert keep.tolist() == [True, False, True, False, True, True, False, True] and last == 9
     keep, last = o.capture_dedupe([0, 0, 3])                # a first frame whose CRC is 0 is dropped (initial value 0)
     assert keep.tolist() == [False, False, True] and last == 3
+
+
+def test_marker_predicate_second_restatement_all_colours():
+    """Independent second restatement (vectorised numpy float32, written from util/src/image.rs:159-187 and
+    vision-common/src/markers/mod.rs:17-54, sharing no code with the C oracle) of hsv + is_any_map_marker_color,
+    compared with the C oracle on all 2^24 colours.  The reference has no known-answer test for this; two
+    independently written restatements agreeing bit for bit is the strongest pin available here."""
+    table = o.marker_table()                                  # uint32[2^24 / 32], bit (r << 16 | g << 8 | b)
+    f32 = np.float32
+    teams = [(105, 100, 100), (285, 46, 85), (158, 60, 91)]
+    chunk = 1 << 21
+    for base in range(0, 1 << 24, chunk):
+        idx = np.arange(base, base + chunk, dtype=np.uint32)
+        r = ((idx >> 16) & 255).astype(f32) / f32(255.0)
+        g = ((idx >> 8) & 255).astype(f32) / f32(255.0)
+        b = (idx & 255).astype(f32) / f32(255.0)
+        mx = np.maximum(r, np.maximum(g, b)); mn = np.minimum(r, np.minimum(g, b))
+        delta = mx - mn
+        with np.errstate(divide="ignore", invalid="ignore"):
+            h = np.where(mx == mn, f32(0.0),
+                         np.where(mx == r, f32(60.0) * np.fmod((g - b) / delta, f32(6.0)),
+                                  np.where(mx == g, f32(60.0) * ((b - r) / delta + f32(2.0)), f32(60.0) * ((r - g) / delta + f32(4.0))))).astype(f32)
+            s = (f32(100.0) * delta) / mx
+        v = f32(100.0) * mx
+        hm = np.fmod(h, f32(360.0))
+        hm = np.where(hm < 0, hm + f32(360.0), hm)
+        H = np.nan_to_num(hm, nan=0.0).astype(np.int64)        # `as u16`: truncation, NaN -> 0 (values are in range)
+        S = np.nan_to_num(s, nan=0.0).astype(np.int64)
+        V = v.astype(np.int64)
+        hit = np.zeros(chunk, bool)
+        for mh, ms, mv in teams:
+            sat_ok = (np.abs(ms - S) <= 15) | (np.abs(S - (ms - 50)) <= 15)
+            hit |= (np.abs(mh - H) <= 15) & sat_ok & (np.abs(mv - V) <= 15)
+        hit &= S >= 35
+        want = ((table[idx >> 5] >> (idx & 31)) & 1).astype(bool)
+        assert np.array_equal(hit, want), "first difference at colour %06x" % int(idx[np.nonzero(hit != want)[0][0]])
+
+
+def test_lsd_second_restatement_matches_the_c_oracle():
+    """tests/independent_lsd.py (numpy, vectorised over rays, written separately from the reference sources) against
+    the C oracle: find_longest_line on assorted points / gaps, and whole find_lines runs on a hand-made mask and on
+    the dilated masks of two sample screenshots (7 and 79 rounds)."""
+    import independent_lsd as ind
+    rng = np.random.default_rng(12)
+    img = np.zeros((180, 260), np.uint8)
+    for k in range(150):                                        # a thick diagonal, a horizontal dashed line, a blob, noise
+        img[20 + k // 2:23 + k // 2, 30 + k:33 + k] = 255
+    for k in range(0, 200, 23):
+        img[140:143, 20 + k:20 + k + 12] = 255
+    img[60:80, 200:222] = 255
+    img[rng.integers(0, 180, 40), rng.integers(0, 260, 40)] = 255
+    pts = [(31.0, 21.0), (100.5, 55.0), (210.0, 70.0), (25.0, 141.0), (0.0, 0.0), (259.0, 179.0), (130.25, 90.75)]
+    for gap in (15.0, 3.0, 0.0, 40.0):
+        for (x, y) in pts:
+            la, na = ind.find_longest_line(img, x, y, gap)
+            lb, nb = o.find_longest_line(img, x, y, gap)
+            assert np.array_equal(la, lb) and na == nb, (x, y, gap, la, lb, na, nb)
+    la, ra = ind.find_lines(img, 15)
+    lb, st = o.find_lines(img, 15)
+    assert np.array_equal(la, lb) and ra == st["rounds"]
+    for stem in ("points_intersect_png", "point_intersect_png"):
+        frame, e, g = fx.load_fixture(stem)
+        ref = o.process_frame(frame, stages=0x1, want_images=True)
+        la, ra = ind.find_lines(ref["lsd"], 15)
+        assert np.array_equal(la, ref["lines"]) and ra == ref["rounds"], stem
