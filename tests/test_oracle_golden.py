@@ -342,3 +342,42 @@ def test_lsd_second_restatement_matches_the_c_oracle():
         ref = o.process_frame(frame, stages=0x1, want_images=True)
         la, ra = ind.find_lines(ref["lsd"], 15)
         assert np.array_equal(la, ref["lines"]) and ra == ref["rounds"], stem
+
+
+def test_brq_stages_second_restatement():
+    """Independent numpy restatement of ocr_preprocess / find_scales_preprocess (vision-cpu/src/lib.rs:39-53,173-251,
+    image 0.23.14 luma) against the C oracle: threshold-heavy random quadrants and a real sample's quadrant."""
+    f32 = np.float32
+
+    def luma(rgb):
+        l = f32(0.2126) * rgb[..., 0].astype(f32) + f32(0.7152) * rgb[..., 1].astype(f32) + f32(0.0722) * rgb[..., 2].astype(f32)
+        return l.astype(np.uint8)                               # NumCast f32 -> u8 truncates
+
+    def ocr(rgb):
+        h, w, _ = rgb.shape
+        c = rgb.astype(np.int32)
+        mono = 2 * (np.abs(c[..., 0] - c[..., 1]) + np.abs(c[..., 0] - c[..., 2]) + np.abs(c[..., 1] - c[..., 2]))   # 9 ordered pairs
+        W = (mono <= 3) & (c.min(axis=2) >= 200)
+        E = (mono <= 48) & (c.min(axis=2) >= 130)
+        Wn = W.copy()
+        Wn[:, w - 2:] = False; Wn[h - 2:, :] = False             # neighbour ranges stop at min(x + 3, w - 3) / min(y + 3, h - 3)
+        pad = np.zeros((h + 6, w + 6), bool); pad[3:h + 3, 3:w + 3] = Wn
+        near = np.zeros((h, w), bool)
+        for dy in range(7):
+            for dx in range(7):
+                near |= pad[dy:dy + h, dx:dx + w]
+        keep = W | (E & near)
+        return np.where(keep, 255 - luma(rgb), 255).astype(np.uint8)
+
+    rng = np.random.default_rng(8)
+    for (h, w) in ((61, 83), (40, 40), (7, 9)):
+        g = rng.choice([128, 129, 130, 131, 198, 199, 200, 201, 255, 0, 1, 2], (h, w))[..., None] + rng.integers(-13, 14, (h, w, 3)) * (rng.random((h, w, 1)) < 0.6)
+        rgb = np.clip(g, 0, 255).astype(np.uint8)
+        assert np.array_equal(ocr(rgb), o.ocr_preprocess(rgb)), (h, w)
+        for start in (0, 5, h):
+            want = np.where(luma(rgb) != 0, 255, 0).astype(np.uint8)
+            got = o.find_scales_preprocess(rgb, start)
+            assert np.array_equal(got[start:], want[start:]) and not got[:start].any()
+    frame, e, g_ = fx.load_fixture("point_intersect_png")
+    brq = o.crop_to_map(frame)["cropped_brq"]
+    assert np.array_equal(ocr(brq), o.ocr_preprocess(brq))
