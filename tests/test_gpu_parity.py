@@ -413,7 +413,7 @@ def test_stress_filled_areas_overflow_the_long_ray_queue(vision):
     _check_markers(vision, frame)
 
 
-@pytest.mark.parametrize("max_gap", [1, 2, 7, 22, 31, 32, 40, 100])
+@pytest.mark.parametrize("max_gap", [0, 1, 2, 7, 22, 31, 32, 40, 49, 50, 100])
 def test_stress_max_gap_values(vision, max_gap):
     """Gap thresholds around the 32-sample batch size (T <= 31: bit-trick state machine, T > 31: run loop)."""
     from squad_mortar_helper_amd import synth
