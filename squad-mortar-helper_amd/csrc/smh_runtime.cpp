@@ -373,7 +373,7 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	}
 	if (b->ev) {
 		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
-			for (int i = 0; i < smhv_batch::TIMING_EVENTS; ++i) (void)hipEventDestroy(b->ev[r][i]);
+			for (int i = 0; i < smhv_batch::TIMING_EVENTS; ++i) if (b->ev[r][i]) (void)hipEventDestroy(b->ev[r][i]);
 		delete[] b->ev;
 	}
 	if (b->s_scales) (void)hipStreamDestroy(b->s_scales);
@@ -407,7 +407,7 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 	if (!b) return fail(SMHV_E_INVALID, "null batch");
 	if (enable && !b->ev) {
 		HIPCHK(hipSetDevice(b->ctx->device));
-		b->ev = new hipEvent_t[smhv_batch::TIMING_RING][smhv_batch::TIMING_EVENTS];
+		b->ev = new hipEvent_t[smhv_batch::TIMING_RING][smhv_batch::TIMING_EVENTS]();   // zeroed: destroy skips what was never created
 		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
 			for (int i = 0; i < smhv_batch::TIMING_EVENTS; ++i) HIPCHK(hipEventCreate(&b->ev[r][i]));
 	}
