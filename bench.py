@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-box testing of the N>1 code path)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
+    ap.add_argument("--no-stream-tuning", action="store_true", help="keep the default stream assignment of the pipelined steps")
     ap.add_argument("--ingest-frames", type=int, default=512,
                     help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1 only)")
     ap.add_argument("--pipeline-depth", type=int, default=2,
@@ -180,6 +181,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()           # all streams of the device
 
+    # ---- stream assignment (untimed) ----
+    # A process has four hardware queues; HIP deals its streams onto them in creation order, and when the main stream
+    # of one pipelined step shares a queue with a branch of the other, the two steps stop overlapping (measured: 214 k
+    # instead of 320 k frames/s, depending only on how many streams the process happened to create before).  So a
+    # few assignments of torch pool streams to (main stream of steps 1.., scales branch of every step) are tried, the
+    # library-owned streams included, and the fastest is kept.
+    tuning = None
+    if depth > 1 and not args.no_stream_tuning:
+        pool = [torch.cuda.Stream() for _ in range(2 * depth + 4)]
+        for st in pool:
+            st.wait_stream(streams[0])
+        own_main = list(streams)
+
+        def assign(j):
+            if j < 0:                                          # the library's own scales streams
+                streams[:] = own_main
+                for b in fbs:
+                    b.set_scales_stream(0)
+            else:
+                for k in range(1, depth):
+                    streams[k] = pool[j + k - 1]
+                for k, b in enumerate(fbs):
+                    b.set_scales_stream(pool[j + depth - 1 + k].cuda_stream)
+
+        def plain_step(i):
+            k = i % depth
+            with torch.cuda.stream(streams[k]):
+                fbs[k].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[k].cuda_stream)
+
+        trials = {}
+        for j in range(-1, 5):
+            assign(j)
+            for i in range(4):
+                plain_step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(16):
+                plain_step(i)
+            torch.cuda.synchronize()
+            trials[j] = (time.perf_counter() - t0) / 16 * 1e3
+        best = min(trials, key=trials.get)
+        assign(best)
+        tuning = {"tried_ms_per_step": {("library" if j < 0 else "pool+%d" % j): round(v, 4) for j, v in trials.items()},
+                  "chosen": "library" if best < 0 else "pool+%d" % best}
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -247,6 +293,8 @@ def main():
         "h2d_seconds_for_batch": h2d_s,
         "all_map_open": bool(all_open),
     }
+    if tuning is not None:
+        out["stream_assignment"] = tuning
     if stages_ms is not None:
         t_map = stages_ms["map_pass"] * 1e-3
         ach = n * map_bytes / t_map / 1e9 if t_map > 0 else 0.0

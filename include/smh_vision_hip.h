@@ -185,6 +185,10 @@ SMHV_API int smhv_batch_read_image(smhv_batch *b, int which /* SMHV_VIEW_* or 10
  * 64 most recent), measured with hipEvents on
  * the run's stream (the analogue of the reference's Timeshares, vision-common/src/debug.rs:3-30).
  * ms[0]=button ms[1]=map pass ms[2]=brq pass ms[3]=lsd ms[4]=scale ratio.  Synchronises. */
+/* Run the scales branch of smhv_batch_run on a caller-provided stream (NULL: the batch's own).  A process has only a few
+ * hardware queues; which HIP streams end up sharing one is decided by creation order, and two pipelined batches whose
+ * branches alias onto one queue lose their overlap -- a host that pipelines batches can pick the streams itself. */
+SMHV_API int smhv_batch_set_scales_stream(smhv_batch *b, void *stream);
 SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
 SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
 

@@ -75,6 +75,10 @@ class FrameBatch:
         a = C.cast(anchors, C.c_void_p) if anchors is not None else None
         L.check(self._lib.smhv_batch_run(self._b, C.c_void_p(frames_ptr), n, stages, int(bool(grayscale)), max_gap, a, C.c_void_p(stream)))
 
+    def set_scales_stream(self, stream=0):
+        """Scales branch on a caller-provided HIP stream (0: the batch's own); see smhv_batch_set_scales_stream."""
+        L.check(self._lib.smhv_batch_set_scales_stream(self._b, C.c_void_p(stream)))
+
     def stage_ms(self):
         ms = (C.c_float * 5)()
         L.check(self._lib.smhv_batch_stage_ms(self._b, ms))

@@ -141,6 +141,7 @@ struct smhv_batch {
 	// concurrent branches of VisionState::process (src/vision/mod.rs:219-223): fork after the button test, join
 	// before the record is finalised.
 	hipStream_t s_scales = nullptr;
+	hipStream_t s_scales_ext = nullptr;       // caller-provided stream for the scales branch (smhv_batch_set_scales_stream)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// the per-mode k_lsd kernels of frames larger than 1080p run side by side (smh_kernels.h, LsdFork)
 	LsdFork lsd_fork{};
@@ -453,7 +454,7 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	uint32_t qflags = 0;
 	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
 	if (scales) qflags |= BRQ_SCALES;
-	hipStream_t sq = b->s_scales;
+	hipStream_t sq = b->s_scales_ext ? b->s_scales_ext : b->s_scales;
 	if (qflags) {
 		// ---- scales branch, concurrent with the LSD of the markers branch.  It forks after the map pass: both
 		// are HBM streaming passes and gain nothing from sharing the chip, while the LSD launch (one workgroup
@@ -479,6 +480,12 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 #undef STAGE_BEGIN
 #undef STAGE_END
 	if (t) b->timed_runs++;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_set_scales_stream(smhv_batch *b, void *stream) {
+	if (!b) return fail(SMHV_E_INVALID, "null batch");
+	b->s_scales_ext = (hipStream_t)stream;                    // nullptr: back to the batch's own stream
 	return SMHV_OK;
 }
 
