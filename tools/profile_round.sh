@@ -11,7 +11,7 @@ R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0"
+B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-stream-tuning"   # profiled runs: only warm-up, timed and isolated launches
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_d1 -- $B --steps 10 --warmup 2 --pipeline-depth 1 > $OUT/${TAG}_bench_profiled_d1.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_d2 -- $B --steps 10 --warmup 2 > $OUT/${TAG}_bench_profiled_d2.json 2>/dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_fetch -- $B --steps 2 --warmup 1 --pipeline-depth 1 > /dev/null 2>&1
