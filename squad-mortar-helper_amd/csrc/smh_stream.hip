@@ -277,12 +277,19 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 
 	uint64_t Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
 	const int rs = max(r0 - 3, 0), re = min(r1 + 2, (int)g.qh - 1);
+	// software pipeline as in k_map_pass: the loads of the next four rows fly under the work on the current four
+	// (inactive lanes re-read quad 0 instead of diverging; their results are masked by vmask)
+	const uint8_t *lp = qact ? fp : fp - (size_t)q * 16;
+	uint4 nx[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
 	for (int r = rs; r <= re; r += 4) {
 		uint4 px[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int rr = min(r + k, re);
-			px[k] = qact ? *(const uint4 *)(fp + (size_t)rr * row_bytes) : make_uint4(0, 0, 0, 0);
+		for (int k = 0; k < 4; ++k) px[k] = nx[k];
+		if (r + 4 <= re) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(r + 4 + k, re) * row_bytes);
 		}
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
