@@ -3,6 +3,7 @@ committed goldens.  Integer outputs (pixels, masks, counts) must be bit-exact; t
 endpoints are compared bit-exactly too (same f32 operation order); derived f64/f32 lengths, meters
 and angles within the north star's 1e-4."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -743,3 +744,24 @@ def test_stress_4k_sparse_candidates_exceed_the_row_cache(vision):
         line, ln = vision.find_longest_line(p, 15.0)
         rl, rn = o.find_longest_line(lsd, p[0], p[1], 15.0)
         assert np.array_equal(line, rl) and ln == rn, (p, line, rl)
+
+
+def test_c_example_runs_the_trait_sequence_without_python(vision, tmp_path):
+    """examples/process_frame.c: the C ABI driven from plain C in its own process (no torch, no ctypes) on a sample
+    screenshot; the printed lines are the oracle's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "process_frame")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "process_frame.c"),
+                           "-L", os.path.join(root, "squad-mortar-helper_amd"), "-l:libsmh_vision_hip.so",
+                           "-Wl,-rpath," + os.path.join(root, "squad-mortar-helper_amd"), "-o", exe])
+    frame, e, g = fx.load_fixture("points_intersect_png")
+    raw = tmp_path / "frame.bgra"
+    frame.tofile(str(raw))
+    out = subprocess.run([exe, str(raw), str(frame.shape[1]), str(frame.shape[0])], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ref = o.process_frame(frame, stages=0x1)
+    got = [[float(v) for v in ln.replace("(", " ").replace(")", " ").replace("->", " ").replace(",", " ").split()]
+           for ln in out.stdout.splitlines() if ln.startswith("  (")]
+    assert len(got) == ref["n_lines"] == 7
+    assert np.allclose(np.array(got), ref["lines"], atol=0.051)            # printed with one decimal

@@ -158,3 +158,16 @@ def test_parse_ocr_labels_follows_the_reference_filter(built):
     assert parse_ocr_labels([dict(text="map", left=0, right=1, bottom=2)]) == ([], None)
     assert parse_ocr_labels([]) == ([], None)
     assert parse_ocr_labels([dict(text="4294967296m", left=0, right=2, bottom=9)]) == ([], None)   # overflows u32
+
+
+def test_header_is_plain_c_and_the_c_example_links(built, tmp_path):
+    """include/smh_vision_hip.h is a C ABI: it must compile as pedantic C99, and a plain C program must link against
+    the library with nothing but the header (examples/process_frame.c; it is run by a GPU test)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "examples", "process_frame.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), src])
+    exe = str(tmp_path / "process_frame")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), src, "-L", os.path.join(root, "squad-mortar-helper_amd"),
+                           "-l:libsmh_vision_hip.so", "-Wl,-rpath," + os.path.join(root, "squad-mortar-helper_amd"), "-o", exe])
+    assert os.path.exists(exe)
