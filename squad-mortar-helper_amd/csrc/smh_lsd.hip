@@ -50,15 +50,18 @@ __device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
 #define LSD_GROUPS ((SMH_LSD_RAYS + 63) / 64)      // 64-ray units per candidate (57)
 #define LSD_GROUPS_HOST 57
 #define LSD_UNITS (LSD_C * LSD_GROUPS)
-#define LSD_LIST_CAP 2048u
-#define LSD_QCAP 2048u
+#define LSD_LIST_CAP 1024u
+#define LSD_QCAP 1024u
 #define LSD_QPT (LSD_QCAP / LSD_BS)                   // queue entries per thread in phase B
 #define LSD_CACHE_MARGIN 72                         // rows around a candidate kept in the GLOBAL mode's LDS row cache (pass 1 walks 64 samples)
 #define LSD_A_BATCHES 2u                            // 32-sample batches walked in phase A before a ray is queued
 #define LSD_WIN_WORDS_CAP 27400u                   // 1080p whole ROI in ROWS mode = 824 rows x 33 words + 4 = 27196 words;
-// the rest of the 160 KB holds the candidate list, the ray queue, LsdShared and the sector culling table (12.7 KB).
-// (Nothing else shares the CU.  Tried: a workgroup small enough for a streaming workgroup of the next pipelined step to
-// co-reside -- measured 2 % slower overall and k_map_pass 0.52 -> 0.62 ms, the two compete for VALU issue.)
+// with the candidate list, the ray queue, LsdShared and the sector culling table (12.7 KB) a workgroup takes 146 KB.
+// That and the 96-VGPR cap on the kernels (amdgpu_waves_per_eu(5, 5): 4 waves x 96 of a SIMD's 512 registers, 48 bytes
+// of scratch) leave room for ONE streaming workgroup of the other pipelined step (k_map_pass: 10.5 KB of LDS, one
+// 96-VGPR wave per SIMD) on the same CU: k_lsd keeps its VALU busy 14 % of the time, so the HBM passes run underneath
+// it: +12 % frames/s at pipeline depth 2 (-3 % at depth 1, the spills).  (Before the sector culling, when this
+// kernel was VALU-bound, the same co-residency cost 2 %.)
 #define LSD_ROWS_PITCH(gp) ((gp) | 1u)                 // LDS row pitch (words) of LSD_MODE_ROWS
 #define LSD_DYN_LDS_BYTES ((LSD_WIN_WORDS_CAP + LSD_LIST_CAP + 2u * LSD_QCAP) * 4u)
 
@@ -878,7 +881,7 @@ __device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux) 
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(LSD_BS) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
+__global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ LsdShared sh;
 	__shared__ uint32_t cull_tab[SMH_CULL_TAB_WORDS];
