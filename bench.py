@@ -185,8 +185,8 @@ def main():
     # A process has four hardware queues; HIP deals its streams onto them in creation order, and when the main stream
     # of one pipelined step shares a queue with a branch of the other, the two steps stop overlapping (measured: 214 k
     # instead of 320 k frames/s, depending only on how many streams the process happened to create before).  So a
-    # few assignments of torch pool streams to (main stream of steps 1.., scales branch of every step) are tried, the
-    # library-owned streams included, and the fastest is kept.
+    # few assignments of torch pool streams to (main stream of steps 1.., scales branch of every step) are tried (48
+    # untimed steps each), the library-owned streams included, and the fastest is kept.
     tuning = None
     if depth > 1 and not args.no_stream_tuning:
         pool = [torch.cuda.Stream() for _ in range(2 * depth + 4)]
@@ -213,14 +213,14 @@ def main():
         trials = {}
         for j in range(-1, 5):
             assign(j)
-            for i in range(4):
+            for i in range(16):                                 # the pipelined schedule takes a few steps to settle
                 plain_step(i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(16):
+            for i in range(32):
                 plain_step(i)
             torch.cuda.synchronize()
-            trials[j] = (time.perf_counter() - t0) / 16 * 1e3
+            trials[j] = (time.perf_counter() - t0) / 32 * 1e3
         best = min(trials, key=trials.get)
         assign(best)
         tuning = {"tried_ms_per_step": {("library" if j < 0 else "pool+%d" % j): round(v, 4) for j, v in trials.items()},
