@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-box testing of the N>1 code path)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
+    ap.add_argument("--no-stagger", action="store_true", help="start the pipelined steps together instead of half a period apart")
     ap.add_argument("--no-stream-tuning", action="store_true", help="keep the default stream assignment of the pipelined steps")
     ap.add_argument("--ingest-frames", type=int, default=512,
                     help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1 only)")
@@ -166,8 +167,16 @@ def main():
 
     step_no = [0]
 
+    def stagger(i):
+        # First round after an idle device: step k starts its streaming pass when step k-1 has finished its own, so the
+        # steps run half a period apart from the outset (the streaming passes of one underneath the LSD of the other);
+        # started together they can lock into the schedule in which they stream together and then search together.
+        if not args.no_stagger and 0 < i < depth:
+            fbs[i - 1].wait_map_pass(streams[i].cuda_stream)
+
     def step():
         k = step_no[0] % depth
+        stagger(step_no[0])
         step_no[0] += 1
         with torch.cuda.stream(streams[k]):
             fbs[k].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[k].cuda_stream)
@@ -180,6 +189,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()           # all streams of the device
+        step_no[0] = 0                     # the device is idle: the next steps are a "first round" again
 
     # ---- stream assignment (untimed) ----
     # A process has four hardware queues; HIP deals its streams onto them in creation order, and when the main stream
@@ -207,6 +217,7 @@ def main():
 
         def plain_step(i):
             k = i % depth
+            stagger(i)
             with torch.cuda.stream(streams[k]):
                 fbs[k].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[k].cuda_stream)
 

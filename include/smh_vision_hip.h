@@ -189,6 +189,11 @@ SMHV_API int smhv_batch_read_image(smhv_batch *b, int which /* SMHV_VIEW_* or 10
  * hardware queues; which HIP streams end up sharing one is decided by creation order, and two pipelined batches whose
  * branches alias onto one queue lose their overlap -- a host that pipelines batches can pick the streams itself. */
 SMHV_API int smhv_batch_set_scales_stream(smhv_batch *b, void *stream);
+/* Make `stream` wait until the streaming pass (k_map_pass) of b's most recent smhv_batch_run has finished.  A host that
+ * pipelines two batches uses it once, before the second batch's first run, to start the two steps half a period apart:
+ * the streaming passes of one step then run underneath the line-segment kernel of the other (they share CUs), instead of
+ * both steps streaming and then both searching. */
+SMHV_API int smhv_batch_wait_map_pass(smhv_batch *b, void *stream);
 SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
 SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "smhv_batch_read_results": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(FrameResult)]),
     "smhv_batch_read_image": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
     "smhv_batch_set_scales_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "smhv_batch_wait_map_pass": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_batch_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "smhv_batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -79,6 +79,10 @@ class FrameBatch:
         """Scales branch on a caller-provided HIP stream (0: the batch's own); see smhv_batch_set_scales_stream."""
         L.check(self._lib.smhv_batch_set_scales_stream(self._b, C.c_void_p(stream)))
 
+    def wait_map_pass(self, stream=0):
+        """`stream` waits for the streaming pass of this batch's most recent run (see smhv_batch_wait_map_pass)."""
+        L.check(self._lib.smhv_batch_wait_map_pass(self._b, C.c_void_p(stream)))
+
     def stage_ms(self):
         ms = (C.c_float * 5)()
         L.check(self._lib.smhv_batch_stage_ms(self._b, ms))

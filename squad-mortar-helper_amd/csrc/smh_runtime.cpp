@@ -142,6 +142,7 @@ struct smhv_batch {
 	// before the record is finalised.
 	hipStream_t s_scales = nullptr;
 	hipStream_t s_scales_ext = nullptr;       // caller-provided stream for the scales branch (smhv_batch_set_scales_stream)
+	hipEvent_t ev_map_done = nullptr;         // recorded after the streaming pass of every run (smhv_batch_wait_map_pass)
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// the per-mode k_lsd kernels of frames larger than 1080p run side by side (smh_kernels.h, LsdFork)
 	LsdFork lsd_fork{};
@@ -341,6 +342,7 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 		hipError_t e = hipStreamCreateWithFlags(&b->s_scales, hipStreamNonBlocking);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_map_done, hipEventDisableTiming);
 		// Only for frame sizes that need them: a process has few hardware queues, and every extra stream makes it more
 		// likely that two independent branches share one (measured: 10 % off the pipelined 1080p throughput).
 		if (max_frames > 1 && !lsd_rows_only(b->g)) {
@@ -380,6 +382,7 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	if (b->s_scales) (void)hipStreamDestroy(b->s_scales);
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
 	if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+	if (b->ev_map_done) (void)hipEventDestroy(b->ev_map_done);
 	if (b->lsd_fork.s1) (void)hipStreamDestroy(b->lsd_fork.s1);
 	if (b->lsd_fork.s2) (void)hipStreamDestroy(b->lsd_fork.s2);
 	if (b->lsd_fork.fork) (void)hipEventDestroy(b->lsd_fork.fork);
@@ -451,6 +454,7 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	STAGE_BEGIN(1, s);
 	if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
 	STAGE_END(1, s);
+	HIPCHK(hipEventRecord(b->ev_map_done, s));
 	uint32_t qflags = 0;
 	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
 	if (scales) qflags |= BRQ_SCALES;
@@ -480,6 +484,13 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 #undef STAGE_BEGIN
 #undef STAGE_END
 	if (t) b->timed_runs++;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_wait_map_pass(smhv_batch *b, void *stream) {
+	if (!b) return fail(SMHV_E_INVALID, "null batch");
+	HIPCHK(hipSetDevice(b->ctx->device));
+	HIPCHK(hipStreamWaitEvent((hipStream_t)stream, b->ev_map_done, 0));   // no-op before the first run
 	return SMHV_OK;
 }
 
