@@ -90,8 +90,9 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 	uint4 nx[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
-	__shared__ uint32_t s_hit_px[16][64], s_hit_res[16][64];
-	__shared__ unsigned short s_hit_id[16][64];
+	// per-wave hit lists, sized by the launch (640 bytes per wave: 2.5 KB at 1080p, so that several of these workgroups fit
+	// into the LDS a k_lsd workgroup of the other pipelined step leaves free on its CU)
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_hits[];
 	for (int r = rs; r <= re; r += 4) {
 		uint4 px[4];
 		uint32_t prehits = 0;
@@ -133,9 +134,9 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 		// a 64-entry LDS list, every lane tests one of them, and the verdicts are scattered back with
 		// LDS atomic ORs.  (This path used to be 40 % of the kernel's time.)
 		if (do_mask && __any(prehits != 0u)) {
-			uint32_t *hpx = s_hit_px[wave];
-			uint32_t *hres = s_hit_res[wave];
-			unsigned short *hid = s_hit_id[wave];
+			uint32_t *hpx = s_hits + wave * 160u;
+			uint32_t *hres = hpx + 64;
+			unsigned short *hid = (unsigned short *)(hres + 64);
 			const uint32_t cnt = (uint32_t)__popc(prehits);
 			uint32_t incl = cnt;
 			for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
@@ -381,8 +382,9 @@ hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 	uint32_t RB = MAP_RB_MAX;
 	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
 	const dim3 grid((g.rh + RB - 1) / RB, n);
-	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
-	else hipLaunchKernelGGL(k_map_pass<false>, grid, dim3(g.m_block), 0, s, g, b, flags, RB);
+	const unsigned lds = (g.m_block / 64u) * 640u;             // 64 x (pixel, verdict, id) per wave
+	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, RB);
+	else hipLaunchKernelGGL(k_map_pass<false>, grid, dim3(g.m_block), lds, s, g, b, flags, RB);
 	return hipGetLastError();
 }
 
