@@ -567,6 +567,18 @@ def test_two_batches_in_flight_on_two_streams_do_not_interfere(vision):
         bb.run(db.data_ptr(), N, anchors=anc_b, stream=s2.cuda_stream)
     torch.cuda.synchronize()
     assert bytes(ba.read_results(0, N)) == ref_a and bytes(bb.read_results(0, N)) == ref_b
+    # the host-chosen stream assignment of bench.py: scales branches on caller streams, second step started half a
+    # period after the first (smhv_batch_set_scales_stream / smhv_batch_wait_map_pass)
+    s3, s4 = torch.cuda.Stream(), torch.cuda.Stream()
+    ba.set_scales_stream(s3.cuda_stream); bb.set_scales_stream(s4.cuda_stream)
+    for k in range(4):
+        ba.run(da.data_ptr(), N, anchors=anc_a, stream=s1.cuda_stream)
+        if k == 0:
+            ba.wait_map_pass(s2.cuda_stream)
+        bb.run(db.data_ptr(), N, anchors=anc_b, stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert bytes(ba.read_results(0, N)) == ref_a and bytes(bb.read_results(0, N)) == ref_b
+    ba.set_scales_stream(0); bb.set_scales_stream(0)
     ba.close(); bb.close()
 
 
