@@ -59,6 +59,13 @@ SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out);
 SMHV_API void smhv_shutdown(smhv_ctx *ctx);
 /* replaces Vision::thread_ctx (vision-gpu/src/lib.rs:154-165): binds the device to the calling thread */
 SMHV_API int smhv_thread_ctx(smhv_ctx *ctx);
+/* The 3600 ray directions of find_longest_line are `((i as f32) / 10.0).to_radians()` through the PLATFORM libm's
+ * cosf / sinf (vision-cpu/src/lib.rs:398-399), so the reference itself is not bit-stable across platforms.  The library
+ * ships the glibc 2.35 values (csrc/ray_table.inc): line end points are bit-exact against a Linux/glibc build of
+ * vision-cpu.  A host on another libm (Windows UCRT, musl, ...) passes its own f32::cos / f32::sin values here once
+ * after smhv_init to get the same guarantee against its own build.  dx, dy: 3600 floats each; applies to every context
+ * on this device; synchronises the device. */
+SMHV_API int smhv_set_ray_table(smhv_ctx *ctx, const float *dx, const float *dy);
 /* thread-local message of the last failing call on this thread ("" if none) */
 SMHV_API const char *smhv_last_error(void);
 
@@ -217,10 +224,13 @@ SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra);
 SMHV_API int smhv_ingest_commit(smhv_ingest *q);
 /* acquire + memcpy + commit for frames that live in ordinary host memory */
 SMHV_API int smhv_ingest_push(smhv_ingest *q, const uint8_t *bgra);
-/* wait for everything committed; *d_frames = slab of *n accepted frames (valid until reset + next commit);
- * *last_crc (optional) = CRC-32 of the last accepted frame.  SMHV_E_STATE if more than `capacity` frames were accepted. */
+/* wait for everything committed (or until the slab is full); *d_frames = slab of *n <= capacity accepted frames, valid
+ * until smhv_ingest_reset; *last_crc (optional) = CRC-32 of the last accepted frame.  Frames committed after the slab
+ * filled up are not lost: they stay queued in their staging slots (at most `slots` of them -- smhv_ingest_acquire
+ * returns SMHV_E_STATE when the slab is full and no slot is free) and go into the next slab after smhv_ingest_reset. */
 SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames, uint32_t *n, uint32_t *last_crc);
-/* start a new slab; the duplicate test keeps comparing with the last accepted frame */
+/* start a new slab (the consumer of the previous one must have finished with it); the duplicate test keeps comparing
+ * with the last accepted frame; frames still queued are resolved into the new slab by the next acquire / batch */
 SMHV_API int smhv_ingest_reset(smhv_ingest *q);
 SMHV_API int smhv_ingest_counts(smhv_ingest *q, uint64_t *n_new, uint64_t *n_dup);
 /* CRC-32/IEEE of nbytes (multiple of 4) of device memory; == crc32fast::hash / zlib crc32 of the same bytes */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "smhv_init": (C.c_int, [C.c_int, LOG_FN, C.POINTER(C.c_void_p)]),
     "smhv_shutdown": (None, [C.c_void_p]),
     "smhv_thread_ctx": (C.c_int, [C.c_void_p]),
+    "smhv_set_ray_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "smhv_last_error": (C.c_char_p, []),
     "smhv_map_bounds": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "smhv_button_bounds": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),

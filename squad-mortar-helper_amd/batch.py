@@ -16,7 +16,7 @@ def make_anchors(per_frame):
     """per_frame: list (len n) of (scales_start_y, [(meters, x, y), ...]) -> ctypes array of smhv_anchors."""
     arr = (L.Anchors * len(per_frame))()
     for i, (start_y, scales) in enumerate(per_frame):
-        arr[i].n = len(scales)
+        arr[i].n = min(len(scales), L.MAX_SCALES)
         arr[i].scales_start_y = start_y
         for j, (m, x, y) in enumerate(scales[:L.MAX_SCALES]):
             arr[i].scales[j][0], arr[i].scales[j][1], arr[i].scales[j][2] = m, x, y
@@ -72,6 +72,8 @@ class FrameBatch:
 
     def run(self, frames_ptr, n, stages=L.STAGE_ALL, grayscale=True, max_gap=15, anchors=None, stream=0):
         """frames_ptr: device address of n tightly packed BGRA8 frames.  Asynchronous on `stream`."""
+        if anchors is not None and len(anchors) < n:
+            raise ValueError("anchors holds %d entries, the run covers %d frames" % (len(anchors), n))
         a = C.cast(anchors, C.c_void_p) if anchors is not None else None
         L.check(self._lib.smhv_batch_run(self._b, C.c_void_p(frames_ptr), n, stages, int(bool(grayscale)), max_gap, a, C.c_void_p(stream)))
 

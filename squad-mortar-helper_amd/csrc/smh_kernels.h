@@ -82,6 +82,8 @@ hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, in
 hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
 size_t lsd_lds_bytes();
+// overwrite the 3600 ray directions of the current device's code object (synchronous)
+hipError_t set_ray_table(const float *dx, const float *dy);
 // CRC-32 of n_dwords 32-bit words at d_msg, xor-ed into *d_acc (zero it first) WITHOUT the init / final-xor terms:
 //   crc = *d_acc ^ crc32_mul(crc32_xpow(32 * n_dwords), 0xFFFFFFFF) ^ 0xFFFFFFFF.
 // wgs workgroups of SMH_CRC_BS threads, rounds * wgs * SMH_CRC_BS * 4 >= n_dwords; x_skip = x^(128 (G - 1)),

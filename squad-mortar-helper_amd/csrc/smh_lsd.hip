@@ -7,6 +7,7 @@
 // part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
 // structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
 #include <atomic>
+#include <cstring>
 
 #include "smh_device.h"
 
@@ -33,7 +34,9 @@ namespace smh {
 // tie rule and the sample counts.
 // ------------------------------------------------------------------------------------------------
 struct RayDir { uint32_t dx, dy; };
-__device__ const RayDir g_ray_table[SMH_LSD_RAYS] = {
+// Not const: smhv_set_ray_table lets a host whose libm is not glibc overwrite it with its own f32::cos / f32::sin values
+// (the reference's ray directions come from the platform libm, vision-cpu/src/lib.rs:398-399).
+__device__ RayDir g_ray_table[SMH_LSD_RAYS] = {
 #include "ray_table.inc"
 };
 
@@ -888,8 +891,13 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 	const uint32_t f = blockIdx.x;
 	const FrameAux aux = b.aux[f];
 	if (mode == 0) {
-		if (MODE == LSD_MODE_ROWS && threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
-		if (!aux.open || aux.n_mask_px == 0) return;
+		// Record ownership is exclusive: the three mode kernels may run concurrently on forked streams, so a frame's record is
+		// touched only by the kernel that owns the frame -- lsd_frame always stores n_lines / rounds / ray_steps at its end --
+		// and frames nobody searches (map closed, empty mask) are zeroed by the ROWS kernel alone.
+		if (!aux.open || aux.n_mask_px == 0) {
+			if (MODE == LSD_MODE_ROWS && threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
+			return;
+		}
 	}
 	if (lsd_mode_for(g, aux) != MODE) return;
 	lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh, cull_tab);
@@ -982,6 +990,12 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		}
 	}
 	return hipGetLastError();
+}
+
+hipError_t set_ray_table(const float *dx, const float *dy) {
+	static RayDir host[SMH_LSD_RAYS];
+	for (int i = 0; i < SMH_LSD_RAYS; ++i) { memcpy(&host[i].dx, &dx[i], 4); memcpy(&host[i].dy, &dy[i], 4); }
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_ray_table), host, sizeof host, 0, hipMemcpyHostToDevice);
 }
 
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s) {

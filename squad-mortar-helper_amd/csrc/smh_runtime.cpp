@@ -10,6 +10,7 @@
 // src/vision/hardware.rs:73-76).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -175,7 +176,20 @@ struct smhv_ctx {
 	uint32_t *sector_tab[SECTOR_CACHE] = {};
 	int sector_n = 0;
 	std::mutex mu;                      // serialises (re)allocation only
+	// Lifetime: batches and ingest queues hold a reference, so smhv_shutdown with children still alive releases the
+	// context's own resources and marks it closed, and the object itself goes with the last child (their destroy
+	// functions only need `device`).  Every entry point that takes a child checks `closed` first.
+	std::atomic<int> refs{1};
+	std::atomic<bool> closed{false};
 };
+
+static void ctx_release(smhv_ctx *c) {
+	if (c && c->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete c;
+}
+#define CTX_OPEN(c)                                                                                          \
+	do {                                                                                                     \
+		if (!(c) || (c)->closed.load(std::memory_order_acquire)) return fail(SMHV_E_INVALID, "the context was shut down"); \
+	} while (0)
 
 static void logf(smhv_ctx *c, int lvl, const char *fmt, ...) {
 	if (!c || !c->log) return;
@@ -283,28 +297,48 @@ extern "C" SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out) {
 }
 
 extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
-	if (!c) return;
+	if (!c || c->closed.exchange(true, std::memory_order_acq_rel)) return;
 	(void)hipSetDevice(c->device);
 	(void)hipDeviceSynchronize();
 	if (c->fb) { smhv_batch_destroy(c->fb); c->fb = nullptr; }
+	c->have_frame = false; c->cropped = false; c->map_open = false; c->mask_valid = false; c->scales_valid = false;
 	for (int i = 0; i < c->sector_n; ++i) (void)hipFree(c->sector_tab[i]);
+	c->sector_n = 0;
 	if (c->d_frame) (void)hipFree(c->d_frame);
 	if (c->h_ocr) (void)hipHostFree(c->h_ocr);
 	if (c->h_scales) (void)hipHostFree(c->h_scales);
-	for (int i = 0; i < 3; ++i) if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+	for (int i = 0; i < 3; ++i) { if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]); c->h_stage[i] = nullptr; c->h_stage_cap[i] = 0; }
 	if (c->h_res) (void)hipHostFree(c->h_res);
 	if (c->h_aux) (void)hipHostFree(c->h_aux);
 	if (c->h_bars) (void)hipHostFree(c->h_bars);
 	if (c->s_main) (void)hipStreamDestroy(c->s_main);
 	if (c->s_markers) (void)hipStreamDestroy(c->s_markers);
 	if (c->s_scales) (void)hipStreamDestroy(c->s_scales);
+	c->d_frame = nullptr; c->d_frame_cap = 0; c->h_ocr = c->h_scales = nullptr; c->h_res = nullptr; c->h_aux = nullptr; c->h_bars = nullptr;
+	c->s_main = c->s_markers = c->s_scales = nullptr;
 	logf(c, 3, "smh_vision_hip shut down");
-	delete c;
+	c->log = nullptr;
+	ctx_release(c);
 }
 
 extern "C" SMHV_API int smhv_thread_ctx(smhv_ctx *c) {
-	if (!c) return fail(SMHV_E_INVALID, "null context");
+	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_set_ray_table(smhv_ctx *c, const float *dx, const float *dy) {
+	if (!c || !dx || !dy) return fail(SMHV_E_INVALID, "bad arguments");
+	CTX_OPEN(c);
+	// sanity: unit vectors at 0.1 degree steps (the sector culling tables assume that geometry)
+	for (int i = 0; i < SMH_LSD_RAYS; ++i) {
+		const double a = (double)i / 10.0 * 3.14159265358979323846 / 180.0;
+		if (!(std::fabs((double)dx[i] - std::cos(a)) < 1e-5 && std::fabs((double)dy[i] - std::sin(a)) < 1e-5))
+			return fail(SMHV_E_INVALID, "ray table entry %d is not (cos, sin) of %.1f degrees", i, i / 10.0);
+	}
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipDeviceSynchronize());                           // no k_lsd launch may be reading the table
+	HIPCHK(set_ray_table(dx, dy));
 	return SMHV_OK;
 }
 
@@ -314,12 +348,14 @@ extern "C" SMHV_API int smhv_thread_ctx(smhv_ctx *c) {
 extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, smhv_batch **out) {
 	if (!c || !out || max_frames == 0) return fail(SMHV_E_INVALID, "bad arguments");
 	*out = nullptr;
+	CTX_OPEN(c);
 	Geom g;
 	int rc = compute_geom(W, H, &g);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(c->device));
 	smhv_batch *b = new (std::nothrow) smhv_batch();
 	if (!b) return fail(SMHV_E_INVALID, "out of host memory");
+	c->refs.fetch_add(1, std::memory_order_relaxed);
 	b->ctx = c; b->g = g; b->max_frames = max_frames;
 	const size_t n = max_frames;
 #define ALLOC0(ptr, bytes)                                          \
@@ -388,6 +424,7 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	if (b->lsd_fork.fork) (void)hipEventDestroy(b->lsd_fork.fork);
 	if (b->lsd_fork.join1) (void)hipEventDestroy(b->lsd_fork.join1);
 	if (b->lsd_fork.join2) (void)hipEventDestroy(b->lsd_fork.join2);
+	ctx_release(b->ctx);
 	delete b;
 }
 
@@ -423,6 +460,7 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                                        const smhv_anchors *anchors, void *stream) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
+	CTX_OPEN(b->ctx);
 	if ((stages & (SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP)) == 0) return fail(SMHV_E_INVALID, "no stage selected");
 	stages &= SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP | SMHV_STAGE_EXACT_STATS;
 	HIPCHK(hipSetDevice(b->ctx->device));
@@ -531,7 +569,7 @@ extern "C" SMHV_API int smhv_batch_device_ptrs(smhv_batch *b, void **r, void **u
 }
 
 extern "C" SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, uint32_t n, smhv_frame_result *out) {
-	if (!b || !out || first + n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+	if (!b || !out || (uint64_t)first + n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
 	HIPCHK(hipSetDevice(b->ctx->device));
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(out, b->d_results + first, sizeof(smhv_frame_result) * n, hipMemcpyDeviceToHost));
@@ -556,6 +594,7 @@ static int copy_image_d2h(smhv_ctx *c, int slot, uint8_t *dst, const uint8_t *d_
 
 extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t frame, uint8_t *out) {
 	if (!b || !out || frame >= b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+	CTX_OPEN(b->ctx);                                         // the staging buffers belong to the context
 	const Geom &g = b->g;
 	HIPCHK(hipSetDevice(b->ctx->device));
 	HIPCHK(hipDeviceSynchronize());
@@ -612,6 +651,7 @@ static void reset_frame_state(smhv_ctx *c) {
 
 extern "C" SMHV_API int smhv_load_frame(smhv_ctx *c, const uint8_t *bgra, uint32_t w, uint32_t h) {
 	if (!c || !bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
+	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
 	int rc = ensure_frame_buffers(c, w, h);
 	if (rc) return rc;
@@ -638,6 +678,7 @@ extern "C" SMHV_API int smhv_load_frame(smhv_ctx *c, const uint8_t *bgra, uint32
 
 extern "C" SMHV_API int smhv_load_frame_device(smhv_ctx *c, const void *d_bgra, uint32_t w, uint32_t h) {
 	if (!c || !d_bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
+	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
 	int rc = ensure_frame_buffers(c, w, h);
 	if (rc) return rc;
@@ -890,6 +931,7 @@ extern "C" SMHV_API int smhv_get_debug_view(smhv_ctx *c, int which, uint8_t *rgb
 
 extern "C" SMHV_API int smhv_debug_marker_table(smhv_ctx *c, uint32_t *bits) {
 	if (!c || !bits) return fail(SMHV_E_INVALID, "bad arguments");
+	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
 	uint32_t *d = nullptr;
 	const size_t bytes = ((size_t)1 << 24) / 8;
@@ -953,6 +995,7 @@ static CrcPlan crc_plan(uint64_t n_dwords) {
 
 extern "C" SMHV_API int smhv_crc32_device(smhv_ctx *c, const void *d_data, uint64_t nbytes, uint32_t *crc) {
 	if (!c || !crc || (nbytes && !d_data) || (nbytes & 3u)) return fail(SMHV_E_INVALID, "crc32: null argument or length not a multiple of 4");
+	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
 	if (nbytes == 0) { *crc = 0; return SMHV_OK; }
 	const uint64_t nd = nbytes / 4;
@@ -976,7 +1019,7 @@ extern "C" SMHV_API int smhv_crc32_device(smhv_ctx *c, const void *d_data, uint6
 
 extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
 	if (!q) return;
-	(void)hipSetDevice(q->ctx->device);
+	if (q->ctx) (void)hipSetDevice(q->ctx->device);
 	if (q->s) (void)hipStreamSynchronize(q->s);
 	for (auto p : q->h_stage) if (p) (void)hipHostFree(p);
 	for (auto p : q->d_stage) if (p) (void)hipFree(p);
@@ -987,6 +1030,7 @@ extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
 	if (q->d_x_wg) (void)hipFree(q->d_x_wg);
 	if (q->d_slab) (void)hipFree(q->d_slab);
 	if (q->s) (void)hipStreamDestroy(q->s);
+	ctx_release(q->ctx);
 	delete q;
 }
 
@@ -1014,12 +1058,14 @@ static int ingest_setup(smhv_ingest *q) {
 extern "C" SMHV_API int smhv_ingest_create(smhv_ctx *c, uint32_t w, uint32_t h, uint32_t slots, uint32_t capacity, smhv_ingest **out) {
 	if (!c || !out || w == 0 || h == 0 || slots < 2 || slots > 64 || capacity == 0) return fail(SMHV_E_INVALID, "ingest_create: bad arguments");
 	*out = nullptr;
+	CTX_OPEN(c);
 	Geom g;
 	int rc = compute_geom(w, h, &g);                          // same frame-size rules as load_frame
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(c->device));
 	smhv_ingest *q = new (std::nothrow) smhv_ingest();
 	if (!q) return fail(SMHV_E_INVALID, "out of memory");
+	c->refs.fetch_add(1, std::memory_order_relaxed);
 	q->ctx = c; q->W = w; q->H = h; q->slots = slots; q->capacity = capacity; q->frame_bytes = (size_t)w * h * 4;
 	rc = ingest_setup(q);
 	if (rc) { smhv_ingest_destroy(q); return rc; }
@@ -1028,14 +1074,15 @@ extern "C" SMHV_API int smhv_ingest_create(smhv_ctx *c, uint32_t w, uint32_t h, 
 }
 
 // Resolve the oldest in-flight frame: wait for its upload + CRC, apply the reference's duplicate rule
-// (capture.rs:44-47) and append it to the slab when it is new.
+// (capture.rs:44-47) and append it to the slab when it is new.  Returns INGEST_FULL (and leaves the frame queued, still
+// intact in its staging slot) when the frame is new but the slab already holds `capacity` frames.
+enum { INGEST_FULL = 1 };
 static int ingest_resolve_one(smhv_ingest *q) {
 	const uint32_t slot = (uint32_t)(q->tail % q->slots);
 	HIPCHK(hipEventSynchronize(q->done[slot]));
 	const uint32_t crc = q->h_acc[slot] ^ q->len_term;
 	if (crc == q->last_crc) { q->tail++; q->n_dup++; return SMHV_OK; }
-	if (q->count == q->capacity)                              // the frame stays queued: take the slab, reset, continue
-		return fail(SMHV_E_STATE, "ingest: the batch slab is full (%u frames); take it with smhv_ingest_batch and reset", q->capacity);
+	if (q->count == q->capacity) return INGEST_FULL;
 	q->last_crc = crc;
 	HIPCHK(hipMemcpyAsync(q->d_slab + (size_t)q->count * q->frame_bytes, q->d_stage[slot], q->frame_bytes, hipMemcpyDeviceToDevice, q->s));
 	q->tail++; q->count++; q->n_new++;
@@ -1048,6 +1095,9 @@ extern "C" SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra)
 	HIPCHK(hipSetDevice(q->ctx->device));
 	while (q->head - q->tail >= q->slots) {                   // every staging slot is in flight: retire the oldest
 		int rc = ingest_resolve_one(q);
+		if (rc == INGEST_FULL)                                // recoverable: nothing is lost, the queued frames go into the next slab
+			return fail(SMHV_E_STATE, "ingest: the batch slab is full (%u frames) and every staging slot holds a queued frame; "
+			                          "take the slab with smhv_ingest_batch, then smhv_ingest_reset", q->capacity);
 		if (rc) return rc;
 	}
 	const uint32_t slot = (uint32_t)(q->head % q->slots);
@@ -1084,8 +1134,9 @@ extern "C" SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames,
 	if (!q || !d_frames || !n) return fail(SMHV_E_INVALID, "ingest_batch: null argument");
 	if (q->acquired) return fail(SMHV_E_INVALID, "ingest_batch: a staging buffer is acquired but not committed");
 	HIPCHK(hipSetDevice(q->ctx->device));
-	while (q->tail < q->head) {
+	while (q->tail < q->head) {                               // drain until everything is resolved or the slab is full
 		int rc = ingest_resolve_one(q);
+		if (rc == INGEST_FULL) break;                         // later frames stay queued for the next slab (after reset)
 		if (rc) return rc;
 	}
 	HIPCHK(hipStreamSynchronize(q->s));                       // slab appends done: any stream may read it now
@@ -1096,8 +1147,10 @@ extern "C" SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames,
 
 extern "C" SMHV_API int smhv_ingest_reset(smhv_ingest *q) {
 	if (!q) return fail(SMHV_E_INVALID, "ingest_reset: null argument");
-	if (q->tail != q->head || q->acquired) return fail(SMHV_E_INVALID, "ingest_reset: frames still in flight (call smhv_ingest_batch first)");
-	q->count = 0;                                             // last_crc is kept: dedupe continues across batches
+	if (q->acquired) return fail(SMHV_E_INVALID, "ingest_reset: a staging buffer is acquired but not committed");
+	// Frames still queued (committed after the slab filled up) are resolved into the fresh slab by the next
+	// acquire / batch call.  last_crc is kept: the duplicate test continues across slabs.
+	q->count = 0;
 	return SMHV_OK;
 }
 

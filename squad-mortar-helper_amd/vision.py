@@ -53,6 +53,13 @@ class HipVision:
     def thread_ctx(self):
         L.check(self._lib.smhv_thread_ctx(self._ctx))
 
+    def set_ray_table(self, dx, dy):
+        """Replace the 3600 ray directions (glibc cosf/sinf by default) with the host libm's values."""
+        dx = np.ascontiguousarray(dx, np.float32); dy = np.ascontiguousarray(dy, np.float32)
+        if dx.shape != (3600,) or dy.shape != (3600,):
+            raise ValueError("dx, dy must be float32[3600]")
+        L.check(self._lib.smhv_set_ray_table(self._ctx, dx.ctypes.data_as(C.POINTER(C.c_float)), dy.ctypes.data_as(C.POINTER(C.c_float))))
+
     def shutdown(self):
         if self._ctx:
             self._lib.smhv_shutdown(self._ctx)

@@ -1,0 +1,354 @@
+"""GPU parity tests (-m gpu) for the BASELINE.json configurations at their FULL sizes, through the C ABI:
+
+  configs[1]  1 x 1920x1080, marker threshold + LSD only (smhv_batch_run with n = 1, stages = SMHV_STAGE_MARKERS)
+  configs[3]  128 x 2560x1440 (the mask does not fit LDS: all three mask residency paths of k_lsd in one launch)
+  configs[4]  the per-GPU shard of the 8-GPU run: 1024 x 1920x1080 resident frames (8.5 GB, byte offsets beyond 2^32)
+
+Sizes the oracle cannot cover in seconds are checked through size-independent properties (idempotence, permutation
+equivariance, periodicity of a tiled batch, popcounts) plus a sample of frames against the oracle; then bounded slices of
+the two fuzzers (tools/fuzz_lsd.py, tools/fuzz_stream.py) so that the driver's own run sees random scenes too."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GREEN = (0, 255, 64, 255)       # BGRA of RGB(64,255,0)
+PURPLE = (217, 117, 192, 255)   # BGRA of RGB(192,117,217)
+
+
+def _lines(r):
+    return np.array([[r.lines[a][b] for b in range(4)] for a in range(r.n_lines)], np.float32).reshape(-1, 4)
+
+
+def test_config1_batch_of_one_markers_only(vision):
+    """BASELINE configs[1]: batch = 1, 1920x1080 synthetic map, marker threshold + LSD only -- exactly the call the
+    bench line `--config 1` times.  Every record field and the mask against the oracle; ui_map / ocr / scales stages are
+    not run (their record fields stay empty)."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H = 1920, 1080
+    fb = smh.FrameBatch(vision, W, H, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    for idx, n_lines in ((0, 2), (1, 1), (2, 4), (3, 0)):
+        frame, info = synth.make_frame(W, H, idx, n_lines=n_lines)
+        d = torch.from_numpy(frame).cuda()
+        fb.run(d.data_ptr(), 1, stages=smh.STAGE_MARKERS, max_gap=15, stream=s)
+        fast = smh.results_to_dicts(fb.read_results(0, 1))[0]
+        fb.run(d.data_ptr(), 1, stages=smh.STAGE_MARKERS | smh.STAGE_EXACT_STATS, max_gap=15, stream=s)
+        r = smh.results_to_dicts(fb.read_results(0, 1))[0]
+        ref = o.process_frame(frame, stages=0x1, max_gap=15, want_images=True)
+        assert r["map_open"] == ref["map_open"] == 1 and r["red_pixels"] == o.button_red_pixels(frame)
+        assert np.array_equal(r["lines"], ref["lines"]) and np.array_equal(fast["lines"], ref["lines"])
+        assert (r["rounds"], r["ray_steps"], r["n_mask_px"]) == (ref["rounds"], ref["steps"], ref["n_mask_px"])
+        assert fast["rounds"] == ref["rounds"] and fast["ray_steps"] <= ref["steps"]
+        assert r["mpx"] is None and r["minimap"] is None
+        m = fb.read_image(smh._lib.VIEW_LSD_INPUT, 0)
+        assert np.array_equal(m, ref["lsd"])
+        assert np.array_equal(np.flatnonzero(m.reshape(-1) == 255), np.flatnonzero(ref["lsd"].reshape(-1) == 255))   # marker pixel coords
+        for k, ln in enumerate(ref["lines"]):
+            length, _ = o.marker_new(ln, 0.0)
+            assert abs(r["length_px"][k] - length) <= TOL and r["meters"][k] == 0.0
+            assert abs(float(r["angle"][k]) - o.marker_angle(ln)) <= TOL
+    # a closed map through the same entry point
+    frame, _ = synth.make_frame(W, H, 9, map_open=False)
+    d = torch.from_numpy(frame).cuda()
+    fb.run(d.data_ptr(), 1, stages=smh.STAGE_MARKERS, stream=s)
+    r = smh.results_to_dicts(fb.read_results(0, 1))[0]
+    assert r["map_open"] == 0 and r["n_lines"] == 0 and r["n_mask_px"] == 0 and r["rounds"] == 0
+    fb.close()
+
+
+def test_config3_full_size_1440p_batch_properties(vision):
+    """BASELINE configs[3] at its full size, 128 x 2560x1440: idempotence, permutation equivariance, mask popcounts, the
+    culled run against the exact-statistics run, and frames against the oracle -- among them three frames built to take
+    the three mask residency paths of k_lsd (whole rows in LDS, bounding-box window in LDS, mask in global memory with
+    an LDS row cache), which run as concurrent kernels over the same record array."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N = 2560, 1440, 128
+    host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
+    frames = host.numpy()
+    _, infos = synth.make_batch(W, H, N, first_idx=2000, n_lines=2, out=frames)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    # frame 5: marker pixels in opposite corners -> bounding box = whole ROI (does not fit LDS)
+    frames[5, y + 2:y + 5, x + 2:x + 90] = GREEN
+    frames[5, y + rh - 6:y + rh - 3, x + rw - 100:x + rw - 3] = GREEN
+    # frame 6: no synthetic lines; one tall, narrow, steep line -> more rows than the whole-row window holds, few columns
+    frames[6], info6 = synth.make_frame(W, H, 2006, n_lines=0)
+    for k in range(rh - 120):
+        frames[6, y + 60 + k, x + 500 + k // 9:x + 503 + k // 9] = PURPLE
+    infos[6] = info6
+    # frame 7: one short line -> small bounding box (whole rows in LDS)
+    frames[7], info7 = synth.make_frame(W, H, 2007, n_lines=0)
+    frames[7, y + 300:y + 303, x + 200:x + 420] = GREEN
+    infos[7] = info7
+    # frame 8: closed map; frame 9: open, empty mask
+    frames[8], infos[8] = synth.make_frame(W, H, 2008, map_open=False)
+    frames[9], infos[9] = synth.make_frame(W, H, 2009, n_lines=0)
+    per = [(i["scales_start_y"], i["anchors"]) for i in infos]
+    anchors = smh.make_anchors(per)
+    d = host.cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    s = torch.cuda.current_stream().cuda_stream
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
+    a = bytes(fb.read_results(0, N))
+    for _ in range(3):                                            # repeated: the concurrent mode kernels must not race on the records
+        fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
+        assert bytes(fb.read_results(0, N)) == a
+    fast = smh.results_to_dicts(fb.read_results(0, N))
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_EXACT_STATS, anchors=anchors, stream=s)
+    recs = smh.results_to_dicts(fb.read_results(0, N))
+    for i, (p, q) in enumerate(zip(fast, recs)):
+        assert np.array_equal(p["lines"], q["lines"]) and p["rounds"] == q["rounds"] and p["ray_steps"] <= q["ray_steps"], i
+        assert p["n_mask_px"] == q["n_mask_px"] and p["mpx"] == q["mpx"]
+        if q["map_open"] and q["n_mask_px"]:
+            assert q["rounds"] > 0, "frame %d has marker pixels but was never searched" % i
+    assert recs[8]["map_open"] == 0 and recs[8]["n_lines"] == 0 and recs[9]["map_open"] == 1 and recs[9]["n_mask_px"] == 0 and recs[9]["rounds"] == 0
+    for i in (0, 5, 6, 7, 64, 127):
+        ref = o.process_frame(frames[i], stages=0xF, anchors=per[i][1], scales_start_y=per[i][0], want_images=True)
+        r = recs[i]
+        assert np.array_equal(r["lines"], ref["lines"]) and r["mpx"] == ref["mpx"], i
+        assert (r["rounds"], r["ray_steps"], r["n_mask_px"]) == (ref["rounds"], ref["steps"], ref["n_mask_px"]), i
+        m = fb.read_image(smh._lib.VIEW_LSD_INPUT, i)
+        assert int((m == 255).sum()) == r["n_mask_px"] and np.array_equal(m, ref["lsd"])
+        assert np.array_equal(fb.read_image(smh._lib.IMAGE_UI_MAP, i), ref["ui_map"])
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_OCR_INPUT, i), ref["ocr"])
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_FIND_SCALES_INPUT, i)[per[i][0]:], ref["scales"][per[i][0]:])
+        for k, ln in enumerate(ref["lines"]):
+            length, meters = o.marker_new(ln, ref["mpx"] if ref["mpx"] is not None else 0.0)
+            assert abs(r["length_px"][k] - length) <= TOL and abs(r["meters"][k] - (meters if ref["mpx"] is not None else 0.0)) <= TOL
+            assert abs(float(r["angle"][k]) - o.marker_angle(ln)) <= TOL
+    assert len(recs[6]["lines"]) >= 1 and len(recs[7]["lines"]) >= 1
+    rev = torch.flip(d, dims=[0]).contiguous()
+    anchors_rev = smh.make_anchors(list(reversed(per)))
+    fb.run(rev.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_EXACT_STATS, anchors=anchors_rev, stream=s)
+    recs_rev = smh.results_to_dicts(fb.read_results(0, N))
+    for i in range(N):
+        r, q = recs[i], recs_rev[N - 1 - i]
+        assert np.array_equal(r["lines"], q["lines"]) and (r["rounds"], r["ray_steps"], r["n_mask_px"], r["mpx"]) == (q["rounds"], q["ray_steps"], q["n_mask_px"], q["mpx"]), i
+    fb.close()
+
+
+def test_config4_shard_of_1024_resident_frames(vision):
+    """The per-GPU shard of BASELINE configs[4]: 1024 x 1920x1080 frames resident in HBM (8.5 GB of input: frame byte
+    offsets pass 2^32 after frame 517).  64 distinct frames tiled 16 times on the device: the records must be periodic,
+    a second run identical, two frames planted in the last 4 GB must be found where they were put, and the distinct
+    frames equal the oracle."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, K, REP = 1920, 1080, 64, 16
+    N = K * REP
+    base, infos = synth.make_batch(W, H, K, first_idx=4096)
+    d = torch.from_numpy(base).cuda().repeat(REP, 1, 1, 1)
+    assert d.shape[0] == N and d.numel() > (1 << 32)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    sp_a, info_a = synth.make_frame(W, H, 5001, n_lines=3)         # planted beyond the 4 GB boundary
+    sp_b, info_b = synth.make_frame(W, H, 5002, map_open=False)
+    ia, ib = 1000, 1023
+    d[ia] = torch.from_numpy(sp_a).cuda()
+    d[ib] = torch.from_numpy(sp_b).cuda()
+    per = [(infos[i % K]["scales_start_y"], infos[i % K]["anchors"]) for i in range(N)]
+    per[ia] = (info_a["scales_start_y"], info_a["anchors"])
+    anchors = smh.make_anchors(per)
+    fb = smh.FrameBatch(vision, W, H, N)
+    s = torch.cuda.current_stream().cuda_stream
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
+    a = bytes(fb.read_results(0, N))
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
+    assert bytes(fb.read_results(0, N)) == a
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_EXACT_STATS, anchors=anchors, stream=s)
+    raw = fb.read_results(0, N)
+    recs = smh.results_to_dicts(raw)
+    rb = bytes(raw)
+    import ctypes
+    sz = ctypes.sizeof(smh._lib.FrameResult)
+    for i in range(K, N):
+        if i in (ia, ib):
+            continue
+        assert rb[i * sz:(i + 1) * sz] == rb[(i % K) * sz:(i % K + 1) * sz], "record %d differs from record %d of the same frame" % (i, i % K)
+    threads = min(os.cpu_count() or 1, K)
+    a9 = np.zeros((K, 3, 3), np.uint32)
+    for i in range(K):
+        for j, sc in enumerate(infos[i]["anchors"][:3]):
+            a9[i, j] = sc
+    ref = o.process_batch(base, threads, stages=0xF, anchors=a9, n_anchors=len(infos[0]["anchors"]), scales_start_y=infos[0]["scales_start_y"])
+    for i in range(K):
+        assert np.array_equal(recs[i]["lines"], _lines(ref[i])) and recs[i]["rounds"] == ref[i].rounds and recs[i]["ray_steps"] == ref[i].steps, i
+        assert recs[i]["n_mask_px"] == ref[i].n_mask_px and recs[i]["mpx"] == (ref[i].mpx if ref[i].has_mpx else None)
+    ra = o.process_frame(sp_a, stages=0xF, anchors=info_a["anchors"], scales_start_y=info_a["scales_start_y"], want_images=True)
+    assert np.array_equal(recs[ia]["lines"], ra["lines"]) and (recs[ia]["rounds"], recs[ia]["ray_steps"]) == (ra["rounds"], ra["steps"]) and recs[ia]["mpx"] == ra["mpx"]
+    assert np.array_equal(fb.read_image(smh._lib.VIEW_LSD_INPUT, ia), ra["lsd"]) and np.array_equal(fb.read_image(smh._lib.IMAGE_UI_MAP, ia), ra["ui_map"])
+    assert np.array_equal(fb.read_image(smh._lib.VIEW_OCR_INPUT, ia), ra["ocr"])
+    assert recs[ib]["map_open"] == 0 and recs[ib]["n_lines"] == 0
+    # images of a frame behind the boundary equal those of its twin in front of it
+    for which in (smh._lib.VIEW_LSD_INPUT, smh._lib.IMAGE_UI_MAP, smh._lib.VIEW_OCR_INPUT, smh._lib.VIEW_FIND_SCALES_INPUT):
+        assert np.array_equal(fb.read_image(which, 3), fb.read_image(which, 3 + 15 * K))
+    fb.close()
+
+
+@pytest.mark.parametrize("seed,size,max_gap", [(11, (1920, 1080), 15), (12, (2560, 1440), 15), (13, (1280, 1024), 22), (14, (1024, 768), 3),
+                                               (15, (1600, 1024), 49), (16, (1920, 1080), 9)])
+def test_fuzz_lsd_slice(vision, seed, size, max_gap):
+    """Bounded slice of tools/fuzz_lsd.py (36 random scenes per case, ~1000 rounds each): lines of all angles and widths,
+    dashed lines with gaps around max_gap, blobs, rings, noise, shapes crossing the borders -- line lists and round counts
+    in the culled run, plus the sample counts in the exact-statistics run, against the oracle."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from fuzz_scenes import scene
+    W, H = size
+    n = 36
+    rng = np.random.default_rng(seed)
+    frames = np.stack([scene(rng, W, H, 100 * seed + i, max_gap) for i in range(n)])
+    ref = o.process_batch(frames, min(os.cpu_count() or 1, n), stages=0x1, max_gap=max_gap)
+    fb = smh.FrameBatch(vision, W, H, n)
+    d = torch.from_numpy(frames).cuda()
+    for exact in (0, smh.STAGE_EXACT_STATS):
+        fb.run(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=max_gap, stream=torch.cuda.current_stream().cuda_stream)
+        got = smh.results_to_dicts(fb.read_results(0, n))
+        for i in range(n):
+            assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (seed, i, bool(exact))
+            assert got[i]["rounds"] == ref[i].rounds and got[i]["n_mask_px"] == ref[i].n_mask_px, (seed, i, bool(exact))
+            if exact:
+                assert got[i]["ray_steps"] == ref[i].steps, (seed, i)
+    assert sum(r.rounds for r in ref) > 100
+    fb.close()
+
+
+def test_fuzz_stream_slice(vision):
+    """Bounded slice of tools/fuzz_stream.py: pixels drawn around every decision threshold of the streaming stages."""
+    import squad_mortar_helper_amd as smh
+    from fuzz_scenes import random_frame
+    rng = np.random.default_rng(5)
+    for it, (W, H) in enumerate([(1920, 1080), (2560, 1440), (1024, 768), (1366, 768), (1680, 1050), (1280, 1024)]):
+        frame = random_frame(rng, W, H)
+        bx, by, bw, bh = smh.button_bounds(W, H)
+        frac = [0.64, 0.66, 1.0, 0.65, 0.7, 0.60][it]
+        red = rng.random((bh, bw)) < frac
+        frame[by:by + bh, bx:bx + bw, :3] = np.where(red[..., None], np.array([49, 67, 217]) + rng.integers(-25, 26, (bh, bw, 3)), 0).astype(np.uint8)
+        start_y = int(rng.integers(0, 50))
+        ref = o.process_frame(frame, stages=0x0E, scales_start_y=start_y, anchors=[(100, 10, start_y)], want_images=True)
+        vision.load_frame(frame)
+        crop = vision.crop_to_map(True)
+        assert (crop is not None) == bool(ref["map_open"]) and vision.red_pixels() == o.button_red_pixels(frame)
+        if crop is None:
+            continue
+        vision.isolate_map_markers(); vision.mask_marker_lines()
+        x, y, rw, rh = smh.map_bounds(W, H)
+        mask_ref = o.mask_marker_lines(np.ascontiguousarray(frame[y:y + rh, x:x + rw, 2::-1]))
+        assert np.array_equal(crop[0], ref["ui_map"]) and np.array_equal(vision.lsd_image(), mask_ref)
+        assert np.array_equal(vision.ocr_preprocess(), ref["ocr"])
+        assert np.array_equal(vision.find_scales_preprocess(start_y)[start_y:], ref["scales"][start_y:])
+        colour = vision.crop_to_map(False)
+        assert np.array_equal(colour[0][..., :3], frame[y:y + rh, x:x + rw, 2::-1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# robustness of the boundary (round-1 advisor findings)
+# ---------------------------------------------------------------------------------------------------
+def test_ingest_queue_survives_more_frames_than_the_slab_holds(vision):
+    """capacity + slots distinct frames: the slab fills up, the surplus stays queued in the staging slots, and after
+    batch + reset it lands in the next slab -- nothing is lost and the queue never wedges."""
+    import zlib
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, SLOTS, CAP = 1024, 768, 3, 4
+    fr = [synth.make_frame(W, H, 900 + i, n_lines=1)[0] for i in range(CAP + SLOTS + 2)]
+    nb = W * H * 4
+    q = smh.IngestQueue(vision, W, H, slots=SLOTS, capacity=CAP)
+    for f in fr[:CAP + SLOTS]:
+        q.push(f)                                                  # the last SLOTS frames cannot be appended: they stay queued
+    with pytest.raises(smh.VisionError) as ei:                     # no free staging slot and a full slab: reported, recoverable
+        q.push(fr[CAP + SLOTS])
+    assert ei.value.code == smh._lib.E_STATE
+    ptr, n, crc = q.batch()
+    assert n == CAP and crc == zlib.crc32(fr[CAP - 1].tobytes())
+    for i in range(CAP):
+        assert smh.crc32_device(vision, ptr + i * nb, nb) == zlib.crc32(fr[i].tobytes())
+    assert q.batch()[1] == CAP                                     # asking again changes nothing
+    q.reset()
+    q.push(fr[CAP + SLOTS])                                        # works again; the queued frames come first
+    q.push(fr[CAP + SLOTS])                                        # duplicate of the previous capture: dropped
+    ptr, n, crc = q.batch()
+    assert n == SLOTS + 1 and crc == zlib.crc32(fr[CAP + SLOTS].tobytes())
+    for i in range(SLOTS + 1):
+        assert smh.crc32_device(vision, ptr + i * nb, nb) == zlib.crc32(fr[CAP + i].tobytes())
+    assert q.counts() == (CAP + SLOTS + 1, 1)
+    q.close()
+
+
+def test_context_shutdown_before_its_children(built):
+    """HipVision.shutdown() with a FrameBatch and an IngestQueue still alive: their calls fail cleanly and closing them
+    afterwards is safe (the context object goes with its last child)."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    v = smh.HipVision.init(0)
+    W, H = 1024, 768
+    frame, _ = synth.make_frame(W, H, 1)
+    d = torch.from_numpy(frame).cuda()
+    fb = smh.FrameBatch(v, W, H, 2)
+    q = smh.IngestQueue(v, W, H, slots=2, capacity=2)
+    fb.run(d.data_ptr(), 1, stages=smh.STAGE_MARKERS)
+    assert fb.read_results(0, 1)[0].map_open == 1
+    v.shutdown()
+    with pytest.raises(smh.VisionError):
+        fb.run(d.data_ptr(), 1, stages=smh.STAGE_MARKERS)
+    with pytest.raises(smh.VisionError):
+        smh.FrameBatch(v, W, H, 1)
+    fb.close(); q.close()
+    v2 = smh.HipVision.init(0)                                      # the device is still usable
+    fb2 = smh.FrameBatch(v2, W, H, 1)
+    fb2.run(d.data_ptr(), 1, stages=smh.STAGE_MARKERS)
+    assert fb2.read_results(0, 1)[0].map_open == 1
+    fb2.close(); v2.shutdown()
+
+
+def test_abi_bounds_checks(vision):
+    import ctypes as C
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H = 1024, 768
+    fb = smh.FrameBatch(vision, W, H, 4)
+    lib = smh._lib.load()
+    recs = (smh._lib.FrameResult * 2)()
+    assert lib.smhv_batch_read_results(fb._b, 0xFFFFFFFF, 2, recs) == smh._lib.E_INVALID     # first + n must not wrap
+    assert lib.smhv_batch_read_results(fb._b, 3, 2, recs) == smh._lib.E_INVALID
+    frames, infos = synth.make_batch(W, H, 4)
+    d = torch.from_numpy(frames).cuda()
+    short = smh.make_anchors([(infos[0]["scales_start_y"], infos[0]["anchors"])])
+    with pytest.raises(ValueError):
+        fb.run(d.data_ptr(), 4, anchors=short)
+    many = smh.make_anchors([(10, [(100, 5, 10), (200, 6, 11), (300, 7, 12), (400, 8, 13)])])
+    assert many[0].n == 3
+    fb.close()
+
+
+def test_host_supplied_ray_table(vision):
+    """smhv_set_ray_table: the glibc table gives the committed results; a table that is not (cos, sin) of 0.1-degree
+    steps is rejected; a table perturbed by one ulp in a few entries is accepted and restoring the original restores the
+    results."""
+    import fixtures as fx
+    import squad_mortar_helper_amd as smh
+    dx, dy = o.ray_table()
+    frame, e, g = fx.load_fixture("points_intersect_png")
+    st = smh.VisionState()
+    try:
+        vision.set_ray_table(dx, dy)
+        assert np.array_equal(st.process(vision, frame).markers, g["lines"])
+        with pytest.raises(smh.VisionError):
+            vision.set_ray_table(dy, dx)
+        dx2 = dx.copy()
+        dx2[[7, 900, 1801, 3599]] = np.nextafter(dx2[[7, 900, 1801, 3599]], np.float32(2.0))
+        vision.set_ray_table(dx2, dy)
+        assert st.process(vision, frame).markers.shape[1] == 4
+    finally:
+        vision.set_ray_table(dx, dy)
+    assert np.array_equal(st.process(vision, frame).markers, g["lines"])

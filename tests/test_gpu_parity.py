@@ -725,14 +725,18 @@ def test_ingest_queue_dedupes_like_the_capture_thread_and_feeds_the_batch(vision
     refb = o.process_frame(want[1], stages=0x3, want_images=True)
     assert np.array_equal(ui, refb["ui_map"]) and np.array_equal(vision.find_marker_lines(15), refb["lines"])
     assert vision.get_cpu_frame() is None
-    # next slab: dedupe continues against the last accepted frame (C), and the capacity limit is an error, not a drop
+    # next slab: dedupe continues against the last accepted frame (C); a frame beyond the capacity is neither an error
+    # nor a drop: it stays queued and opens the next slab
     q.reset()
     for f in (Cc, A, B, A, B):
         q.push(f)
     assert q.batch()[1] == 4 and q.counts() == (8, 5)
     q.push(A)
-    with pytest.raises(smh.VisionError):
-        q.batch()
+    assert q.batch()[1] == 4 and q.counts() == (8, 5)
+    q.reset()
+    ptr, n, crc = q.batch()
+    assert n == 1 and crc == zlib.crc32(A.tobytes()) and q.counts() == (9, 5)
+    assert smh.crc32_device(vision, ptr, nb) == crc
     q.close()
 
 

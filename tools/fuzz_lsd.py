@@ -7,49 +7,15 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 import squad_mortar_helper_amd as smh
 from squad_mortar_helper_amd import synth
 from oracle import oracle as orc   # checker only
-
-GREEN, PURPLE, TEAL = (0, 255, 64, 255), (217, 117, 192, 255), (181, 232, 93, 255)
-
-
-def scene(rng, W, H, idx, max_gap):
-    frame, _ = synth.make_frame(W, H, idx, n_lines=0)
-    x, y, rw, rh = smh.map_bounds(W, H)
-    roi = frame[y:y + rh, x:x + rw]
-    for _ in range(int(rng.integers(0, 7))):
-        col = (GREEN, PURPLE, TEAL)[int(rng.integers(0, 3))]
-        p0 = rng.uniform([-20, -20], [rw + 20, rh + 20]); ang = rng.uniform(0, 2 * np.pi)
-        L = rng.uniform(20, 0.9 * min(rw, rh)) if rng.random() < 0.6 else rng.uniform(40, 62)
-        t = np.arange(0.0, L, 0.5)
-        on = np.ones_like(t, dtype=bool)
-        if rng.random() < 0.4:                                  # dashes with gaps around max_gap
-            period = rng.uniform(8, 40); gap = max(max_gap + rng.integers(-2, 3), 1)
-            on = (t % (period + gap)) < period
-        px = np.rint(p0[0] + np.cos(ang) * t).astype(int); py = np.rint(p0[1] + np.sin(ang) * t).astype(int)
-        th = int(rng.integers(1, 6))
-        for dy in range(th):
-            for dx in range(th):
-                xx, yy = px + dx, py + dy
-                ok = on & (xx >= 0) & (xx < rw) & (yy >= 0) & (yy < rh)
-                roi[yy[ok], xx[ok]] = col
-    for _ in range(int(rng.integers(0, 5))):
-        cx, cy, r = int(rng.integers(0, rw)), int(rng.integers(0, rh)), int(rng.integers(3, 30))
-        yy, xx = np.ogrid[-r:r + 1, -r:r + 1]
-        d2 = xx * xx + yy * yy
-        m = (d2 <= r * r) & ((d2 >= (r - 3) ** 2) if rng.random() < 0.5 else True)
-        ys, xs = np.nonzero(m)
-        ys, xs = ys + cy - r, xs + cx - r
-        ok = (xs >= 0) & (xs < rw) & (ys >= 0) & (ys < rh)
-        roi[ys[ok], xs[ok]] = GREEN
-    k = int(rng.integers(0, 200))
-    roi[rng.integers(0, rh, k), rng.integers(0, rw, k)] = PURPLE
-    return frame
-
+from fuzz_scenes import scene
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4

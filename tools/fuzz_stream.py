@@ -5,26 +5,13 @@ saturation / value jitter around the tolerances, button reds around the 0.65 fra
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import squad_mortar_helper_amd as smh
 from oracle import oracle as orc   # checker only
-
-
-def random_frame(rng, W, H):
-    f = np.empty((H, W, 4), np.uint8)
-    f[..., 3] = 255
-    kind = rng.integers(0, 6, (H, W))
-    base = rng.integers(0, 256, (H, W, 3))
-    # greys around the OCR thresholds with small channel spreads
-    g = rng.choice([128, 129, 130, 131, 198, 199, 200, 201, 255], (H, W))[..., None] + rng.integers(-13, 14, (H, W, 3)) * (rng.random((H, W, 1)) < 0.5)
-    # near-black (luma trunc 0 / 1)
-    nb = rng.integers(0, 4, (H, W, 3))
-    # marker colours with jitter (BGR order)
-    team = np.array([[0, 255, 64], [217, 117, 192], [181, 232, 93]])[rng.integers(0, 3, (H, W))] + rng.integers(-40, 41, (H, W, 3))
-    out = np.where((kind == 0)[..., None], base, np.where((kind <= 2)[..., None], g, np.where((kind == 3)[..., None], nb, team)))
-    f[..., :3] = np.clip(out, 0, 255).astype(np.uint8)
-    return f
+from fuzz_scenes import random_frame
 
 
 def main():
