@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "smh_device.h"
+#include "smh_proximity.h"
 
 namespace smh {
 
@@ -306,17 +307,7 @@ __device__ void get_centre(const Win &m, float px, float py, float &ox, float &o
 	oy = (up + down) / 2.0f;
 }
 
-// lsd.rs:47-58 + the `< 50.0` test of lsd.rs:84-89 (u is not clamped: infinite line).
-__device__ __forceinline__ bool near_line(float x, float y, float x0, float y0, float x1, float y1) {
-	const float dx = x1 - x0, dy = y1 - y0;
-	float nx = x0, ny = y0;
-	if (!(dx == 0.0f && dy == 0.0f)) {
-		const float u = ((x - x0) * dx + (y - y0) * dy) / (dx * dx + dy * dy);
-		nx = x0 + u * dx; ny = y0 + u * dy;
-	}
-	const float ex = x - nx, ey = y - ny;
-	return ex * ex + ey * ey < SMH_LSD_PROXIMITY_SQ;
-}
+// near_line (lsd.rs:47-58,84-89) and its cheap word-level classifier live in smh_proximity.h (shared with a host test)
 
 // Diagnostic build only (-DSMH_LSD_PROFILE): thread 0 accumulates s_memtime deltas per phase and stores
 // them in the tail of the record's `meters` array (never read by product code in that build).
@@ -348,10 +339,21 @@ struct LsdShared {
 	unsigned short ulist[LSD_UNITS];
 	unsigned long long live[LSD_C];          // units (64-ray sectors) of each candidate that have to be cast
 	float lines[SMH_LSD_MAX_LINES][4];
+	// prox_line() of each accepted line (smh_proximity.h): slope of the signed distance along x, unit direction
+	float prox_a[SMH_LSD_MAX_LINES];
+	double prox_d[SMH_LSD_MAX_LINES][2];
 #ifdef SMH_LSD_PROFILE
 	uint32_t exp_far, exp_units;
 #endif
 };
+
+__device__ __forceinline__ ProxLine shared_prox_line(const LsdShared &sh, uint32_t l) {
+	ProxLine L;
+	L.x0 = sh.lines[l][0]; L.y0 = sh.lines[l][1]; L.x1 = sh.lines[l][2]; L.y1 = sh.lines[l][3];
+	L.a = sh.prox_a[l]; L.dxl = sh.prox_d[l][0]; L.dyl = sh.prox_d[l][1];
+	L.degenerate = L.dxl == 0.0 && L.dyl == 0.0;
+	return L;
+}
 
 // find_longest_line for nc candidates at once (start points in sh.cand_pt).  On return (after a
 // barrier) sh.cand_best / cand_end / cand_steps hold, per candidate, the winning key, its end point
@@ -699,15 +701,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				const uint32_t r = wi / wwords, c = wi - r * wwords;
 				py = (float)(wy0 + r);
 				px0 = (float)(xorg + (int)(c * 32u));
-				for (uint32_t l = 0; l < n_lines && surv; ++l) {
-					const float x0 = sh.lines[l][0], y0 = sh.lines[l][1], x1 = sh.lines[l][2], y1 = sh.lines[l][3];
-					uint32_t s = surv;
-					while (s) {
-						const uint32_t bit = __builtin_ctz(s);
-						s &= s - 1u;
-						if (near_line(px0 + (float)bit, py, x0, y0, x1, y1)) surv &= ~(1u << bit);
-					}
-				}
+				for (uint32_t l = 0; l < n_lines && surv; ++l) surv = prox_filter_word(surv, px0, py, shared_prox_line(sh, l));
 			}
 			while (true) {
 				// ---- the next (up to) LSD_C surviving white pixels in raster order ----
@@ -834,6 +828,8 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 						// every thread stores the same four values (no barrier needed for its own later reads)
 						sh.lines[n_lines][0] = sh.cand_pt[c][0]; sh.lines[n_lines][1] = sh.cand_pt[c][1];
 						sh.lines[n_lines][2] = ex; sh.lines[n_lines][3] = ey;
+						const ProxLine pl = prox_line(sh.cand_pt[c][0], sh.cand_pt[c][1], ex, ey);
+						sh.prox_a[n_lines] = pl.a; sh.prox_d[n_lines][0] = pl.dxl; sh.prox_d[n_lines][1] = pl.dyl;
 						++n_lines;
 						if (n_lines == SMH_LSD_MAX_LINES) { done = true; break; }
 					}
@@ -844,15 +840,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				// width restarts at 1 after an acceptance and doubles after every acceptance-free group.
 				cmax = (n_lines != first_new) ? LSD_C_RESET : min(cmax * 2u, LSD_C);
 				PROF_MARK(5);   // resolve
-				for (uint32_t l = first_new; l < n_lines && surv; ++l) {
-					const float x0 = sh.lines[l][0], y0 = sh.lines[l][1], x1 = sh.lines[l][2], y1 = sh.lines[l][3];
-					uint32_t s = surv;
-					while (s) {
-						const uint32_t bit = __builtin_ctz(s);
-						s &= s - 1u;
-						if (near_line(px0 + (float)bit, py, x0, y0, x1, y1)) surv &= ~(1u << bit);
-					}
-				}
+				for (uint32_t l = first_new; l < n_lines && surv; ++l) surv = prox_filter_word(surv, px0, py, shared_prox_line(sh, l));
 			}
 			__syncthreads();
 		}
