@@ -134,6 +134,11 @@ SMHV_API int smhv_get_debug_view(smhv_ctx *ctx, int which, uint8_t *rgba, uint32
                                         cannot hold an acceptable ray (lines, rounds and every other output are identical;
                                         ray_steps then counts only the samples actually taken). */
 
+#define SMHV_STAGE_LSD_HELPERS 0x40u /* tuning: workgroups of the line-segment kernel that have finished their own frame help
+                                       the frames still being searched (ray-cast candidates ahead of the owner; results are
+                                       identical either way).  Shortens a single batch with a few heavy frames; only gets in
+                                       the way when several batches are pipelined, so it is off by default. */
+
 /* One record per frame (what a node-level gather moves between GPUs).  mpx/derived fields follow
  * src/ui/mod.rs:131-140 (length_px, meters in f64) and src/ui/markers.rs:98 (angle = atan2f). */
 typedef struct {
@@ -202,6 +207,10 @@ SMHV_API int smhv_batch_set_scales_stream(smhv_batch *b, void *stream);
  * both steps streaming and then both searching. */
 SMHV_API int smhv_batch_wait_map_pass(smhv_batch *b, void *stream);
 SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
+/* diagnostic: per-frame cooperation counters of the most recent line-segment launch, 4 words per frame:
+ * {groups of the owner that had helpers attached, candidates it took from the helpers' cache, candidates cast by helpers,
+ *  requests posted}.  Synchronises. */
+SMHV_API int smhv_batch_lsd_coop_stats(smhv_batch *b, uint32_t first, uint32_t n, uint32_t *out);
 SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
 
 /* exhaustive colour-predicate check support: writes 2^24/32 words, bit (r<<16|g<<8|b) = device

@@ -16,6 +16,7 @@ MAX_SCALES = 3
 STAGE_MARKERS, STAGE_UI_MAP, STAGE_OCR, STAGE_SCALES, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 STAGE_MINIMAP = 0x10
 STAGE_EXACT_STATS = 0x20
+STAGE_LSD_HELPERS = 0x40
 VIEW_NONE, VIEW_OCR_INPUT, VIEW_FIND_SCALES_INPUT, VIEW_LSD_PREPROCESS, VIEW_LSD_INPUT, VIEW_CROPPED_BRQ = range(6)
 IMAGE_UI_MAP = 100
 
@@ -89,6 +90,7 @@ SIGNATURES = {
     "smhv_batch_set_scales_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_batch_wait_map_pass": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_batch_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "smhv_batch_lsd_coop_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "smhv_batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),

@@ -90,6 +90,13 @@ class FrameBatch:
         L.check(self._lib.smhv_batch_stage_ms(self._b, ms))
         return dict(zip(STAGE_NAMES, [float(v) for v in ms]))
 
+    def lsd_coop_stats(self, first=0, n=None):
+        """Diagnostic: uint32[n, 4] = (helped groups, cache hits, helper casts, requests posted) per frame of the last LSD launch."""
+        n = self.max_frames - first if n is None else n
+        out = np.zeros((n, 4), np.uint32)
+        L.check(self._lib.smhv_batch_lsd_coop_stats(self._b, first, n, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
     def device_ptrs(self):
         p = [C.c_void_p() for _ in range(6)]
         L.check(self._lib.smhv_batch_device_ptrs(self._b, *[C.byref(x) for x in p]))

@@ -38,6 +38,43 @@ struct FrameAux {
 	uint32_t pad;
 };
 
+// ---- cooperation between the workgroups of one k_lsd launch (smh_lsd.hip) ---------------------------------------
+// A frame's line scan is sequential, but casting the rays of a candidate pixel is a pure function of (mask, pixel):
+// workgroups that have finished their own frame ("helpers") load the mask of a frame that is still being searched and
+// ray-cast candidates its owner has posted ahead of its own position; the results travel back through a per-frame
+// hash table keyed by the pixel.  The owner never waits for a helper and a missing result only means it casts itself,
+// so the outputs are the sequential algorithm's bit for bit.
+struct LsdCoop {             // one 64-byte line per frame, zeroed before every launch
+	uint32_t req_tail;       // requests posted by the owner
+	uint32_t req_head;       // requests claimed by helpers (the owner raises it to req_tail to cancel what is pending)
+	uint32_t done;           // the owner has finished the frame
+	uint32_t helpers;        // helpers attached
+	uint32_t remaining;      // surviving candidate pixels the owner still has in front of it (what helpers go by)
+	uint32_t mode1;          // 1 + mask residency mode of the owner's kernel (helpers of another mode's kernel keep off)
+	uint32_t stat_groups, stat_hits, stat_casts;   // diagnostics: helped groups of the owner, cache hits, candidates cast by helpers
+	uint32_t pad[7];
+};
+struct LsdCtl {              // per launch, zeroed with the LsdCoop array; [residency mode]
+	uint32_t started[3];     // owner workgroups dispatched
+	uint32_t finished[3];    // owner workgroups that have left their frame
+	uint32_t pad[10];
+};
+struct LsdCacheEntry {       // 32 bytes
+	unsigned long long tag;  // epoch << 32 | busy << 31 | y << 12 | x ; epoch identifies the launch (stale entries = empty)
+	unsigned long long best; // max over rays of (len^2 bits << 32 | ray index)
+	float ex, ey;            // end point of that ray
+	uint32_t steps, pad;     // mask samples of all rays of the candidate
+};
+#define SMH_LSD_REQ_CAP 64u          // request ring entries per frame (seq << 24 | y << 12 | x)
+#define SMH_LSD_CACHE_SLOTS 512u     // hash slots per frame
+struct LsdCoopBufs {
+	LsdCtl *ctl;             // null: no cooperation (Vision::find_longest_line, or the buffers are absent)
+	LsdCoop *coop;
+	uint32_t *req;           // n x SMH_LSD_REQ_CAP
+	LsdCacheEntry *cache;    // n x SMH_LSD_CACHE_SLOTS
+	uint32_t epoch;
+};
+
 struct Buffers {
 	const uint8_t *frames;   // n * frame_bytes
 	uint8_t *ui, *mask, *ocr, *scales;
@@ -49,6 +86,7 @@ struct Buffers {
 	//   [SMH_CULL_CELLS words] cell (row oy + R) * 4 + j: mask of the annulus pixels among offsets ox = -R + 32 j + [0, 32)
 	//   [(2R+1)^2 bytes, row-major] unit range of each annulus pixel: first_unit | (n_units - 1) << 6, 0xFF = every unit
 	const uint32_t *cull_tab;
+	LsdCoopBufs co;
 };
 
 // Sector culling table as k_build_sector_table writes it: (2R+1)^2 entries, entry (oy+R)*(2R+1) + (ox+R) = bit mask of the
@@ -73,7 +111,9 @@ hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 struct LsdFork { hipStream_t s1, s2; hipEvent_t fork, join1, join2; };
 bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame: find_lines launches one kernel
 // mode 0: find_lines (whole frame); mode 1: one find_longest_line round from (px,py), result in results[f].lines[0], len^2 in length_px[0]
+// b.co (if present) is zeroed on `s` before the launch; extra_helpers: additional workgroups that only help (small batches).
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk);
+size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocation, zeroed per launch)
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);
 hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s);

@@ -6,6 +6,7 @@
 // right at a threshold, so the reference's scalar f32 operation order (no FMA contraction, IEEE divide) is
 // part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
 // structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 
@@ -51,6 +52,7 @@ __device__ RayDir g_ray_table[SMH_LSD_RAYS] = {
 #ifndef LSD_C_RESET
 #define LSD_C_RESET 2u
 #endif
+#define LSD_LOOKAHEAD 24u                          // candidates beyond its own group an owner posts for its helpers
 #define LSD_GROUPS ((SMH_LSD_RAYS + 63) / 64)      // 64-ray units per candidate (57)
 #define LSD_GROUPS_HOST 57
 #define LSD_UNITS (LSD_C * LSD_GROUPS)
@@ -335,6 +337,13 @@ struct LsdShared {
 	uint32_t cand_key[LSD_C];
 	uint32_t scan[LSD_NW];
 	uint32_t qtail, segnext, unit_next;
+	uint32_t cand_px[LSD_C][2];              // the candidates' pixels (start of get_centre)
+	uint32_t cand_wkey[LSD_C];               // their raster keys (word index << 5 | bit, + 1)
+	uint32_t cached;                         // candidates whose result came out of the helpers' cache
+	uint32_t post[LSD_LOOKAHEAD];            // look-ahead candidates to post (valid << 31 | pixel)
+	uint32_t req_tail, posted_hi, posted_new, helpers_seen, head_seen;
+	uint32_t h_n;                            // helper: claimed requests / flags
+	unsigned long long pick;
 	uint32_t nlive;                          // live units of the group, listed (in no particular order) in ulist
 	unsigned short ulist[LSD_UNITS];
 	unsigned long long live[LSD_C];          // units (64-ray sectors) of each candidate that have to be cast
@@ -555,49 +564,121 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 	__syncthreads();
 }
 
-template <int MODE>
-__device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max_gap, int mode, float spx, float spy, const FrameAux &aux,
-                          uint32_t *smem, LsdShared &sh, uint32_t *cull_tab) {
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	smhv_frame_result *res = &b.results[f];
-	const uint32_t *gbits = b.bits + (size_t)f * g.bits_stride_w;
+// ------------------------------------------------------------------------------------------------
+// cooperation primitives (LsdCoop / request ring / result cache; smh_kernels.h explains the scheme)
+// ------------------------------------------------------------------------------------------------
+#define LSD_MAX_HELPERS 4u            // helpers per frame
+#define LSD_HELP_MIN_REMAINING 24u    // a frame with fewer surviving candidates is not worth loading its mask
+#define LSD_CACHE_PROBES 6
+#define LSD_HELPER_IDLE_POLLS 12u     // polls (~4 us each) without a request before a helper leaves its frame / the kernel
 
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_acquire(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_relaxed(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_release(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ uint32_t pix_pack(uint32_t x, uint32_t y) { return x | (y << 12); }     // ROI sides are below 4096
+__device__ __forceinline__ uint32_t cache_slot0(uint32_t pix) { return (pix * 2654435761u) >> 23; }   // 9 bits = SMH_LSD_CACHE_SLOTS
+
+// -> true and the payload when the result for `pix` of this launch is present and complete
+__device__ bool cache_lookup(const LsdCacheEntry *tab, uint32_t epoch, uint32_t pix, unsigned long long &best, float &ex, float &ey, uint32_t &steps) {
+	static_assert(SMH_LSD_CACHE_SLOTS == 512u, "cache_slot0 yields 9 bits");
+	const unsigned long long want = ((unsigned long long)epoch << 32) | pix;
+	const uint32_t h = cache_slot0(pix);
+	for (int p = 0; p < LSD_CACHE_PROBES; ++p) {
+		const LsdCacheEntry *e = tab + ((h + (uint32_t)p) & (SMH_LSD_CACHE_SLOTS - 1u));
+		const unsigned long long tag = __hip_atomic_load(&e->tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+		if (tag == want) { best = e->best; ex = e->ex; ey = e->ey; steps = e->steps; return true; }
+		if ((uint32_t)(tag >> 32) != epoch) return false;           // a slot of another launch is an empty slot: end of the probe sequence
+	}
+	return false;
+}
+
+__device__ void cache_insert(LsdCacheEntry *tab, uint32_t epoch, uint32_t pix, unsigned long long best, float ex, float ey, uint32_t steps) {
+	const unsigned long long ready = ((unsigned long long)epoch << 32) | pix, busy = ready | 0x80000000ull;
+	const uint32_t h = cache_slot0(pix);
+	for (int p = 0; p < LSD_CACHE_PROBES; ++p) {
+		LsdCacheEntry *e = tab + ((h + (uint32_t)p) & (SMH_LSD_CACHE_SLOTS - 1u));
+		unsigned long long tag = __hip_atomic_load(&e->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		while ((uint32_t)(tag >> 32) != epoch) {                    // free: claim it, fill it, publish it
+			if (__hip_atomic_compare_exchange_strong(&e->tag, &tag, busy, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+				e->best = best; e->ex = ex; e->ey = ey; e->steps = steps;
+				__hip_atomic_store(&e->tag, ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+		}
+		if ((tag & ~0x80000000ull) == ready) return;                // another helper has (or is writing) this pixel
+	}
+}
+
+// One thread: claims up to LSD_C pending requests of a frame.  Entries carry the lap number of the ring so that one the
+// owner has meanwhile overwritten is recognised and dropped (a request is only ever a hint).
+__device__ uint32_t ring_claim(LsdCoop *co, const uint32_t *ring, uint32_t *pix_out) {
+	uint32_t head = ld_relaxed(&co->req_head);
+	const uint32_t tail = ld_acquire(&co->req_tail);
+	uint32_t n = 0;
+	while ((int)(tail - head) > 0) {
+		n = min(tail - head, LSD_C);
+		if (__hip_atomic_compare_exchange_strong(&co->req_head, &head, head + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+		n = 0;
+	}
+	uint32_t k = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint32_t v = ld_relaxed(&ring[(head + i) % SMH_LSD_REQ_CAP]);
+		if ((v >> 24) == (((head + i) / SMH_LSD_REQ_CAP) & 0xFFu)) pix_out[k++] = v & 0xFFFFFFu;
+	}
+	return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A frame's mask as a workgroup sees it: the sampling window `m` (three residency modes) and the compaction domain
+// (wrows x wwords words; word (r, c) holds pixels x = xorg + 32 c + [0,32) of image row wy0 + r).
+// ------------------------------------------------------------------------------------------------
+struct FrameView {
 	Win m;
+	const uint32_t *gbits;
+	uint32_t wy0, wrows, wwords;
+	int xorg;
+	uint32_t c_pitch, c_cap_rows;      // GLOBAL: geometry of the LDS row cache
+};
+
+template <int MODE>
+__device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uint32_t f, const FrameAux &aux, uint32_t *smem, FrameView &v) {
+	const uint32_t tid = threadIdx.x;
+	const uint32_t *gbits = b.bits + (size_t)f * g.bits_stride_w;
+	Win &m = v.m;
+	v.gbits = gbits;
 	m.w = g.rw; m.h = g.rh; m.wf = (float)g.rw; m.hf = (float)g.rh;
 	m.rows0 = nullptr; m.ylo_f = 0.0f; m.yhi_f = 0.0f;
 	m.c_p = (const LdsWord *)smem; m.c_y0 = 0u; m.c_rows = 0u; m.c_pitch4 = 0u;
-	uint32_t *list, *queue;
-	// compaction domain: wrows x wwords words; word (r, c) holds pixels x = xorg + 32 c + [0,32) of image row wy0 + r
-	uint32_t wy0, wrows, wwords;
-	int xorg;
-	PROF_DECL
+	v.c_pitch = g.bits_pitch_w | 1u; v.c_cap_rows = min(g.rh, LSD_WIN_WORDS_CAP / v.c_pitch);
 	if (MODE == LSD_MODE_ROWS) {
-		wy0 = aux.y_min; wrows = aux.y_max - aux.y_min + 1u; wwords = LSD_ROWS_PITCH(g.bits_pitch_w); xorg = 0;
-		const uint32_t pitch = wwords, gp = g.bits_pitch_w;          // odd LDS pitch: consecutive rows fall on different banks
+		const uint32_t wy0 = aux.y_min, wrows = aux.y_max - aux.y_min + 1u;
+		v.wy0 = wy0; v.wrows = wrows; v.wwords = LSD_ROWS_PITCH(g.bits_pitch_w); v.xorg = 0;
+		const uint32_t pitch = v.wwords, gp = g.bits_pitch_w;          // odd LDS pitch: consecutive rows fall on different banks
 		// [2 pad words][row y_min-1 = zeros][rows y_min..y_max, shifted right by xoff bits][row y_max+1 = zeros][2 pad words]
 		const uint32_t total = (wrows + 2u) * pitch + 4u;
 		for (uint32_t idx = tid; idx < total; idx += LSD_BS) {
-			uint32_t v = 0;
+			uint32_t val = 0;
 			if (idx >= 2u + pitch && idx < 2u + (wrows + 1u) * pitch) {
 				const uint32_t k = idx - 2u - pitch, r = k / pitch, c = k - r * pitch;
 				if (c < gp) {
 					const uint32_t *src = gbits + (size_t)(wy0 + r) * gp + c;
 					const uint32_t lo = src[0], hi = (c + 1u < gp) ? src[1] : 0u;
-					v = __builtin_amdgcn_alignbit(hi, lo, g.m_xoff);       // bit x of the row = pixel x
+					val = __builtin_amdgcn_alignbit(hi, lo, g.m_xoff);       // bit x of the row = pixel x
 				}
 			}
-			smem[idx] = v;
+			smem[idx] = val;
 		}
 		m.p = smem + 2; m.pitch4 = pitch * 4u;
 		m.y_lo = (int)wy0 - 1; m.rows_hi = wrows + 1u;
 		m.xbias = 0; m.cols_hi = pitch - 1u;
 		m.rows0 = (const char *)(smem + 2) - (ptrdiff_t)((int)wy0 - 1) * (ptrdiff_t)(pitch * 4u);
 		m.ylo_f = (float)((int)wy0 - 1); m.yhi_f = (float)(wy0 + wrows);
-		list = smem + LSD_WIN_WORDS_CAP;
 	} else if (MODE == LSD_MODE_XWIN) {
-		const uint32_t ww0 = aux.w_min;
-		wy0 = aux.y_min; wrows = aux.y_max - aux.y_min + 1u; wwords = aux.w_max - aux.w_min + 1u;
-		xorg = (int)(ww0 * 32u) - (int)g.m_xoff;
+		const uint32_t ww0 = aux.w_min, wy0 = aux.y_min, wrows = aux.y_max - aux.y_min + 1u, wwords = aux.w_max - aux.w_min + 1u;
+		v.wy0 = wy0; v.wrows = wrows; v.wwords = wwords;
+		v.xorg = (int)(ww0 * 32u) - (int)g.m_xoff;
 		const uint32_t pitch = (wwords + 2u) | 1u;                     // odd pitch: rows spread over the LDS banks
 		m.p = smem; m.pitch4 = pitch * 4u;
 		m.y_lo = (int)wy0 - 1; m.rows_hi = wrows + 1u;
@@ -605,36 +686,139 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		const uint32_t total = (wrows + 2u) * pitch;
 		for (uint32_t idx = tid; idx < total; idx += LSD_BS) {
 			const uint32_t r = idx / pitch, c = idx - r * pitch;
-			uint32_t v = 0;
-			if (r >= 1u && r <= wrows && c >= 1u && c <= wwords) v = gbits[(size_t)(wy0 + r - 1u) * g.bits_pitch_w + ww0 + c - 1u];
-			smem[idx] = v;
+			uint32_t val = 0;
+			if (r >= 1u && r <= wrows && c >= 1u && c <= wwords) val = gbits[(size_t)(wy0 + r - 1u) * g.bits_pitch_w + ww0 + c - 1u];
+			smem[idx] = val;
 		}
-		list = smem + LSD_WIN_WORDS_CAP;
 	} else {
-		wy0 = 0; wrows = g.rh; wwords = g.bits_pitch_w; xorg = -(int)g.m_xoff;
+		v.wy0 = 0; v.wrows = g.rh; v.wwords = g.bits_pitch_w; v.xorg = -(int)g.m_xoff;
 		m.p = gbits; m.pitch4 = g.bits_pitch_w * 4u;
 		m.y_lo = 0; m.rows_hi = g.rh - 1u;
 		m.xbias = (int)g.m_xoff; m.cols_hi = g.bits_pitch_w - 1u;
-		list = smem + LSD_WIN_WORDS_CAP;
 	}
-	// GLOBAL: (re)load the row cache so that it covers rows [lo, hi] (a uniform decision; hi - lo < rows that fit)
-	const uint32_t c_pitch = g.bits_pitch_w | 1u, c_cap_rows = min(g.rh, LSD_WIN_WORDS_CAP / c_pitch);
-	auto cache_cover = [&](int lo, int hi) __attribute__((always_inline)) {
-		if (MODE != LSD_MODE_GLOBAL) return;
-		lo = max(lo, 0); hi = min(hi, (int)g.rh - 1);
-		if (m.c_rows && lo >= (int)m.c_y0 && hi < (int)(m.c_y0 + m.c_rows)) return;
-		__syncthreads();                                   // nobody still reads the old rows
-		const uint32_t y0 = (uint32_t)min(lo, (int)(g.rh - c_cap_rows));
-		for (uint32_t idx = tid; idx < c_cap_rows * c_pitch; idx += LSD_BS) {
-			const uint32_t r = idx / c_pitch, c = idx - r * c_pitch;
-			smem[idx] = c < g.bits_pitch_w ? gbits[(size_t)(y0 + r) * g.bits_pitch_w + c] : 0u;
-		}
-		m.c_y0 = y0; m.c_rows = c_cap_rows; m.c_pitch4 = c_pitch * 4u;
-		__syncthreads();
-	};
-	queue = list + LSD_LIST_CAP;
-	const uint32_t WT = wrows * wwords;   // word index wi -> row wi / wwords, column wi % wwords
 	__syncthreads();
+}
+
+// GLOBAL: (re)load the row cache so that it covers rows [lo, hi] (a uniform decision).  Rows outside it are read from
+// global memory, so the coverage only ever matters for speed.
+template <int MODE>
+__device__ __forceinline__ void cache_cover(const Geom &g, FrameView &v, uint32_t *smem, int lo, int hi) {
+	if (MODE != LSD_MODE_GLOBAL) return;
+	Win &m = v.m;
+	lo = max(lo, 0); hi = min(hi, (int)g.rh - 1);
+	if (m.c_rows && lo >= (int)m.c_y0 && hi < (int)(m.c_y0 + m.c_rows)) return;
+	__syncthreads();                                   // nobody still reads the old rows
+	const uint32_t y0 = (uint32_t)min(lo, (int)(g.rh - v.c_cap_rows));
+	for (uint32_t idx = threadIdx.x; idx < v.c_cap_rows * v.c_pitch; idx += LSD_BS) {
+		const uint32_t r = idx / v.c_pitch, c = idx - r * v.c_pitch;
+		smem[idx] = c < g.bits_pitch_w ? v.gbits[(size_t)(y0 + r) * g.bits_pitch_w + c] : 0u;
+	}
+	m.c_y0 = y0; m.c_rows = v.c_cap_rows; m.c_pitch4 = v.c_pitch * 4u;
+	__syncthreads();
+}
+
+// Reset the per-group accumulators for nc candidates (followed by a barrier at the caller).
+__device__ __forceinline__ void group_reset(LsdShared &sh, uint32_t nc, bool cull) {
+	const uint32_t tid = threadIdx.x;
+	if (tid < nc * LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; }
+	if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; sh.live[tid] = cull ? 0ull : ~0ull; }
+	if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; sh.nlive = 0u; sh.cached = 0u;
+#ifdef SMH_LSD_PROFILE
+		sh.exp_far = 0u; sh.exp_units = 0u;
+#endif
+	}
+}
+
+// find_longest_line for the nc pixels in sh.cand_px (their accumulators reset, barrier passed): get_centre of each,
+// sector culling, unit list and the ray engine for the candidates whose bit in sh.cached is clear.  On return (after a
+// barrier) sh.cand_pt holds every start point and sh.cand_best / cand_end / cand_steps the results of the cast ones.
+template <int MODE>
+__device__ __forceinline__ void cast_group(const Win &m, LsdShared &sh, uint32_t *queue, const uint32_t *cull_tab, uint32_t nc, bool cull, float max_gap,
+                                           unsigned long long *prof_t = nullptr) {
+	const uint32_t tid = threadIdx.x;
+#ifdef SMH_LSD_PROFILE
+	unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#endif
+	if (tid < nc * 32u) {
+		// get_centre (lsd.rs:5-44) of the nc integer pixel positions, 32 lanes per candidate: lane (dir, k)
+		// evaluates the k-th loop condition of direction dir (left, right, up, down); the walk length is the
+		// number of leading true conditions (k = 5 always fails: |offset| < 5.0).  px - k is exact in f32.
+		const uint32_t c = tid >> 5, l = tid & 31u, dir = l >> 3, k = l & 7u;
+		const float cx = (float)sh.cand_px[c][0], cy = (float)sh.cand_px[c][1];
+		const float fk = (float)k;
+		bool cond = k < 5u;
+		if (dir == 0u) cond = cond && (cx - fk > 0.0f) && white_at(m, cx - fk, cy);
+		else if (dir == 1u) cond = cond && (cx + fk < (float)(m.w - 1u)) && white_at(m, cx + fk, cy);
+		else if (dir == 2u) cond = cond && (cy - fk > 0.0f) && white_at(m, cx, cy - fk);
+		else cond = cond && (cy + fk < (float)(m.h - 1u)) && white_at(m, cx, cy + fk);
+		const uint32_t bits = (uint32_t)(__ballot(cond) >> (tid & 32u));
+		if (l == 0u) {
+			const float nl = (float)__builtin_ctz(~(bits & 0xFFu)), nr = (float)__builtin_ctz(~((bits >> 8) & 0xFFu));
+			const float nu = (float)__builtin_ctz(~((bits >> 16) & 0xFFu)), nd = (float)__builtin_ctz(~((bits >> 24) & 0xFFu));
+			sh.cand_pt[c][0] = ((cx - nl) + (cx + nr)) / 2.0f;
+			sh.cand_pt[c][1] = ((cy - nu) + (cy + nd)) / 2.0f;
+		}
+	}
+	__syncthreads();
+#ifdef SMH_LSD_PROFILE
+	if (prof_t) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[10] += _n - prof_last; prof_last = _n; }
+#endif
+	const uint32_t cached = sh.cached;
+	if (cull) {
+		// ---- sector culling: which 64-ray units can see a white pixel at a distance in [50 - T, 50]? ----
+		// One thread per (candidate, row, 32-pixel word) cell of the (2R+1)-row neighbourhood: the mask word,
+		// funnel-shifted so that bit 0 is offset -R from floor(start point), is ANDed with the annulus mask of
+		// the cell; every white annulus pixel left contributes its unit range (a byte code per pixel).
+		for (uint32_t id = tid; id < nc * SMH_CULL_CELLS; id += LSD_BS) {
+			const uint32_t c = id / SMH_CULL_CELLS, cell = id - c * SMH_CULL_CELLS;
+			if ((cached >> c) & 1u) continue;
+			const int fx = (int)floorf(sh.cand_pt[c][0]), fy = (int)floorf(sh.cand_pt[c][1]);
+			const int yi = fy + (int)(cell >> 2) - SMH_SECTOR_R;
+			if ((uint32_t)yi >= m.h) continue;
+			const int b0 = fx - SMH_SECTOR_R + (int)((cell & 3u) << 5) + m.xbias;   // view bit coordinate of the cell's bit 0
+			const uint32_t lo = win_word(m, b0 >> 5, yi), hi = win_word(m, (b0 >> 5) + 1, yi);
+			uint32_t hit = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)b0 & 31u) & cull_tab[cell];
+			if (hit) {
+				const uint8_t *codes = (const uint8_t *)(cull_tab + SMH_CULL_CELLS) + (cell >> 2) * SMH_SECTOR_DIM + ((cell & 3u) << 5);
+				unsigned long long acc = 0ull;
+				while (hit) {                           // white annulus pixels of this word: their unit ranges
+					const uint32_t code = codes[__builtin_ctz(hit)];
+					hit &= hit - 1u;
+					acc |= code == 0xFFu ? ~0ull : ((2ull << (code >> 6)) - 1ull) << (code & 63u);   // first <= 56, n <= 4
+				}
+				atomicOr(&sh.live[c], (acc | (acc >> LSD_GROUPS)) & ((1ull << LSD_GROUPS) - 1ull));   // units wrap at 57
+			}
+		}
+		__syncthreads();
+	}
+	if (tid < nc * LSD_GROUPS) {                    // list the units that have to be cast
+		const uint32_t c = tid / LSD_GROUPS;
+		if (!((cached >> c) & 1u) && ((sh.live[c] >> (tid - c * LSD_GROUPS)) & 1ull)) sh.ulist[atomicAdd(&sh.nlive, 1u)] = (unsigned short)tid;
+	}
+	__syncthreads();
+#ifdef SMH_LSD_PROFILE
+	if (prof_t) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof_t[11] += _n - prof_last; prof_last = _n; }
+#endif
+	if (sh.nlive != 0u) ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);   // else every cast candidate is rejected: cand_best = 0
+}
+
+// ------------------------------------------------------------------------------------------------
+// lsd::find_lines::<32> (vision-common/src/lsd.rs:60-107) of frame f by its owner workgroup; mode 1: one
+// Vision::find_longest_line round.  `co` != nullptr: helpers may be attached (posting + result cache).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max_gap, int mode, float spx, float spy, const FrameAux &aux,
+                          uint32_t *smem, LsdShared &sh, uint32_t *cull_tab, LsdCoop *co) {
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	smhv_frame_result *res = &b.results[f];
+	PROF_DECL
+	FrameView v;
+	frame_setup<MODE>(g, b, f, aux, smem, v);
+	Win &m = v.m;
+	uint32_t *list = smem + LSD_WIN_WORDS_CAP, *queue = list + LSD_LIST_CAP;
+	const uint32_t wy0 = v.wy0, wrows = v.wrows, wwords = v.wwords;
+	const int xorg = v.xorg;
+	const uint32_t WT = wrows * wwords;   // word index wi -> row wi / wwords, column wi % wwords
 	auto dom_word = [&](uint32_t wi) -> uint32_t {
 		const uint32_t r = wi / wwords, c = wi - r * wwords;
 		if (MODE == LSD_MODE_ROWS) return m.p[(r + 1u) * wwords + c];
@@ -644,7 +828,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 
 	if (mode == 1) {   // Vision::find_longest_line on an arbitrary point
 		if (tid < LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; sh.ulist[tid] = (unsigned short)tid; }
-		cache_cover((int)spy - (int)(c_cap_rows / 2u), (int)spy - (int)(c_cap_rows / 2u) + (int)c_cap_rows - 1);
+		cache_cover<MODE>(g, v, smem, (int)spy - (int)(v.c_cap_rows / 2u), (int)spy - (int)(v.c_cap_rows / 2u) + (int)v.c_cap_rows - 1);
 		if (tid == 0) { sh.live[0] = ~0ull; sh.cand_best[0] = 0ull; sh.cand_steps[0] = 0u; sh.cand_kmax[0] = 0u; sh.qtail = 0u; sh.unit_next = LSD_NW; sh.nlive = LSD_GROUPS; sh.cand_pt[0][0] = spx; sh.cand_pt[0][1] = spy; }
 		__syncthreads();
 		ray_engine<MODE>(m, sh, queue, 1u, max_gap, true PROF_ARG);
@@ -658,7 +842,10 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 
 	// sector culling needs the table for this max_gap (absent in exact-statistics mode) and a gap threshold below 50
 	const bool cull = b.cull_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
-	if (cull) for (uint32_t i = tid; i < SMH_CULL_TAB_WORDS; i += LSD_BS) cull_tab[i] = b.cull_tab[i];   // visible after the first barrier below
+	const uint32_t *ring = co ? b.co.req + (size_t)f * SMH_LSD_REQ_CAP : nullptr;
+	const LsdCacheEntry *ctab = co ? b.co.cache + (size_t)f * SMH_LSD_CACHE_SLOTS : nullptr;
+	if (tid == 0) { sh.req_tail = 0u; sh.posted_hi = 0u; sh.posted_new = 0u; sh.helpers_seen = 0u; sh.head_seen = 0u; if (co) st_relaxed(&co->mode1, (uint32_t)MODE + 1u); }
+	if (tid < LSD_LOOKAHEAD) sh.post[tid] = 0u;
 	uint32_t rounds = 0, n_lines = 0;
 	unsigned long long steps = 0ull;
 	uint32_t seg_start = 0, cmax = 1u;
@@ -693,7 +880,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 
 		for (uint32_t cbase = 0; cbase < Tn && !done; cbase += LSD_BS) {
 			const uint32_t e = cbase + tid;
-			uint32_t surv = 0;
+			uint32_t surv = 0, wkey0 = 0;
 			float py = 0.0f, px0 = 0.0f;
 			if (e < Tn) {
 				const uint32_t wi = list[e];
@@ -701,9 +888,15 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				const uint32_t r = wi / wwords, c = wi - r * wwords;
 				py = (float)(wy0 + r);
 				px0 = (float)(xorg + (int)(c * 32u));
+				wkey0 = (wi << 5) + 1u;                                // raster key of the word's bit 0 (> 0, grows along the scan)
 				for (uint32_t l = 0; l < n_lines && surv; ++l) surv = prox_filter_word(surv, px0, py, shared_prox_line(sh, l));
 			}
 			while (true) {
+				// the coop line of this frame is fetched under the scan: are helpers attached, how far have they claimed?
+				if (co && tid == 0) {
+					sh.helpers_seen = ld_relaxed(&co->helpers); sh.head_seen = ld_relaxed(&co->req_head);
+					sh.posted_hi = max(sh.posted_hi, sh.posted_new);       // what the previous group posted
+				}
 				// ---- the next (up to) LSD_C surviving white pixels in raster order ----
 				const uint32_t pc = __popc(surv);
 				uint32_t pin = pc;
@@ -714,95 +907,78 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 #pragma unroll
 				for (int k = 0; k < LSD_NW; ++k) { const uint32_t s = sh.scan[k]; if ((uint32_t)k < wave) wp += s; tot += s; }
 				if (tot == 0u) break;
+				const bool helped = co != nullptr && sh.helpers_seen != 0u;
+				const uint32_t posted_hi = sh.posted_hi;
 				uint32_t nc = min(tot, cmax);
 				uint32_t rank = wp + pin - pc;
 				while (surv && rank < cmax) {
 					const uint32_t bit = __builtin_ctz(surv);
 					surv &= surv - 1u;
 					sh.cand_key[rank] = (tid << 5) | bit;
+					sh.cand_wkey[rank] = wkey0 + bit;
+					sh.cand_px[rank][0] = (uint32_t)((int)px0 + (int)bit); sh.cand_px[rank][1] = (uint32_t)py;
 					++rank;
 				}
-				if (tid < nc * LSD_GROUPS) { sh.unit_key[tid] = 0ull; sh.unit_kmax[tid] = 0u; }
-				if (tid < LSD_C) { sh.cand_best[tid] = 0ull; sh.cand_steps[tid] = 0u; sh.cand_kmax[tid] = 0u; sh.live[tid] = cull ? 0ull : ~0ull; }
-				if (tid == 0) { sh.qtail = 0u; sh.unit_next = LSD_NW; sh.nlive = 0u;
-#ifdef SMH_LSD_PROFILE
-					sh.exp_far = 0u; sh.exp_units = 0u;
-#endif
+				if (helped) {
+					// the LSD_LOOKAHEAD survivors behind this group, as far as they have not been posted yet, go to the helpers
+					uint32_t s2 = surv, r2 = rank;
+					while (s2 && r2 < cmax + LSD_LOOKAHEAD) {
+						const uint32_t bit = __builtin_ctz(s2);
+						s2 &= s2 - 1u;
+						if (r2 >= cmax && wkey0 + bit > posted_hi) {
+							sh.post[r2 - cmax] = 0x80000000u | pix_pack((uint32_t)((int)px0 + (int)bit), (uint32_t)py);
+							atomicMax(&sh.posted_new, wkey0 + bit);
+						}
+						++r2;
+					}
 				}
+				if (co && tid == 0) st_relaxed(&co->remaining, tot);
+				group_reset(sh, nc, cull);
 				__syncthreads();
 				if (MODE == LSD_MODE_GLOBAL) {
 					// Keep the mask rows every candidate of this group can reach in pass 1 (64 samples), the culling scan and
 					// get_centre inside the LDS row cache; candidates (in raster order) that would not fit are handed back.
-					auto cand_row = [&](uint32_t c) { return (int)(wy0 + list[cbase + (sh.cand_key[c] >> 5)] / wwords); };
-					const int lo = max(cand_row(0) - LSD_CACHE_MARGIN, 0);
+					const int lo = max((int)sh.cand_px[0][1] - LSD_CACHE_MARGIN, 0);
 					uint32_t nce = 1;
-					while (nce < nc && cand_row(nce) + LSD_CACHE_MARGIN - lo < (int)c_cap_rows) ++nce;
+					while (nce < nc && (int)sh.cand_px[nce][1] + LSD_CACHE_MARGIN - lo < (int)v.c_cap_rows) ++nce;
 					for (uint32_t c = nce; c < nc; ++c) {
 						const uint32_t key = sh.cand_key[c];
 						if ((key >> 5) == tid) surv |= 1u << (key & 31u);
 					}
 					nc = nce;
-					cache_cover(lo, cand_row(nc - 1) + LSD_CACHE_MARGIN);
+					cache_cover<MODE>(g, v, smem, lo, (int)sh.cand_px[nc - 1u][1] + LSD_CACHE_MARGIN);
 				}
-				if (tid < nc * 32u) {
-					// get_centre (lsd.rs:5-44) of the nc integer pixel positions, 32 lanes per candidate: lane (dir, k)
-					// evaluates the k-th loop condition of direction dir (left, right, up, down); the walk length is the
-					// number of leading true conditions (k = 5 always fails: |offset| < 5.0).  px - k is exact in f32.
-					const uint32_t c = tid >> 5, l = tid & 31u, dir = l >> 3, k = l & 7u;
-					const uint32_t key = sh.cand_key[c];
-					const uint32_t cwi = list[cbase + (key >> 5)];
-					const uint32_t cr = cwi / wwords, cc = cwi - cr * wwords;
-					const float cy = (float)(wy0 + cr);
-					const float cx = (float)(xorg + (int)(cc * 32u + (key & 31u)));
-					const float fk = (float)k;
-					bool cond = k < 5u;
-					if (dir == 0u) cond = cond && (cx - fk > 0.0f) && white_at(m, cx - fk, cy);
-					else if (dir == 1u) cond = cond && (cx + fk < (float)(m.w - 1u)) && white_at(m, cx + fk, cy);
-					else if (dir == 2u) cond = cond && (cy - fk > 0.0f) && white_at(m, cx, cy - fk);
-					else cond = cond && (cy + fk < (float)(m.h - 1u)) && white_at(m, cx, cy + fk);
-					const uint32_t bits = (uint32_t)(__ballot(cond) >> (tid & 32u));
-					if (l == 0u) {
-						const float nl = (float)__builtin_ctz(~(bits & 0xFFu)), nr = (float)__builtin_ctz(~((bits >> 8) & 0xFFu));
-						const float nu = (float)__builtin_ctz(~((bits >> 16) & 0xFFu)), nd = (float)__builtin_ctz(~((bits >> 24) & 0xFFu));
-						sh.cand_pt[c][0] = ((cx - nl) + (cx + nr)) / 2.0f;
-						sh.cand_pt[c][1] = ((cy - nu) + (cy + nd)) / 2.0f;
-					}
-				}
-				__syncthreads();
-				PROF_MARK(10);  // chunk filter + candidate selection + centres
-				if (cull) {
-					// ---- sector culling: which 64-ray units can see a white pixel at a distance in [50 - T, 50]? ----
-					// One thread per (candidate, row, 32-pixel word) cell of the (2R+1)-row neighbourhood: the mask word,
-					// funnel-shifted so that bit 0 is offset -R from floor(start point), is ANDed with the annulus mask of
-					// the cell; every white annulus pixel left contributes its unit range (a byte code per pixel).
-					for (uint32_t id = tid; id < nc * SMH_CULL_CELLS; id += LSD_BS) {
-						const uint32_t c = id / SMH_CULL_CELLS, cell = id - c * SMH_CULL_CELLS;
-						const int fx = (int)floorf(sh.cand_pt[c][0]), fy = (int)floorf(sh.cand_pt[c][1]);
-						const int yi = fy + (int)(cell >> 2) - SMH_SECTOR_R;
-						if ((uint32_t)yi >= m.h) continue;
-						const int b0 = fx - SMH_SECTOR_R + (int)((cell & 3u) << 5) + m.xbias;   // view bit coordinate of the cell's bit 0
-						const uint32_t lo = win_word(m, b0 >> 5, yi), hi = win_word(m, (b0 >> 5) + 1, yi);
-						uint32_t hit = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)b0 & 31u) & cull_tab[cell];
-						if (hit) {
-							const uint8_t *codes = (const uint8_t *)(cull_tab + SMH_CULL_CELLS) + (cell >> 2) * SMH_SECTOR_DIM + ((cell & 3u) << 5);
-							unsigned long long acc = 0ull;
-							while (hit) {                           // white annulus pixels of this word: their unit ranges
-								const uint32_t code = codes[__builtin_ctz(hit)];
-								hit &= hit - 1u;
-								acc |= code == 0xFFu ? ~0ull : ((2ull << (code >> 6)) - 1ull) << (code & 63u);   // first <= 56, n <= 4
-							}
-							atomicOr(&sh.live[c], (acc | (acc >> LSD_GROUPS)) & ((1ull << LSD_GROUPS) - 1ull));   // units wrap at 57
+				if (helped) {
+					if (wave == 0) {
+						// post the look-ahead (wave 0 owns the ring), in raster order, as far as the ring has room
+						const uint32_t pv = lane < LSD_LOOKAHEAD ? sh.post[lane] : 0u;
+						if (lane < LSD_LOOKAHEAD) sh.post[lane] = 0u;
+						const unsigned long long valid = __ballot((pv >> 31) != 0u);
+						const uint32_t tail = sh.req_tail, used = tail - min(sh.head_seen, tail);
+						const uint32_t room = SMH_LSD_REQ_CAP - min(used, SMH_LSD_REQ_CAP);
+						const uint32_t pos = (uint32_t)__popcll(valid & ((1ull << lane) - 1ull));
+						const uint32_t np = min((uint32_t)__popcll(valid), room);
+						if ((pv >> 31) && pos < np) {
+							const uint32_t idx = tail + pos;
+							st_relaxed(const_cast<uint32_t *>(ring) + idx % SMH_LSD_REQ_CAP, (((idx / SMH_LSD_REQ_CAP) & 0xFFu) << 24) | (pv & 0xFFFFFFu));
+						}
+						if (lane == 0 && np) { st_release(&co->req_tail, tail + np); sh.req_tail = tail + np; }
+						if (lane == 0) __hip_atomic_fetch_add(&co->stat_groups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					} else if (tid >= 64u && tid < 64u + nc) {
+						// has a helper already cast this candidate?  (keys are per launch; a hit is the result this workgroup
+						// would compute itself: ray casting is a pure function of the mask and the pixel)
+						const uint32_t c = tid - 64u;
+						unsigned long long best; float ex, ey; uint32_t st;
+						if (cache_lookup(ctab, b.co.epoch, pix_pack(sh.cand_px[c][0], sh.cand_px[c][1]), best, ex, ey, st)) {
+							sh.cand_best[c] = best; sh.cand_end[c][0] = ex; sh.cand_end[c][1] = ey; sh.cand_steps[c] = st;
+							atomicOr(&sh.cached, 1u << c);
+							__hip_atomic_fetch_add(&co->stat_hits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						}
 					}
 					__syncthreads();
 				}
-				if (tid < nc * LSD_GROUPS) {                    // list the units that have to be cast
-					const uint32_t c = tid / LSD_GROUPS;
-					if ((sh.live[c] >> (tid - c * LSD_GROUPS)) & 1ull) sh.ulist[atomicAdd(&sh.nlive, 1u)] = (unsigned short)tid;
-				}
-				__syncthreads();
-				PROF_MARK(11);  // sector culling scan
-				if (sh.nlive != 0u) ray_engine<MODE>(m, sh, queue, nc, max_gap, false PROF_ARG);   // else every candidate of the group is rejected: cand_best = 0
+				PROF_MARK(10);  // chunk filter + candidate selection
+				cast_group<MODE>(m, sh, queue, cull_tab, nc, cull, max_gap PROF_ARG);
 #ifdef SMH_LSD_PROFILE
 				prof_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -810,11 +986,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 				// ---- resolve in raster order (every thread computes the same thing) ----
 				const uint32_t first_new = n_lines;
 				for (uint32_t c = 0; c < nc; ++c) {
-					const uint32_t key = sh.cand_key[c];
-					const uint32_t cwi = list[cbase + (key >> 5)];
-					const uint32_t cr = cwi / wwords, cc = cwi - cr * wwords;
-					const float cy = (float)(wy0 + cr);
-					const float cx = (float)(xorg + (int)(cc * 32u + (key & 31u)));
+					const float cx = (float)sh.cand_px[c][0], cy = (float)sh.cand_px[c][1];
 					bool skip = false;
 					for (uint32_t l = first_new; l < n_lines; ++l)
 						skip = skip || near_line(cx, cy, sh.lines[l][0], sh.lines[l][1], sh.lines[l][2], sh.lines[l][3]);
@@ -825,7 +997,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					if (len > SMH_LSD_ACCEPT_LEN_SQ) {
 						float ex, ey;
 						get_centre(m, sh.cand_end[c][0], sh.cand_end[c][1], ex, ey);
-						// every thread stores the same four values (no barrier needed for its own later reads)
+						// every thread stores the same values (no barrier needed for its own later reads)
 						sh.lines[n_lines][0] = sh.cand_pt[c][0]; sh.lines[n_lines][1] = sh.cand_pt[c][1];
 						sh.lines[n_lines][2] = ex; sh.lines[n_lines][3] = ey;
 						const ProxLine pl = prox_line(sh.cand_pt[c][0], sh.cand_pt[c][1], ex, ey);
@@ -835,6 +1007,11 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 					}
 				}
 				if (done) break;
+				if (helped && n_lines != first_new && tid == 0) {
+					// a new line: what is pending in the ring was chosen without it -- drop it and post afresh from here on
+					__hip_atomic_fetch_max(&co->req_head, sh.req_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					sh.posted_hi = sh.cand_wkey[nc - 1u]; sh.posted_new = 0u;
+				}
 				// Speculation width: a line accepted inside a group invalidates the later candidates of that
 				// group near it (wasted ray casts), and acceptances cluster (first pixels of a marker), so the
 				// width restarts at 1 after an acceptance and doubles after every acceptance-free group.
@@ -857,6 +1034,103 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 	PROF_STORE(res);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Helper: a workgroup with nothing (left) to do of its own attaches to the frame with the most surviving candidates
+// per helper, loads its mask and ray-casts the candidates the owner has posted; results go into the frame's cache.
+// It leaves when every owner of the launch has finished, or when nothing has needed it for a while.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ void lsd_help(const Geom &g, const Buffers &b, uint32_t n_frames, float max_gap, uint32_t *smem, LsdShared &sh, uint32_t *cull_tab, bool have_cull_tab) {
+	const uint32_t tid = threadIdx.x;
+	const bool cull = b.cull_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
+	if (cull && !have_cull_tab) for (uint32_t i = tid; i < SMH_CULL_TAB_WORDS; i += LSD_BS) cull_tab[i] = b.cull_tab[i];
+	uint32_t *queue = smem + LSD_WIN_WORDS_CAP + LSD_LIST_CAP;
+	uint32_t idle = 0;
+	while (true) {
+		// ---- pick: most remaining candidates per attached helper ----
+		unsigned long long key = 0ull;
+		for (uint32_t f = tid; f < n_frames; f += LSD_BS) {
+			const LsdCoop *c = &b.co.coop[f];
+			const uint32_t rem = ld_relaxed(&c->remaining), hl = ld_relaxed(&c->helpers), dn = ld_relaxed(&c->done);
+			// (the mode is published before `remaining`: a frame of another residency kernel would not fit this one's window)
+			if (!dn && hl < LSD_MAX_HELPERS && rem >= LSD_HELP_MIN_REMAINING && ld_relaxed(&c->mode1) == (uint32_t)MODE + 1u) {
+				const unsigned long long k = ((unsigned long long)(rem / (hl + 1u)) << 32) | f;
+				key = k > key ? k : key;
+			}
+		}
+		if (tid == 0) sh.pick = 0ull;
+		__syncthreads();
+		key = wave_max64(key);
+		if ((tid & 63u) == 0 && key) atomicMax(&sh.pick, key);
+		__syncthreads();
+		const unsigned long long pick = sh.pick;
+		if (pick == 0ull) {
+			if (tid == 0) sh.h_n = ld_relaxed(&b.co.ctl->finished[MODE]);      // one reader: the decision must be the same in every wave
+			__syncthreads();
+			const uint32_t fin = sh.h_n;
+			__syncthreads();
+			if (fin >= n_frames || ++idle > LSD_HELPER_IDLE_POLLS) return;
+			__builtin_amdgcn_s_sleep(127);
+			continue;
+		}
+		const uint32_t f = (uint32_t)pick;
+		LsdCoop *co = &b.co.coop[f];
+		if (tid == 0) {
+			const uint32_t prev = __hip_atomic_fetch_add(&co->helpers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			sh.h_n = prev < LSD_MAX_HELPERS ? 1u : 0u;
+			if (prev >= LSD_MAX_HELPERS) __hip_atomic_fetch_sub(&co->helpers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__syncthreads();
+		if (sh.h_n == 0u) { __syncthreads(); continue; }
+		__syncthreads();
+		const FrameAux aux = b.aux[f];
+		FrameView v;
+		frame_setup<MODE>(g, b, f, aux, smem, v);
+		const uint32_t *ring = b.co.req + (size_t)f * SMH_LSD_REQ_CAP;
+		LsdCacheEntry *ctab = b.co.cache + (size_t)f * SMH_LSD_CACHE_SLOTS;
+		uint32_t misses = 0;
+		while (true) {
+			if (tid == 0) {
+				uint32_t px[LSD_C];
+				uint32_t n = 0;
+				if (ld_relaxed(&co->done)) n = 0xFFFFFFFFu;
+				else {
+					const uint32_t got = ring_claim(co, ring, px);
+					for (uint32_t i = 0; i < got; ++i) {
+						const uint32_t x = px[i] & 0xFFFu, y = px[i] >> 12;
+						unsigned long long best; float ex, ey; uint32_t st;
+						if (x < v.m.w && y < v.m.h && !cache_lookup(ctab, b.co.epoch, px[i], best, ex, ey, st)) { sh.cand_px[n][0] = x; sh.cand_px[n][1] = y; ++n; }
+					}
+				}
+				sh.h_n = n;
+			}
+			__syncthreads();
+			const uint32_t nc = sh.h_n;
+			if (nc == 0xFFFFFFFFu) break;                      // the owner has finished
+			if (nc == 0u) {
+				__syncthreads();
+				if (++misses > LSD_HELPER_IDLE_POLLS) break;
+				__builtin_amdgcn_s_sleep(127);
+				continue;
+			}
+			misses = 0; idle = 0;
+			group_reset(sh, nc, cull);
+			__syncthreads();
+			if (MODE == LSD_MODE_GLOBAL) {
+				int lo = (int)sh.cand_px[0][1], hi = lo;
+				for (uint32_t c = 1; c < nc; ++c) { lo = min(lo, (int)sh.cand_px[c][1]); hi = max(hi, (int)sh.cand_px[c][1]); }
+				cache_cover<MODE>(g, v, smem, lo - LSD_CACHE_MARGIN, min(hi + LSD_CACHE_MARGIN, lo - LSD_CACHE_MARGIN + (int)v.c_cap_rows - 1));
+			}
+			cast_group<MODE>(v.m, sh, queue, cull_tab, nc, cull, max_gap);
+			if (tid == 0) __hip_atomic_fetch_add(&co->stat_casts, nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (tid < nc) cache_insert(ctab, b.co.epoch, pix_pack(sh.cand_px[tid][0], sh.cand_px[tid][1]), sh.cand_best[tid], sh.cand_end[tid][0], sh.cand_end[tid][1], sh.cand_steps[tid]);
+			__syncthreads();
+		}
+		if (tid == 0) __hip_atomic_fetch_sub(&co->helpers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+	}
+}
+
 // One kernel per mask residency mode, each over all frames: a workgroup whose frame needs another mode exits at
 // once (launch_lsd runs them side by side, or only the ROWS one when the frame size guarantees it).  Split this way
 // the common ROWS kernel carries no call to the rarely used variants: 113 VGPRs and no scratch, where a kernel
@@ -871,24 +1145,51 @@ __device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux) 
 	return lmode;
 }
 
+// grid = n_frames owner workgroups (+ extra workgroups that only help, for batches smaller than the chip)
 template <int MODE>
-__global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy) {
+__global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy, uint32_t n_frames) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ LsdShared sh;
 	__shared__ uint32_t cull_tab[SMH_CULL_TAB_WORDS];
 	const uint32_t f = blockIdx.x;
-	const FrameAux aux = b.aux[f];
-	if (mode == 0) {
-		// Record ownership is exclusive: the three mode kernels may run concurrently on forked streams, so a frame's record is
-		// touched only by the kernel that owns the frame -- lsd_frame always stores n_lines / rounds / ray_steps at its end --
-		// and frames nobody searches (map closed, empty mask) are zeroed by the ROWS kernel alone.
-		if (!aux.open || aux.n_mask_px == 0) {
-			if (MODE == LSD_MODE_ROWS && threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
-			return;
+	const bool coop = mode == 0 && b.co.ctl != nullptr;
+	bool have_tab = false;
+	if (f < n_frames) {
+		if (coop && threadIdx.x == 0) __hip_atomic_fetch_add(&b.co.ctl->started[MODE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const FrameAux aux = b.aux[f];
+		bool mine = true;
+		if (mode == 0) {
+			// Record ownership is exclusive: the three mode kernels may run concurrently on forked streams, so a frame's record is
+			// touched only by the kernel that owns the frame -- lsd_frame always stores n_lines / rounds / ray_steps at its end --
+			// and frames nobody searches (map closed, empty mask) are zeroed by the ROWS kernel alone.
+			if (!aux.open || aux.n_mask_px == 0) {
+				if (MODE == LSD_MODE_ROWS && threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
+				mine = false;
+			}
 		}
+		if (mine && lsd_mode_for(g, aux) != MODE) mine = false;
+		if (mine) {
+			const bool cull = mode == 0 && b.cull_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
+			if (cull) { for (uint32_t i = threadIdx.x; i < SMH_CULL_TAB_WORDS; i += LSD_BS) cull_tab[i] = b.cull_tab[i]; have_tab = true; }   // visible after the barrier in frame_setup
+			lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh, cull_tab, coop ? &b.co.coop[f] : nullptr);
+		}
+		if (!coop) return;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			if (mine) { st_relaxed(&b.co.coop[f].remaining, 0u); st_release(&b.co.coop[f].done, 1u); }
+			__hip_atomic_fetch_add(&b.co.ctl->finished[MODE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// Helping holds this CU: only when every owner workgroup of the launch has been dispatched (they are dispatched in
+			// index order), and never for a workgroup that had no frame of its own (it would only sit on the CU another mode's
+			// kernel is waiting for).
+			sh.h_n = (mine && ld_relaxed(&b.co.ctl->started[MODE]) >= n_frames) ? 1u : 0u;
+		}
+		__syncthreads();
+		if (sh.h_n == 0u) return;
+		__syncthreads();
+	} else if (!coop) {
+		return;
 	}
-	if (lsd_mode_for(g, aux) != MODE) return;
-	lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh, cull_tab);
+	lsd_help<MODE>(g, b, n_frames, max_gap, smem, sh, cull_tab, have_tab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -957,6 +1258,23 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	}
 	// every non-empty frame of this size is a ROWS frame (lsd_mode_for): the other two kernels would only exit
 	const bool rows_only = mode == 0 && lsd_rows_only(g);
+	const bool coop = mode == 0 && b.co.ctl != nullptr;
+	if (coop) {
+		hipError_t e = hipMemsetAsync(b.co.ctl, 0, lsd_coop_ctl_bytes(n), s);
+		if (e != hipSuccess) return e;
+	}
+	// Batches smaller than the chip get workgroups that only help (they are dispatched after the owners and leave as soon
+	// as nothing needs them); with three concurrent mode kernels only finished owners help.
+	uint32_t extra = 0;
+	if (coop && rows_only) {
+		static std::atomic<int> n_cus{0};
+		int cus = n_cus.load(std::memory_order_relaxed);
+		if (cus == 0) {
+			if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+			n_cus.store(cus, std::memory_order_relaxed);
+		}
+		if (n < (uint32_t)cus) extra = std::min((uint32_t)cus - n, 4u * n);
+	}
 	hipStream_t s1 = s, s2 = s;
 	if (!rows_only && fk) {
 		hipError_t e = hipEventRecord(fk->fork, s);
@@ -965,10 +1283,10 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		if (e != hipSuccess) return e;
 		s1 = fk->s1; s2 = fk->s2;
 	}
-	hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py);
+	hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	if (!rows_only) {
-		hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py);
-		hipLaunchKernelGGL(k_lsd<LSD_MODE_GLOBAL>, dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py);
+		hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
+		hipLaunchKernelGGL(k_lsd<LSD_MODE_GLOBAL>, dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py, n);
 		if (fk) {
 			hipError_t e = hipEventRecord(fk->join1, s1);
 			if (e == hipSuccess) e = hipEventRecord(fk->join2, s2);
@@ -979,6 +1297,8 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	}
 	return hipGetLastError();
 }
+
+size_t lsd_coop_ctl_bytes(uint32_t n) { return sizeof(LsdCtl) + sizeof(LsdCoop) * (size_t)n; }
 
 hipError_t set_ray_table(const float *dx, const float *dy) {
 	static RayDir host[SMH_LSD_RAYS];

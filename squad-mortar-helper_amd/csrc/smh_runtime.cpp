@@ -126,6 +126,11 @@ struct smhv_batch {
 	FrameAux *d_aux = nullptr;
 	smhv_frame_result *d_results = nullptr;   // max_frames (+3 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
+	// k_lsd cooperation (smh_kernels.h): [LsdCtl][LsdCoop x n] zeroed per launch, request rings, result caches
+	uint8_t *d_lsd_ctl = nullptr;
+	uint32_t *d_lsd_req = nullptr;
+	LsdCacheEntry *d_lsd_cache = nullptr;
+	uint32_t lsd_epoch = 0;
 	// pinned staging for the per-run anchor upload (a pageable source would make hipMemcpyAsync synchronous);
 	// two slots + events so a run never overwrites a slot whose copy is still in flight
 	smhv_anchors *h_anchors[2] = {nullptr, nullptr};
@@ -260,6 +265,16 @@ static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t resul
 	bf.bits = b->d_bits; bf.aux = b->d_aux;
 	bf.results = b->d_results + result_slot;
 	bf.anchors = b->d_anchors;
+	bf.co.ctl = nullptr;                                     // k_lsd cooperation is opt-in: smhv_batch_run sets it for SMHV_STAGE_LSD_HELPERS
+	bf.co.coop = (LsdCoop *)(b->d_lsd_ctl + sizeof(LsdCtl));
+	bf.co.req = b->d_lsd_req;
+	bf.co.cache = b->d_lsd_cache;
+	// a fresh epoch per set of launches: cache entries of earlier launches read as empty slots (0 = never used)
+	if (++b->lsd_epoch == 0) {
+		(void)hipMemset(b->d_lsd_cache, 0, sizeof(LsdCacheEntry) * SMH_LSD_CACHE_SLOTS * (size_t)b->max_frames);
+		b->lsd_epoch = 1;
+	}
+	bf.co.epoch = b->lsd_epoch;
 	return bf;
 }
 
@@ -373,6 +388,9 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 	ALLOC0(b->d_results, sizeof(smhv_frame_result) * (n + 3));
 	ALLOC0(b->d_anchors, sizeof(smhv_anchors) * n);
 	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
+	ALLOC0(b->d_lsd_ctl, lsd_coop_ctl_bytes(max_frames));
+	ALLOC0(b->d_lsd_req, sizeof(uint32_t) * SMH_LSD_REQ_CAP * n);
+	ALLOC0(b->d_lsd_cache, sizeof(LsdCacheEntry) * SMH_LSD_CACHE_SLOTS * n);
 #undef ALLOC0
 	{
 		hipError_t e = hipStreamCreateWithFlags(&b->s_scales, hipStreamNonBlocking);
@@ -403,7 +421,8 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	if (!b) return;
 	if (b->ctx) (void)hipSetDevice(b->ctx->device);
 	(void)hipDeviceSynchronize();
-	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars};
+	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars,
+	                b->d_lsd_ctl, b->d_lsd_req, b->d_lsd_cache};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
 	for (int i = 0; i < 2; ++i) {
@@ -462,11 +481,12 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
 	CTX_OPEN(b->ctx);
 	if ((stages & (SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP)) == 0) return fail(SMHV_E_INVALID, "no stage selected");
-	stages &= SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP | SMHV_STAGE_EXACT_STATS;
+	stages &= SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP | SMHV_STAGE_EXACT_STATS | SMHV_STAGE_LSD_HELPERS;
 	HIPCHK(hipSetDevice(b->ctx->device));
 	hipStream_t s = (hipStream_t)stream;
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
+	if (stages & SMHV_STAGE_LSD_HELPERS) bf.co.ctl = (LsdCtl *)b->d_lsd_ctl;
 	if ((stages & SMHV_STAGE_MARKERS) && !(stages & SMHV_STAGE_EXACT_STATS)) {
 		int rc = sector_table_for(b->ctx, max_gap, s, &bf);
 		if (rc) return rc;
@@ -554,6 +574,16 @@ extern "C" SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]) {
 	}
 	for (int i = 0; i < 5; ++i) ms[i] = (float)(acc[i] / (double)runs);
 	b->timed_runs = 0;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_lsd_coop_stats(smhv_batch *b, uint32_t first, uint32_t n, uint32_t *out) {
+	if (!b || !out || (uint64_t)first + n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+	HIPCHK(hipSetDevice(b->ctx->device));
+	HIPCHK(hipDeviceSynchronize());
+	std::vector<LsdCoop> h(n);
+	HIPCHK(hipMemcpy(h.data(), b->d_lsd_ctl + sizeof(LsdCtl) + sizeof(LsdCoop) * (size_t)first, sizeof(LsdCoop) * n, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < n; ++i) { out[4 * i] = h[i].stat_groups; out[4 * i + 1] = h[i].stat_hits; out[4 * i + 2] = h[i].stat_casts; out[4 * i + 3] = h[i].req_tail; }
 	return SMHV_OK;
 }
 

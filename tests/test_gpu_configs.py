@@ -249,6 +249,33 @@ def test_fuzz_stream_slice(vision):
         assert np.array_equal(colour[0][..., :3], frame[y:y + rh, x:x + rw, 2::-1])
 
 
+def test_lsd_helpers_do_not_change_any_record(vision):
+    """SMHV_STAGE_LSD_HELPERS: workgroups that have finished their frame ray-cast candidates for the frames still being
+    searched.  Ray casting is a pure function of (mask, pixel), so every record must stay byte-identical -- on a batch
+    with a few very heavy frames (where helpers do attach), at 1080p (one kernel) and 1440p (three residency kernels)."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    for (W, H, N) in ((1920, 1080, 96), (2560, 1440, 48)):
+        frames, infos = synth.make_batch(W, H, N, first_idx=7000, n_lines=2)
+        for i in range(0, N, 12):                                   # heavy frames: more lines, more blobs
+            frames[i], infos[i] = synth.make_frame(W, H, 7500 + i, n_lines=6)
+        anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+        d = torch.from_numpy(frames).cuda()
+        fb = smh.FrameBatch(vision, W, H, N)
+        s = torch.cuda.current_stream().cuda_stream
+        fb.run(d.data_ptr(), N, anchors=anchors, stream=s)
+        plain = bytes(fb.read_results(0, N))
+        for stages in (smh.STAGE_ALL | smh.STAGE_LSD_HELPERS, smh.STAGE_ALL | smh.STAGE_LSD_HELPERS, smh.STAGE_ALL):
+            fb.run(d.data_ptr(), N, stages=stages, anchors=anchors, stream=s)
+            assert bytes(fb.read_results(0, N)) == plain
+        fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_LSD_HELPERS | smh.STAGE_EXACT_STATS, anchors=anchors, stream=s)
+        exact_h = bytes(fb.read_results(0, N))
+        fb.run(d.data_ptr(), N, stages=smh.STAGE_ALL | smh.STAGE_EXACT_STATS, anchors=anchors, stream=s)
+        assert bytes(fb.read_results(0, N)) == exact_h
+        fb.close()
+
+
 # ---------------------------------------------------------------------------------------------------
 # robustness of the boundary (round-1 advisor findings)
 # ---------------------------------------------------------------------------------------------------
