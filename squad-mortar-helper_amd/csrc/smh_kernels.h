@@ -122,6 +122,8 @@ hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, in
 hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
 size_t lsd_lds_bytes();
+// diagnostic: find_lines on the workgroup-synchronous k_lsd for every frame instead of k_lsd_wave (also SMH_LSD_CLASSIC=1)
+void lsd_set_classic(bool on);
 // overwrite the 3600 ray directions of the current device's code object (synchronous)
 hipError_t set_ray_table(const float *dx, const float *dy);
 // CRC-32 of n_dwords 32-bit words at d_msg, xor-ed into *d_acc (zero it first) WITHOUT the init / final-xor terms:

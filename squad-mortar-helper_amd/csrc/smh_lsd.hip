@@ -8,6 +8,7 @@
 // structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include "smh_device.h"
@@ -1192,6 +1193,8 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 	lsd_help<MODE>(g, b, n_frames, max_gap, smem, sh, cull_tab, have_tab);
 }
 
+#include "smh_lsd_wave.inc"
+
 // ------------------------------------------------------------------------------------------------
 // Sector culling for find_lines (k_lsd).  lsd.rs:94 keeps a candidate only if its longest ray has
 // len^2 > 2500, i.e. the ray's fatal gap starts at step K >= 51 (an aborted ray ends K-1 unit steps from its
@@ -1240,6 +1243,12 @@ __global__ void k_build_sector_table(unsigned long long *tab, uint32_t T) {
 // ------------------------------------------------------------------------------------------------
 size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 
+static std::atomic<bool> &lsd_classic_flag() {
+	static std::atomic<bool> flag{[] { const char *e = getenv("SMH_LSD_CLASSIC"); return e && e[0] == '1'; }()};
+	return flag;
+}
+void lsd_set_classic(bool on) { lsd_classic_flag().store(on, std::memory_order_relaxed); }
+
 bool lsd_rows_only(const Geom &g) { return (g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP; }
 
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk) {
@@ -1253,6 +1262,8 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		hipError_t e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_GLOBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_wave<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_DYN_LDS_BYTES);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_wave<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_DYN_LDS_BYTES);
 		if (e != hipSuccess) return e;
 		if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 	}
@@ -1283,9 +1294,14 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		if (e != hipSuccess) return e;
 		s1 = fk->s1; s2 = fk->s2;
 	}
-	hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
+	// find_lines runs one wave per candidate (k_lsd_wave) for the two LDS-resident mask modes; Vision::find_longest_line, the
+	// global-memory mask mode and the helper experiment stay on the workgroup-synchronous k_lsd (SMH_LSD_CLASSIC=1: everything).
+	const bool wave = mode == 0 && !coop && !lsd_classic_flag().load(std::memory_order_relaxed);
+	if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_ROWS>, dim3(n), dim3(LSD_BS), W_DYN_LDS_BYTES, s, g, b, max_gap);
+	else hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	if (!rows_only) {
-		hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
+		if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), W_DYN_LDS_BYTES, s1, g, b, max_gap);
+		else hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
 		hipLaunchKernelGGL(k_lsd<LSD_MODE_GLOBAL>, dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py, n);
 		if (fk) {
 			hipError_t e = hipEventRecord(fk->join1, s1);

@@ -342,6 +342,11 @@ extern "C" SMHV_API int smhv_thread_ctx(smhv_ctx *c) {
 	return SMHV_OK;
 }
 
+extern "C" SMHV_API int smhv_debug_lsd_classic(int on) {
+	lsd_set_classic(on != 0);
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_set_ray_table(smhv_ctx *c, const float *dx, const float *dy) {
 	if (!c || !dx || !dy) return fail(SMHV_E_INVALID, "bad arguments");
 	CTX_OPEN(c);
