@@ -213,8 +213,10 @@ SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
 SMHV_API int smhv_batch_lsd_coop_stats(smhv_batch *b, uint32_t first, uint32_t n, uint32_t *out);
 SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
 
-/* diagnostic (process-wide): on != 0 runs find_lines on the workgroup-synchronous kernel (k_lsd) for every frame instead of
- * the one-wave-per-candidate kernel (k_lsd_wave); both produce the reference's results, the tests compare them. */
+/* diagnostic (process-wide): find_lines has two kernels -- the workgroup-synchronous k_lsd (on != 0; the default) and the
+ * task-based k_lsd_wave (on == 0, or SMH_LSD_WAVE=1 in the environment): waves of a frame's workgroup claim 64-ray units of
+ * the oldest candidate in flight, candidates retire in order through a reorder buffer.  Both produce the reference's
+ * results bit for bit; the tests run every fuzz scene through both. */
 SMHV_API int smhv_debug_lsd_classic(int on);
 /* exhaustive colour-predicate check support: writes 2^24/32 words, bit (r<<16|g<<8|b) = device
  * is_any_map_marker_color(r,g,b) (vision-common/src/markers/mod.rs:40-54) */

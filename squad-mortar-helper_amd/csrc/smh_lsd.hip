@@ -1244,7 +1244,9 @@ __global__ void k_build_sector_table(unsigned long long *tab, uint32_t T) {
 size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 
 static std::atomic<bool> &lsd_classic_flag() {
-	static std::atomic<bool> flag{[] { const char *e = getenv("SMH_LSD_CLASSIC"); return e && e[0] == '1'; }()};
+	// default: the workgroup-synchronous kernel (it co-exists better with the streaming passes of a pipelined second batch);
+	// SMH_LSD_WAVE=1 or smhv_debug_lsd_classic(0) selects k_lsd_wave
+	static std::atomic<bool> flag{[] { const char *e = getenv("SMH_LSD_WAVE"); return !(e && e[0] == '1'); }()};
 	return flag;
 }
 void lsd_set_classic(bool on) { lsd_classic_flag().store(on, std::memory_order_relaxed); }
@@ -1294,8 +1296,9 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		if (e != hipSuccess) return e;
 		s1 = fk->s1; s2 = fk->s2;
 	}
-	// find_lines runs one wave per candidate (k_lsd_wave) for the two LDS-resident mask modes; Vision::find_longest_line, the
-	// global-memory mask mode and the helper experiment stay on the workgroup-synchronous k_lsd (SMH_LSD_CLASSIC=1: everything).
+	// find_lines has two implementations for the LDS-resident mask modes: the workgroup-synchronous k_lsd (default) and the
+	// task-based k_lsd_wave (SMH_LSD_WAVE=1); Vision::find_longest_line, the global-memory mask mode and the helper workgroups
+	// are k_lsd only.
 	const bool wave = mode == 0 && !coop && !lsd_classic_flag().load(std::memory_order_relaxed);
 	if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_ROWS>, dim3(n), dim3(LSD_BS), W_DYN_LDS_BYTES, s, g, b, max_gap);
 	else hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);

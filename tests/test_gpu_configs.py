@@ -221,6 +221,38 @@ def test_fuzz_lsd_slice(vision, seed, size, max_gap):
     fb.close()
 
 
+def test_both_line_segment_kernels_agree_with_the_oracle(vision):
+    """find_lines has two kernels (smhv_debug_lsd_classic): the workgroup-synchronous k_lsd and the task-based k_lsd_wave
+    (reorder buffer, waves claim 64-ray units).  Random scenes and synthetic frames through both, culled and exact."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    from fuzz_scenes import scene
+    lib = smh._lib.load()
+    try:
+        for seed, (W, H), max_gap in ((31, (1920, 1080), 15), (32, (2560, 1440), 15), (33, (1280, 1024), 30), (34, (1024, 768), 0), (35, (1600, 1024), 50)):
+            n = 24
+            rng = np.random.default_rng(seed)
+            frames = np.stack([scene(rng, W, H, 100 * seed + i, max_gap) if i % 3 else synth.make_frame(W, H, 100 * seed + i, n_lines=3)[0] for i in range(n)])
+            ref = o.process_batch(frames, min(os.cpu_count() or 1, n), stages=0x1, max_gap=max_gap)
+            fb = smh.FrameBatch(vision, W, H, n)
+            d = torch.from_numpy(frames).cuda()
+            for classic in (0, 1):
+                lib.smhv_debug_lsd_classic(classic)
+                for exact in (0, smh.STAGE_EXACT_STATS):
+                    for rep in range(2):
+                        fb.run(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=max_gap, stream=torch.cuda.current_stream().cuda_stream)
+                        got = smh.results_to_dicts(fb.read_results(0, n))
+                        for i in range(n):
+                            assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (seed, i, classic, bool(exact))
+                            assert got[i]["rounds"] == ref[i].rounds, (seed, i, classic, bool(exact))
+                            if exact:
+                                assert got[i]["ray_steps"] == ref[i].steps, (seed, i, classic)
+            fb.close()
+    finally:
+        lib.smhv_debug_lsd_classic(1)
+
+
 def test_fuzz_stream_slice(vision):
     """Bounded slice of tools/fuzz_stream.py: pixels drawn around every decision threshold of the streaming stages."""
     import squad_mortar_helper_amd as smh

@@ -28,7 +28,7 @@ for i in range(N):
     if b["rounds"] == 0xFFFFFFFF:
         import struct
         print("   WATCHDOG: head %d tail %d disp_e %d end %d n_lines %d flags %d wave %d head-state %d" % tuple(struct.unpack("I", struct.pack("f", raw[i].angle[24 + k]))[0] for k in range(8)))
-    print("   wave debug: list entries %d dispatched %d nonzero-survivor-words-at-exit %d skipped-at-retire %d . failed dispatch polls %d" % (dbg[i][0], dbg[i][1], dbg[i][2], dbg[i][3], dbg[i][5]))
+    print("   wave debug: list entries %d units cast %d candidates set up %d skipped-at-retire %d . idle polls %d" % (dbg[i][0], dbg[i][1], dbg[i][2], dbg[i][3], dbg[i][5]))
     print("   words filtered %d, of which emptied %d; head %r tail %r disp_e %r; exit flags %d scan iterations %d" % (dbg[i][6], dbg[i][7], dbg2[i][0], dbg2[i][1], dbg2[i][2], dbg[i][8], dbg[i][4]))
     if not same:
         k = min(len(a["lines"]), len(b["lines"]))

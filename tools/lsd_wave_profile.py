@@ -1,0 +1,30 @@
+"""Diagnostic (debug build: -DSMH_LSD_WDEBUG -DSMH_LSD_PROFILE): where the waves of k_lsd_wave spend their cycles."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import squad_mortar_helper_amd as smh
+from squad_mortar_helper_amd import synth
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+W, H = 1920, 1080
+host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
+_, infos = synth.make_batch(W, H, N, out=host.numpy())
+d = host.cuda()
+v = smh.HipVision.init(0)
+fb = smh.FrameBatch(v, W, H, N)
+fb.enable_timing(True)
+for _ in range(3):
+    fb.run(d.data_ptr(), N, stages=smh.STAGE_MARKERS | smh.STAGE_UI_MAP, stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+print("stage ms", fb.stage_ms())
+raw = fb.read_results(0, N)
+names = ["claim", "unit", "finish", "lock-wait", "control", "setup", "idle", "total"]
+P = np.array([[raw[i].meters[20 + k] for k in range(8)] for i in range(N)])
+D = np.array([[raw[i].meters[28 + k] for k in range(4)] for i in range(N)])
+rounds = np.array([raw[i].rounds for i in range(N)])
+tot = P[:, 7].sum()
+print("share of wave-cycles: " + ", ".join("%s %.1f%%" % (names[k], 100 * P[:, k].sum() / tot) for k in range(7)))
+print("per frame: units cast %.1f, candidates set up %.1f, skipped at retire %.1f, rounds %.1f" % (D[:, 0].mean(), D[:, 1].mean(), D[:, 2].mean(), rounds.mean()))
+ft = P[:, 7] / 16
+print("frame cycles (wave total / 16): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
+for i in np.argsort(-ft)[:4]:
+    print("  frame %d rounds %d units %d cands %d: %.3g cycles; shares %s" % (i, rounds[i], D[i, 0], D[i, 1], ft[i], ["%.0f%%" % (100 * P[i, k] / P[i, 7]) for k in range(7)]))
