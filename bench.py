@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- map frames/s through the full CV pipeline on N MI355X GPUs (one process per GPU).
+"""bench.py -- map frames/s through the vision hot path on N MI355X GPUs (one process per GPU).
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a batch of
-1920x1080 synthetic map frames RESIDENT IN HBM per GPU, full pipeline per step: close-deployment
-button test, ui_map, marker threshold + dilation, ocr_preprocess, find_scales_preprocess + m/px,
-ray-cast line-segment detection, derived marker lengths/angles; with N > 1 the per-frame result
-records are gathered to rank 0 over RCCL inside the timed step.  Frames are independent, so the
-batch is block-sharded over ranks (weak scaling: --frames-per-gpu is fixed as N grows).
+Workloads (BASELINE.json `configs`; --config picks one, default 2 = the configuration the metric is quoted on):
+  1  batch = 1, 1920x1080 synthetic map, marker threshold + dilation + LSD only
+  2  256 x 1920x1080 frames RESIDENT IN HBM per GPU, full pipeline: close-deployment button test, ui_map, marker
+     threshold + dilation, ocr_preprocess, find_scales_preprocess + m/px, ray-cast line-segment detection, derived
+     marker lengths / angles
+  3  128 x 2560x1440 frames, full pipeline
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs the same workload on its own block of
+the global batch (frames are independent: weak scaling) and the per-frame result records are gathered to rank 0 over RCCL
+inside the timed step.
+
+One "step" = --rounds-per-step passes of the hot path over the resident batch (default 8, so that the default 20-step
+region lasts ~0.1 s instead of 15 ms); `value` counts every frame of every pass.  The passes go through
+smhv_pipeline_submit: the library owns the streams and the schedule (--pipeline-depth batches in flight, default 2);
+`value_depth1` is the same workload with ONE batch in flight, timed right after the main region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
-  roofline     -- the dominant HBM streaming kernel (k_map_pass): algorithmic bytes / hipEvent time
-  stages_ms    -- average per-stage device time over the timed steps (hipEvents on the run's stream)
+  roofline     -- the dominant HBM streaming kernel: algorithmic bytes / hipEvent launch duration on the run's stream
+  stages_ms    -- average per-stage device time over the timed passes
   lsd          -- workload statistics of the (non-HBM-bound) ray-cast stage
-  cpu_baseline -- the C oracle (a port of the reference's vision-cpu; the Rust original cannot be
-                  built here) timed on this box's host cores on a bounded sample of the same frames
+  cpu_baseline -- the C oracle (a port of the reference's vision-cpu; the Rust original cannot be built here) timed on this
+                  box's host cores on a bounded sample of the same frames, plus its single-thread per-stage split
 """
 import argparse
 import json
@@ -29,21 +37,62 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
+CONFIGS = {
+    1: dict(frames=1, width=1920, height=1080, stages=0x1, rounds=64,
+            name="BASELINE configs[1]: batch=1 1920x1080 synthetic map, marker threshold + dilation + LSD only"),
+    2: dict(frames=256, width=1920, height=1080, stages=0xF, rounds=8,
+            name="BASELINE configs[2]: 256 x 1920x1080 BGRA frames resident in HBM per GPU, full pipeline (button, ui_map, "
+                 "marker mask+dilate, LSD, ocr_preprocess, scales+m/px)"),
+    3: dict(frames=128, width=2560, height=1440, stages=0xF, rounds=8,
+            name="BASELINE configs[3]: 128 x 2560x1440 BGRA frames resident in HBM per GPU, full pipeline"),
+}
 
-def algorithmic_bytes(roi_w, roi_h, btn_w, btn_h):
-    """each input ROI pixel read once as BGRA, each API-visible output written once."""
+
+def algorithmic_bytes(roi_w, roi_h, btn_w, btn_h, stages):
+    """each input ROI pixel read once as BGRA, each API-visible output written once.
+    -> (bytes of the streaming kernel per frame, bytes of the whole step per frame)"""
     qw, qh = roi_w // 2, roi_h // 2
-    map_pass = roi_w * roi_h * 4 + roi_w * roi_h * 4 + roi_w * roi_h          # read BGRA, write ui RGBA, write u8 mask
-    full = btn_w * btn_h * 4 + map_pass + 2 * qw * qh + 516                    # + button, ocr_out, scales, <=32 lines
-    return map_pass, full
+    px = roi_w * roi_h
+    kernel = px * 4                                            # read the ROI as BGRA
+    if stages & 0x2:
+        kernel += px * 4                                       # ui_map RGBA
+    if stages & 0x1:
+        kernel += px                                           # u8 marker mask
+    if stages & 0x4:
+        kernel += qw * qh                                      # ocr_out
+    if stages & 0x8:
+        kernel += qw * qh                                      # scales
+    full = btn_w * btn_h * 4 + kernel + (516 if stages & 0x1 else 0)   # + button pixels, <= 32 lines
+    return kernel, full
 
 
-def ingest_leg(smh, vision, fbs, src, anchors, args, W, H, n):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_stage_split(orc, frames, infos, max_gap=15):
+    """Single-thread per-stage milliseconds of the C oracle, mean over the given frames."""
+    acc = dict(crop_to_map=0.0, threshold_dilate=0.0, lsd=0.0, ocr_preprocess=0.0, find_scales_preprocess=0.0)
+    for fr, info in zip(frames, infos):
+        t = time.perf_counter(); crop = orc.crop_to_map(fr, True); acc["crop_to_map"] += time.perf_counter() - t
+        t = time.perf_counter(); mask = orc.mask_marker_lines(crop["cropped_map"]); acc["threshold_dilate"] += time.perf_counter() - t
+        t = time.perf_counter(); orc.find_lines(mask, max_gap); acc["lsd"] += time.perf_counter() - t
+        t = time.perf_counter(); orc.ocr_preprocess(crop["cropped_brq"]); acc["ocr_preprocess"] += time.perf_counter() - t
+        t = time.perf_counter(); orc.find_scales_preprocess(crop["cropped_brq"], info["scales_start_y"]); acc["find_scales_preprocess"] += time.perf_counter() - t
+    return {k: v / len(frames) * 1e3 for k, v in acc.items()}
+
+
+def ingest_leg(smh, vision, pipe, src, anchors, stages, frames_total, W, H, n):
     """PCIe-inclusive rate (never `value`): frames travel pinned host memory -> HBM through the ingest queue (async
-    copy, device CRC-32 duplicate test, slab append) and every full slab goes through the same batch pipeline; two
-    queues alternate so the uploads of one slab overlap the compute of the other.  The staging buffers are filled
-    once; each frame then gets a fresh counter in pixel (0,0) (outside every ROI) so that no CRC repeats."""
-    import torch
+    copy, device CRC-32 duplicate test, slab append) and every full slab goes through the same pipeline; two queues
+    alternate so the uploads of one slab overlap the compute of the other.  The staging buffers are filled once; each
+    frame then gets a fresh counter in pixel (0,0) (outside every ROI) so that no CRC repeats."""
     slots = 4
     qs = [smh.IngestQueue(vision, W, H, slots=slots, capacity=n) for _ in range(2)]
     for q in qs:                                               # prime the staging buffers (their content persists)
@@ -52,14 +101,15 @@ def ingest_leg(smh, vision, fbs, src, anchors, args, W, H, n):
             q.commit()
         q.batch()
         q.reset()
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    slabs = max(2, (args.ingest_frames + n - 1) // n)
+    slabs = max(2, (frames_total + n - 1) // n)
     counter = 1
+    pending = [None, None]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for b in range(slabs):
-        q, st, fb = qs[b % 2], streams[b % 2], fbs[b % len(fbs)]
-        st.synchronize()                                       # the previous run on this queue's slab has finished
+        q = qs[b % 2]
+        if pending[b % 2] is not None:
+            pipe.wait(pending[b % 2])                          # the previous run on this queue's slab has finished
         q.reset()
         for _ in range(n):
             buf = q.acquire()
@@ -68,54 +118,57 @@ def ingest_leg(smh, vision, fbs, src, anchors, args, W, H, n):
             q.commit()
         ptr, cnt, _ = q.batch()
         assert cnt == n, "ingest dropped frames: %d of %d" % (cnt, n)
-        with torch.cuda.stream(st):
-            fb.run(ptr, cnt, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=st.cuda_stream)
-    torch.cuda.synchronize()
+        pending[b % 2] = pipe.submit(ptr, cnt, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
+    pipe.wait()
     dt = time.perf_counter() - t0
     frames = slabs * n
-    # pageable source: one extra host copy per frame (bounded sample)
     q = qs[0]
     q.reset()
     k = min(64, n)
     t1 = time.perf_counter()
-    for i in range(k):
-        src[i][0, 0, 3] = 254 - (i & 1)                        # alternate so consecutive CRCs differ
-        q.push(src[i])
+    for i in range(k):                                         # pageable source: one extra host copy per frame (bounded sample)
+        src[i % len(src)][0, 0, 3] = 254 - (i & 1)             # alternate so consecutive CRCs differ
+        q.push(src[i % len(src)])
     q.batch()
     dt_push = time.perf_counter() - t1
-    for i in range(k):
+    for i in range(min(k, len(src))):
         src[i][0, 0, 3] = 255
-    new, dup = qs[0].counts()
+    _, dup = qs[0].counts()
     for q in qs:
         q.close()
     return {"frames_per_s": frames / dt, "frames": frames, "h2d_GBps": frames * W * H * 4 / dt / 1e9,
             "push_frames_per_s": k / dt_push, "duplicates_dropped": dup,
             "note": "PCIe-inclusive: pinned staging -> async H2D -> device CRC-32 dedupe (src/capture.rs:44-47) -> slab -> same "
-                    "batch pipeline, two slabs in flight; push_frames_per_s adds the host memcpy from pageable memory (one thread)"}
+                    "pipeline, two slabs in flight; push_frames_per_s adds the host memcpy from pageable memory (one thread)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-gpu", type=int, default=256)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] index of the workload")
+    ap.add_argument("--frames-per-gpu", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--stages", type=lambda s: int(s, 0), default=None)
+    ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
-    ap.add_argument("--stages", type=lambda s: int(s, 0), default=0xF)
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="batches in flight (smhv_pipeline_create depth)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-box testing of the N>1 code path)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
-    ap.add_argument("--no-stagger", action="store_true", help="start the pipelined steps together instead of half a period apart")
-    ap.add_argument("--no-stream-tuning", action="store_true", help="keep the default stream assignment of the pipelined steps")
     ap.add_argument("--ingest-frames", type=int, default=512,
-                    help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1 only)")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="steps in flight: consecutive steps alternate between this many HIP streams / output buffer sets, so "
-                         "the tail of one step's per-frame LSD workgroups overlaps the next step's streaming passes")
+                    help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1, config 2 only)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    n = args.frames_per_gpu or cfg["frames"]
+    W, H = args.width or cfg["width"], args.height or cfg["height"]
+    stages = cfg["stages"] if args.stages is None else args.stages
+    rounds = args.rounds_per_step or cfg["rounds"]
+    custom = (n, W, H, stages) != (cfg["frames"], cfg["width"], cfg["height"], cfg["stages"])
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,9 +183,10 @@ def main():
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
+    nccl = args.dist_backend == "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
+        if nccl:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
@@ -141,7 +195,6 @@ def main():
     from squad_mortar_helper_amd import dist as sdist
     from squad_mortar_helper_amd import synth
 
-    W, H, n = args.width, args.height, args.frames_per_gpu
     first = rank * n                                   # block shard of the global batch
     frames_host = torch.empty((n, H, W, 4), dtype=torch.uint8, pin_memory=True)
     _, infos = synth.make_batch(W, H, n, first_idx=first, n_lines=args.lines, out=frames_host.numpy())
@@ -152,132 +205,93 @@ def main():
 
     vision = smh.HipVision.init(local_rank)
     depth = max(1, args.pipeline_depth)
-    fbs = [smh.FrameBatch(vision, W, H, n) for _ in range(depth)]
-    fb = fbs[0]
-    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
+    pipe = smh.Pipeline(vision, W, H, n, depth)
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 0x8 else None
+    fptr = frames.data_ptr()
 
-    def rec_view(b):   # torch view over the library's device result records (for the RCCL gather)
-        class _Rec:
-            __cuda_array_interface__ = {"shape": (n * sdist.RECORD_BYTES,), "typestr": "|u1", "data": (b.device_ptrs()["results"], False), "version": 2}
-        return torch.as_tensor(_Rec(), device="cuda")
-    rec_tensors = [rec_view(b) for b in fbs]
-    for st in streams[1:]:
-        st.wait_stream(streams[0])          # the frame upload happened on the current stream
+    # N > 1: the records of every pass are gathered to rank 0 on the slot's own stream (RCCL orders itself after the
+    # work already enqueued there); all buffers are allocated once, up front.
+    gather = None
+    if world > 1:
+        gather = sdist.RecordGather(dist, n, world, rank, device=("cuda" if nccl else "cpu"))
+        slot_streams = [torch.cuda.ExternalStream(s) for s in pipe.streams]
+        rec_views = [sdist.device_records_view(b.device_ptrs()["results"], n) for b in pipe.slots]
 
-    step_no = [0]
+    def one_pass(p):
+        slot = p.submit(fptr, n, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
+        if gather is not None and p is pipe:
+            with torch.cuda.stream(slot_streams[slot]):
+                gather.run(rec_views[slot] if nccl else rec_views[slot].cpu(), slot)
+        return slot
 
-    def stagger(i):
-        # First round after an idle device: step k starts its streaming pass when step k-1 has finished its own, so the
-        # steps run half a period apart from the outset (the streaming passes of one underneath the LSD of the other);
-        # started together they can lock into the schedule in which they stream together and then search together.
-        if not args.no_stagger and 0 < i < depth:
-            fbs[i - 1].wait_map_pass(streams[i].cuda_stream)
-
-    def step():
-        k = step_no[0] % depth
-        stagger(step_no[0])
-        step_no[0] += 1
-        with torch.cuda.stream(streams[k]):
-            fbs[k].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[k].cuda_stream)
-            if world > 1:
-                t = rec_tensors[k] if args.dist_backend == "nccl" else rec_tensors[k].cpu()   # gloo gathers host tensors
-                return sdist.gather_records(t, dist, sizes=[n * sdist.RECORD_BYTES] * world)
-        return None
+    def step(p=pipe):
+        for _ in range(rounds):
+            one_pass(p)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()           # all streams of the device
-        step_no[0] = 0                     # the device is idle: the next steps are a "first round" again
-
-    # ---- stream assignment (untimed) ----
-    # A process has four hardware queues; HIP deals its streams onto them in creation order, and when the main stream
-    # of one pipelined step shares a queue with a branch of the other, the two steps stop overlapping (measured: 214 k
-    # instead of 320 k frames/s, depending only on how many streams the process happened to create before).  So a
-    # few assignments of torch pool streams to (main stream of steps 1.., scales branch of every step) are tried (48
-    # untimed steps each), the library-owned streams included, and the fastest is kept.
-    tuning = None
-    if depth > 1 and not args.no_stream_tuning:
-        pool = [torch.cuda.Stream() for _ in range(2 * depth + 4)]
-        for st in pool:
-            st.wait_stream(streams[0])
-        own_main = list(streams)
-
-        def assign(j):
-            if j < 0:                                          # the library's own scales streams
-                streams[:] = own_main
-                for b in fbs:
-                    b.set_scales_stream(0)
-            else:
-                for k in range(1, depth):
-                    streams[k] = pool[j + k - 1]
-                for k, b in enumerate(fbs):
-                    b.set_scales_stream(pool[j + depth - 1 + k].cuda_stream)
-
-        def plain_step(i):
-            k = i % depth
-            stagger(i)
-            with torch.cuda.stream(streams[k]):
-                fbs[k].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[k].cuda_stream)
-
-        trials = {}
-        for j in range(-1, 5):
-            assign(j)
-            for i in range(16):                                 # the pipelined schedule takes a few steps to settle
-                plain_step(i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(32):
-                plain_step(i)
-            torch.cuda.synchronize()
-            trials[j] = (time.perf_counter() - t0) / 32 * 1e3
-        best = min(trials, key=trials.get)
-        assign(best)
-        tuning = {"tried_ms_per_step": {("library" if j < 0 else "pool+%d" % j): round(v, 4) for j, v in trials.items()},
-                  "chosen": "library" if best < 0 else "pool+%d" % best}
 
     for _ in range(args.warmup):
         step()
     barrier()
     if not args.no_stage_timing:
-        for b in fbs:
+        for b in pipe.slots:
             b.enable_timing(True)
     t0 = time.perf_counter()
-    gathered = None
     for _ in range(args.steps):
-        gathered = step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
     stages_ms = None
     if not args.no_stage_timing:
-        per = [b.stage_ms() for b in fbs[:min(depth, args.steps)]]
+        per = [b.stage_ms() for b in pipe.slots[:min(depth, args.steps * rounds)]]
         stages_ms = {k: float(np.mean([p[k] for p in per])) for k in per[0]}
-    # the same step, not overlapped with anything (outside the timed region): per-stage durations in isolation
-    iso_ms = None
-    if not args.no_stage_timing:
-        fbs[0].enable_timing(True)
-        for _ in range(3):
-            with torch.cuda.stream(streams[0]):
-                fbs[0].run(frames.data_ptr(), n, stages=args.stages, grayscale=True, max_gap=15, anchors=anchors, stream=streams[0].cuda_stream)
-            torch.cuda.synchronize()
-        iso_ms = fbs[0].stage_ms()
-    for b in fbs:
-        b.enable_timing(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        for b in pipe.slots:
+            b.enable_timing(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if nccl else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- the same workload with ONE batch in flight, and one pass alone for the per-stage durations in isolation ----
+    value_d1 = ms_d1 = iso_ms = None
+    if not args.no_depth1 or not args.no_stage_timing:
+        pipe1 = smh.Pipeline(vision, W, H, n, 1)
+        if not args.no_depth1:
+            k1 = max(2, args.steps // 2)
+            for _ in range(2):
+                step(pipe1)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(k1):
+                step(pipe1)
+            barrier()
+            d1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if nccl else "cpu")
+            if world > 1:
+                dist.all_reduce(d1, op=dist.ReduceOp.MAX)
+            ms_d1 = float(d1.item()) / k1 * 1e3
+            value_d1 = n * world * rounds * k1 / float(d1.item())
+        if not args.no_stage_timing:
+            pipe1.slots[0].enable_timing(True)
+            for _ in range(3):
+                one_pass(pipe1)
+                torch.cuda.synchronize()
+            iso_ms = pipe1.slots[0].stage_ms()
+        pipe1.close()
+
     # ---- result sanity + workload statistics (outside the timed region) ----
+    fb = pipe.slots[0]
     recs = smh.results_to_dicts(fb.read_results(0, n))
-    rounds = float(np.mean([r["rounds"] for r in recs]))
+    rounds_pf = float(np.mean([r["rounds"] for r in recs]))
     ray_steps = float(np.mean([r["ray_steps"] for r in recs]))
     n_lines = float(np.mean([r["n_lines"] for r in recs]))
     all_open = all(r["map_open"] for r in recs)
-    if world > 1 and rank == 0:
-        total = sum(g.numel() for g in gathered) // sdist.RECORD_BYTES
-        assert total == n * world, "gather returned %d records, expected %d" % (total, n * world)
+    if gather is not None and rank == 0:
+        got = gather.records(0)
+        assert len(got) == n * world, "gather returned %d records, expected %d" % (len(got), n * world)
+        assert all(bytes(got[i]) == bytes(fb.read_results(i, 1)[0]) for i in (0, n - 1)), "rank 0's own block of the gather differs from its records"
 
     if rank != 0:
         if world > 1:
@@ -286,79 +300,86 @@ def main():
 
     x, y, rw, rh = fb.roi
     bw, bh = fb.layout.button[2], fb.layout.button[3]
-    map_bytes, full_bytes = algorithmic_bytes(rw, rh, bw, bh)
-    total_frames = n * world * args.steps
+    kernel_bytes, full_bytes = algorithmic_bytes(rw, rh, bw, bh, stages)
+    total_frames = n * world * rounds * args.steps
     value = total_frames / dt
+    what = "full CV pipeline" if stages == 0xF else ("marker threshold + LSD" if stages == 0x1 else "stages 0x%x" % stages)
     out = {
-        "metric": ("map frames/sec (1080p full CV pipeline), whole job" if (W, H) == (1920, 1080) else "map frames/sec (%dx%d full CV pipeline), whole job" % (W, H)),
+        "metric": "map frames/sec (%dx%d %s), whole job" % (W, H, what),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: %d x %dx%d BGRA frames resident in HBM per GPU, full pipeline "
-                               "(button, ui_map, marker mask+dilate, LSD, ocr_preprocess, scales+m/px)%s" % (
-                                   n, W, H, ", RCCL gather of result records" if world > 1 else ""),
-                   "frames_per_gpu": n, "global_batch": n * world, "frame": [W, H], "stages": args.stages,
+        "config": {"workload": (cfg["name"] if not custom else "custom: %d x %dx%d frames, stages 0x%x" % (n, W, H, stages)) +
+                               (", RCCL gather of result records" if world > 1 else ""),
+                   "baseline_config": args.config, "frames_per_gpu": n, "global_batch": n * world, "frame": [W, H], "stages": stages,
+                   "passes_per_step": rounds, "frames_per_step": n * world * rounds,
                    "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world,
-                   "pipeline_depth": depth},
+                   "pipeline_depth": depth, "schedule": "smhv_pipeline (library-owned streams, staggered start)"},
+        "ms_per_pass": dt / (args.steps * rounds) * 1e3,
         "per_gpu_frames_per_s": value / world,
+        "value_depth1": value_d1, "ms_per_pass_depth1": (ms_d1 / rounds if ms_d1 is not None else None),
         "h2d_seconds_for_batch": h2d_s,
         "all_map_open": bool(all_open),
     }
-    if tuning is not None:
-        out["stream_assignment"] = tuning
     if stages_ms is not None:
         t_map = stages_ms["map_pass"] * 1e-3
-        ach = n * map_bytes / t_map / 1e9 if t_map > 0 else 0.0
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction);
-        # only quoted when it was measured on this frame size
-        traffic = None
+        ach = n * kernel_bytes / t_map / 1e9 if t_map > 0 else 0.0
+        traffic, tsrc = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tj = json.load(f)
-            if tj.get("frame") == [W, H] and args.stages == 0xF:
+            if tj.get("frame") == [W, H] and stages == tj.get("stages", 0xF) and n == tj.get("frames", n):
                 traffic = tj["bytes_per_frame"] * n
+                tsrc = "profiles/traffic.json (committed rocprofv3 PMC run %s: FETCH_SIZE x2 + WRITE_SIZE of the kernel, gfx950 correction)" % tj.get("run", "")
         except (OSError, ValueError, KeyError):
             pass
-        out["roofline"] = {"bound": "hbm", "kernel": "k_map_pass", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "algorithmic_bytes_per_frame": map_bytes, "launch_ms": stages_ms["map_pass"],
-                           "note": "launch duration from hipEvents inside the timed (pipelined) region: with pipeline_depth > 1 the "
-                                   "kernel shares the chip with the previous step's LSD tail; roofline_isolated is the same kernel "
-                                   "timed alone right after the timed region"}
+        kname = "k_map_brq_pass" if (stages & 0xC) and (stages & 0x3) else "k_map_pass"
+        out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                           "algorithmic_bytes_per_frame": kernel_bytes, "launch_ms": stages_ms["map_pass"],
+                           "note": "launch duration from hipEvents on the launch's stream inside the timed region: with pipeline_depth > 1 "
+                                   "the kernel shares the chip with the other batch's line-segment search; roofline_isolated is the same "
+                                   "kernel in a pass that runs alone"}
         if iso_ms is not None and iso_ms["map_pass"] > 0:
-            a2 = n * map_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9
-            out["roofline_isolated"] = {"kernel": "k_map_pass", "achieved": a2, "frac": a2 / HBM_PEAK_GBS, "unit": "GB/s",
+            a2 = n * kernel_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9
+            out["roofline_isolated"] = {"kernel": kname, "achieved": a2, "frac": a2 / HBM_PEAK_GBS, "unit": "GB/s",
                                         "launch_ms": iso_ms["map_pass"], "stages_ms": iso_ms}
         out["stages_ms"] = stages_ms
         out["pipeline_algorithmic_GBps"] = value / world * full_bytes / 1e9
         out["pipeline_hbm_frac"] = value / world * full_bytes / 1e9 / HBM_PEAK_GBS
         t_lsd = stages_ms["lsd"] * 1e-3
-        out["lsd"] = {"rounds_per_frame": rounds, "ray_steps_per_frame": ray_steps, "lines_per_frame": n_lines,
+        out["lsd"] = {"rounds_per_frame": rounds_pf, "ray_steps_per_frame": ray_steps, "lines_per_frame": n_lines,
                       "ray_steps_per_s": (n * ray_steps / t_lsd) if t_lsd > 0 else None,
                       "time_share": stages_ms["lsd"] / max(sum(stages_ms.values()), 1e-9)}
 
-    if args.ingest_frames > 0 and world == 1:
-        out["ingest"] = ingest_leg(smh, vision, fbs, frames_host.numpy(), anchors, args, W, H, n)
+    if args.ingest_frames > 0 and world == 1 and args.config == 2 and not custom:
+        out["ingest"] = ingest_leg(smh, vision, pipe, frames_host.numpy(), anchors, stages, args.ingest_frames, W, H, n)
 
     if args.cpu_sample > 0 and world == 1:
         from oracle import oracle as orc   # CPU baseline leg only (checker, never the product path)
-        k = min(args.cpu_sample, n)
+        k = min(args.cpu_sample, n) if n > 1 else min(args.cpu_sample, 16)
+        if n == 1:                                         # config 1: more frames of the same kind for a stable figure
+            sub, sinfo = synth.make_batch(W, H, k, first_idx=first, n_lines=args.lines)
+        else:
+            sub, sinfo = frames_host.numpy()[:k], infos[:k]
         cores = min(os.cpu_count() or 1, k)              # threads actually used: one frame per thread at a time
         a = np.zeros((k, 3, 3), np.uint32)
         for i in range(k):
-            for j, s in enumerate(infos[i]["anchors"][:3]):
-                a[i, j] = s
-        sub = frames_host.numpy()[:k]
-        orc.process_batch(sub[:min(k, cores)], cores, stages=args.stages, anchors=a[:min(k, cores)], n_anchors=len(infos[0]["anchors"]),
-                          scales_start_y=infos[0]["scales_start_y"])          # warm-up
+            for j, s_ in enumerate(sinfo[i]["anchors"][:3]):
+                a[i, j] = s_
+        kw = dict(stages=stages, anchors=a, n_anchors=len(sinfo[0]["anchors"]), scales_start_y=sinfo[0]["scales_start_y"])
+        orc.process_batch(sub[:min(k, cores)], cores, stages=stages, anchors=a[:min(k, cores)], n_anchors=kw["n_anchors"], scales_start_y=kw["scales_start_y"])   # warm-up
         t0 = time.perf_counter()
-        res = orc.process_batch(sub, cores, stages=args.stages, anchors=a, n_anchors=len(infos[0]["anchors"]), scales_start_y=infos[0]["scales_start_y"])
+        res = orc.process_batch(sub, cores, **kw)
         cdt = time.perf_counter() - t0
-        same = all(res[i].n_lines == recs[i]["n_lines"] and res[i].rounds == recs[i]["rounds"] for i in range(k))
-        out["cpu_baseline"] = {"value": k / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
-                               "sample": "first %d frames of rank 0's batch, same stages, C oracle (gcc -O2), frames parallel across %d threads; "
-                                         "line/round counts match GPU: %s" % (k, cores, same)}
+        same = n == 1 or all(res[i].n_lines == recs[i]["n_lines"] and res[i].rounds == recs[i]["rounds"] for i in range(k))
+        split = cpu_stage_split(orc, sub[:4], sinfo[:4])
+        out["cpu_baseline"] = {"value": k / cdt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+                               "single_thread_stage_ms": split, "single_thread_frames_per_s": 1e3 / max(sum(split.values()), 1e-9),
+                               "sample": "%d frames of rank 0's workload, same stages, C oracle (gcc -O2, -ffp-contract=off), frames parallel across "
+                                         "%d threads; line/round counts match GPU: %s; stage split: mean of 4 frames on one thread" % (k, cores, same)}
     print(json.dumps(out))
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

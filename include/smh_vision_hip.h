@@ -184,8 +184,9 @@ SMHV_API int smhv_batch_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h
 SMHV_API void smhv_batch_destroy(smhv_batch *b);
 SMHV_API int smhv_batch_layout_get(smhv_batch *b, smhv_batch_layout *out);
 /* Runs the selected stages over n resident frames (d_frames: n * frame_w*frame_h*4 bytes of BGRA8 in
- * device memory) on `stream` (a hipStream_t, NULL = default stream).  Asynchronous: results are in
- * device memory when the stream reaches this point.  anchors: host array of n smhv_anchors or NULL. */
+ * device memory) on `stream` (a hipStream_t, NULL = default stream).  Asynchronous and non-blocking: every kernel and
+ * copy is enqueued on `stream` and the call returns; results are in device memory when the stream reaches this point.
+ * anchors: host array of n smhv_anchors or NULL (copied into pinned staging before the call returns). */
 SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                             const smhv_anchors *anchors, void *stream);
 /* device pointers of the batch outputs (valid for the life of the batch) */
@@ -197,14 +198,12 @@ SMHV_API int smhv_batch_read_image(smhv_batch *b, int which /* SMHV_VIEW_* or 10
  * 64 most recent), measured with hipEvents on
  * the run's stream (the analogue of the reference's Timeshares, vision-common/src/debug.rs:3-30).
  * ms[0]=button ms[1]=map pass ms[2]=brq pass ms[3]=lsd ms[4]=scale ratio.  Synchronises. */
-/* Run the scales branch of smhv_batch_run on a caller-provided stream (NULL: the batch's own).  A process has only a few
- * hardware queues; which HIP streams end up sharing one is decided by creation order, and two pipelined batches whose
- * branches alias onto one queue lose their overlap -- a host that pipelines batches can pick the streams itself. */
+/* Kept for source compatibility; has no effect: the batched pipeline runs entirely on the stream given to
+ * smhv_batch_run (the quadrant stages are fused into the streaming pass, the scale scan into the record kernel). */
 SMHV_API int smhv_batch_set_scales_stream(smhv_batch *b, void *stream);
-/* Make `stream` wait until the streaming pass (k_map_pass) of b's most recent smhv_batch_run has finished.  A host that
- * pipelines two batches uses it once, before the second batch's first run, to start the two steps half a period apart:
- * the streaming passes of one step then run underneath the line-segment kernel of the other (they share CUs), instead of
- * both steps streaming and then both searching. */
+/* Make `stream` wait until the streaming pass (k_map_pass) of b's most recent smhv_batch_run has finished.  (What
+ * smhv_pipeline_submit uses to start pipelined batches half a period apart; a host that pipelines smhv_batch objects by
+ * hand can do the same.) */
 SMHV_API int smhv_batch_wait_map_pass(smhv_batch *b, void *stream);
 SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
 /* diagnostic: per-frame cooperation counters of the most recent line-segment launch, 4 words per frame:
@@ -218,6 +217,25 @@ SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
  * the oldest candidate in flight, candidates retire in order through a reorder buffer.  Both produce the reference's
  * results bit for bit; the tests run every fuzz scene through both. */
 SMHV_API int smhv_debug_lsd_classic(int on);
+/* ---- pipeline: several batches in flight, scheduled by the library ----------------------------------------------
+ * `depth` output buffer sets (smhv_batch objects) of max_frames frames, each with its own stream.  The streams are
+ * created by the library, in a fixed order, and consecutive submissions are started half a period apart, so the
+ * throughput does not depend on what streams the host created before or on how it interleaves its calls.
+ *   submit : asynchronous.  Enqueues the stages for n resident frames on the next slot (round robin) and returns at
+ *            once; it only waits when that slot's previous submission (`depth` submissions ago) is still running.
+ *            after_stream (optional): a stream whose already enqueued work (e.g. the producer of d_frames) must finish
+ *            first.  *slot receives the slot index.
+ *   wait   : host waits for the slot's most recent submission.
+ *   slot   : the slot's batch object (results, device pointers, images) and stream (to order a consumer after it). */
+typedef struct smhv_pipeline smhv_pipeline;
+SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth, smhv_pipeline **out);
+SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p);
+SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                                  const smhv_anchors *anchors, void *after_stream, uint32_t *slot);
+SMHV_API int smhv_pipeline_wait(smhv_pipeline *p, uint32_t slot);
+SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p);
+SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv_batch **batch, void **stream);
+
 /* exhaustive colour-predicate check support: writes 2^24/32 words, bit (r<<16|g<<8|b) = device
  * is_any_map_marker_color(r,g,b) (vision-common/src/markers/mod.rs:40-54) */
 SMHV_API int smhv_debug_marker_table(smhv_ctx *ctx, uint32_t *bits);

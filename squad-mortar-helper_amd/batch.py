@@ -41,11 +41,15 @@ def results_to_dicts(recs):
 class FrameBatch:
     """Owns the output buffers for up to `max_frames` frames of one size on one device."""
 
-    def __init__(self, vision, frame_w, frame_h, max_frames):
+    def __init__(self, vision, frame_w, frame_h, max_frames, _handle=None):
         self._lib = L.load()
         self._vision = vision            # keeps the context alive
-        b = C.c_void_p()
-        L.check(self._lib.smhv_batch_create(vision._ctx, frame_w, frame_h, max_frames, C.byref(b)))
+        self._owned = _handle is None    # a pipeline slot's batch belongs to the pipeline
+        if _handle is None:
+            b = C.c_void_p()
+            L.check(self._lib.smhv_batch_create(vision._ctx, frame_w, frame_h, max_frames, C.byref(b)))
+        else:
+            b = _handle
         self._b = b
         self.max_frames = max_frames
         self.frame_w, self.frame_h = frame_w, frame_h
@@ -54,7 +58,8 @@ class FrameBatch:
 
     def close(self):
         if self._b:
-            self._lib.smhv_batch_destroy(self._b)
+            if self._owned:
+                self._lib.smhv_batch_destroy(self._b)
             self._b = None
 
     def __del__(self):
@@ -118,3 +123,49 @@ class FrameBatch:
             out = np.empty((h // 2, w // 2), np.uint8)
         L.check(self._lib.smhv_batch_read_image(self._b, which, frame, out.ctypes.data))
         return out
+
+
+class Pipeline:
+    """`depth` batches in flight on library-owned streams (smhv_pipeline_*): submit() is asynchronous and returns the slot;
+    the library starts consecutive submissions half a period apart and owns every stream of the schedule."""
+
+    def __init__(self, vision, frame_w, frame_h, max_frames, depth=2):
+        self._lib = L.load()
+        self._vision = vision
+        p = C.c_void_p()
+        L.check(self._lib.smhv_pipeline_create(vision._ctx, frame_w, frame_h, max_frames, depth, C.byref(p)))
+        self._p = p
+        self.depth = depth
+        self.slots, self.streams = [], []
+        for i in range(depth):
+            b, st = C.c_void_p(), C.c_void_p()
+            L.check(self._lib.smhv_pipeline_slot(self._p, i, C.byref(b), C.byref(st)))
+            self.slots.append(FrameBatch(vision, frame_w, frame_h, max_frames, _handle=b))
+            self.streams.append(st.value or 0)
+
+    def submit(self, frames_ptr, n, stages=L.STAGE_ALL, grayscale=True, max_gap=15, anchors=None, after_stream=0):
+        if anchors is not None and len(anchors) < n:
+            raise ValueError("anchors holds %d entries, the submission covers %d frames" % (len(anchors), n))
+        a = C.cast(anchors, C.c_void_p) if anchors is not None else None
+        slot = C.c_uint32(0)
+        L.check(self._lib.smhv_pipeline_submit(self._p, C.c_void_p(frames_ptr), n, stages, int(bool(grayscale)), max_gap, a, C.c_void_p(after_stream), C.byref(slot)))
+        return int(slot.value)
+
+    def wait(self, slot=None):
+        if slot is None:
+            L.check(self._lib.smhv_pipeline_wait_all(self._p))
+        else:
+            L.check(self._lib.smhv_pipeline_wait(self._p, slot))
+
+    def close(self):
+        if self._p:
+            for b in self.slots:
+                b.close()
+            self._lib.smhv_pipeline_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

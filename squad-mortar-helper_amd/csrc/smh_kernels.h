@@ -103,6 +103,8 @@ enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
 hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s);
+// map pass + quadrant pass in one (the quadrant pixels are read once); flags: MAP_*, qflags: BRQ_*
+hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
 // k_lsd is three kernels, one per mask residency mode, each over all frames (a workgroup whose frame needs another mode
 // exits at once).  When the whole ROI fits the LDS window (<= 1080p) every frame is a ROWS frame and only that kernel is
@@ -117,6 +119,7 @@ size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocatio
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);
 hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s);
+hipError_t launch_scales_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, uint32_t *d_bars, hipStream_t s);   // scale ratio + finalize
 // which: SMHV_VIEW_*; isolated: LSDPreprocess shows the marker-isolated crop (after isolate_map_markers)
 hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s);
 hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);

@@ -64,8 +64,9 @@ __device__ bool find_scale_width(const uint8_t *img, size_t pitch, uint32_t w, u
 	return false;
 }
 
-__global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) {
-	const uint32_t f = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+// (block of 64 * SMHV_MAX_SCALES threads; ends with the result in results[f].has_mpx / mpx, written by thread 0)
+__device__ __forceinline__ void scale_ratio_body(const Geom &g, const Buffers &b, uint32_t f, uint32_t *bars) {
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	__shared__ double s_ratio[SMHV_MAX_SCALES];
 	__shared__ uint32_t s_ok[SMHV_MAX_SCALES];
 	smhv_frame_result *res = &b.results[f];
@@ -99,6 +100,8 @@ __global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Bu
 		res->mpx = k == 0 ? 0.0 : (k == 1 ? sum : sum / (double)k);
 	}
 }
+
+__global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) { scale_ratio_body(g, b, blockIdx.x, bars); }
 
 // ------------------------------------------------------------------------------------------------
 // k_find_minimap: src/vision/find_minimap.rs (the caller's step right after crop_to_map).
@@ -178,8 +181,8 @@ __global__ void __launch_bounds__(256) k_find_minimap(Geom g, Buffers b) {
 // ------------------------------------------------------------------------------------------------
 // k_finalize: per-frame record header + ui::Marker::new / angle (src/ui/mod.rs:131-140, markers.rs:98)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t stages) {
-	const uint32_t f = blockIdx.x, l = threadIdx.x;
+__device__ __forceinline__ void finalize_body(const Geom &g, const Buffers &b, uint32_t f, uint32_t stages) {
+	const uint32_t l = threadIdx.x;
 	smhv_frame_result *res = &b.results[f];
 	const FrameAux aux = b.aux[f];
 	const bool open = aux.open != 0;
@@ -215,6 +218,15 @@ __global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t sta
 		if (!(stages & SMHV_STAGE_MINIMAP)) { res->has_minimap = 0; res->minimap[0] = 0; res->minimap[1] = 0; res->minimap[2] = 0; res->minimap[3] = 0; }
 		res->reserved = 0;
 	}
+}
+
+__global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t stages) { finalize_body(g, b, blockIdx.x, stages); }
+
+// calc_meters_to_px_ratio + the record in one launch (the batched pipeline: one stream, no branch to join)
+__global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scales_finalize(Geom g, Buffers b, uint32_t stages, uint32_t *bars) {
+	scale_ratio_body(g, b, blockIdx.x, bars);
+	__syncthreads();                                       // thread 0's has_mpx / mpx are visible to the block
+	if (threadIdx.x < 64) finalize_body(g, b, blockIdx.x, stages);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -269,6 +281,11 @@ hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipS
 
 hipError_t launch_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, hipStream_t s) {
 	hipLaunchKernelGGL(k_finalize, dim3(n), dim3(64), 0, s, g, b, stages);
+	return hipGetLastError();
+}
+
+hipError_t launch_scales_finalize(const Geom &g, const Buffers &b, uint32_t n, uint32_t stages, uint32_t *d_bars, hipStream_t s) {
+	hipLaunchKernelGGL(k_scales_finalize, dim3(n), dim3(64 * SMHV_MAX_SCALES), 0, s, g, b, stages, d_bars);
 	return hipGetLastError();
 }
 

@@ -131,11 +131,9 @@ struct smhv_batch {
 	uint32_t *d_lsd_req = nullptr;
 	LsdCacheEntry *d_lsd_cache = nullptr;
 	uint32_t lsd_epoch = 0;
-	// pinned staging for the per-run anchor upload (a pageable source would make hipMemcpyAsync synchronous);
-	// two slots + events so a run never overwrites a slot whose copy is still in flight
-	smhv_anchors *h_anchors[2] = {nullptr, nullptr};
-	hipEvent_t anchors_done[2] = {};
-	uint32_t anchors_slot = 0;
+	// pinned staging buffers for the per-run anchor upload, each with the event of the copy that last read it
+	struct AnchorStage { smhv_anchors *h = nullptr; hipEvent_t done = nullptr; };
+	std::vector<AnchorStage> anchor_stage;
 	// per-stage hipEvent ring: up to TIMING_RING timed runs are kept so a benchmark loop can read the
 	// average stage durations afterwards without synchronising between steps
 	static constexpr int TIMING_RING = 64;
@@ -398,10 +396,7 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 	ALLOC0(b->d_lsd_cache, sizeof(LsdCacheEntry) * SMH_LSD_CACHE_SLOTS * n);
 #undef ALLOC0
 	{
-		hipError_t e = hipStreamCreateWithFlags(&b->s_scales, hipStreamNonBlocking);
-		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
-		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_map_done, hipEventDisableTiming);
+		hipError_t e = hipEventCreateWithFlags(&b->ev_map_done, hipEventDisableTiming);
 		// Only for frame sizes that need them: a process has few hardware queues, and every extra stream makes it more
 		// likely that two independent branches share one (measured: 10 % off the pipelined 1080p throughput).
 		if (max_frames > 1 && !lsd_rows_only(b->g)) {
@@ -412,11 +407,6 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&b->lsd_fork.join2, hipEventDisableTiming);
 		}
 		if (e != hipSuccess) { smhv_batch_destroy(b); return fail(SMHV_E_HIP, "branch streams: %s", hipGetErrorString(e)); }
-	}
-	for (int i = 0; i < 2; ++i) {
-		hipError_t e = hipHostMalloc((void **)&b->h_anchors[i], sizeof(smhv_anchors) * n);
-		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->anchors_done[i], hipEventDisableTiming);
-		if (e != hipSuccess) { smhv_batch_destroy(b); return fail(SMHV_E_HIP, "anchor staging: %s", hipGetErrorString(e)); }
 	}
 	*out = b;
 	return SMHV_OK;
@@ -430,9 +420,9 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	                b->d_lsd_ctl, b->d_lsd_req, b->d_lsd_cache};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
-	for (int i = 0; i < 2; ++i) {
-		if (b->h_anchors[i]) (void)hipHostFree(b->h_anchors[i]);
-		if (b->anchors_done[i]) (void)hipEventDestroy(b->anchors_done[i]);
+	for (auto &a : b->anchor_stage) {
+		if (a.h) (void)hipHostFree(a.h);
+		if (a.done) (void)hipEventDestroy(a.done);
 	}
 	if (b->ev) {
 		for (int r = 0; r < smhv_batch::TIMING_RING; ++r)
@@ -498,11 +488,23 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	}
 	const bool scales = (stages & SMHV_STAGE_SCALES) && anchors;
 	if (scales) {
-		const uint32_t slot = b->anchors_slot++ & 1u;
-		HIPCHK(hipEventSynchronize(b->anchors_done[slot]));      // the copy that last used this slot (two runs ago)
-		memcpy(b->h_anchors[slot], anchors, sizeof(smhv_anchors) * n);
-		HIPCHK(hipMemcpyAsync(b->d_anchors, b->h_anchors[slot], sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, s));
-		HIPCHK(hipEventRecord(b->anchors_done[slot], s));
+		// Pinned staging for the anchor upload (a pageable source would make hipMemcpyAsync synchronous).  A staging
+		// buffer is reused once the copy that read it has completed; if none is free another one is allocated, so this call
+		// never waits for the device.
+		smhv_batch::AnchorStage *st = nullptr;
+		for (auto &a : b->anchor_stage)
+			if (hipEventQuery(a.done) == hipSuccess) { st = &a; break; }
+		if (!st) {
+			smhv_batch::AnchorStage a;
+			hipError_t e = hipHostMalloc((void **)&a.h, sizeof(smhv_anchors) * b->max_frames);
+			if (e == hipSuccess) e = hipEventCreateWithFlags(&a.done, hipEventDisableTiming);
+			if (e != hipSuccess) { if (a.h) (void)hipHostFree(a.h); return fail(SMHV_E_HIP, "anchor staging: %s", hipGetErrorString(e)); }
+			b->anchor_stage.push_back(a);
+			st = &b->anchor_stage.back();
+		}
+		memcpy(st->h, anchors, sizeof(smhv_anchors) * n);
+		HIPCHK(hipMemcpyAsync(b->d_anchors, st->h, sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, s));
+		HIPCHK(hipEventRecord(st->done, s));
 	}
 	const bool t = b->timing;
 	hipEvent_t *ev = t ? b->ev[b->timed_runs % smhv_batch::TIMING_RING] : nullptr;
@@ -511,39 +513,30 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	STAGE_BEGIN(0, s);
 	HIPCHK(launch_button(g, bf, n, 0, s));
 	STAGE_END(0, s);
-	uint32_t mflags = 0;                            // ---- markers branch: streaming pass ----
+	// ---- ONE streaming pass: ui_map, marker mask + dilation, and -- on the pixels it has loaded anyway -- the two
+	// bottom-right-quadrant images (ocr_preprocess, find_scales_preprocess).  Everything runs on the caller's stream: the
+	// schedule does not depend on how HIP happens to map extra streams onto hardware queues.
+	uint32_t mflags = 0, qflags = 0;
 	if (stages & SMHV_STAGE_MARKERS) mflags |= MAP_MASK;
 	if (stages & SMHV_STAGE_UI_MAP) mflags |= MAP_UI;
-	STAGE_BEGIN(1, s);
-	if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
-	STAGE_END(1, s);
-	HIPCHK(hipEventRecord(b->ev_map_done, s));
-	uint32_t qflags = 0;
 	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
 	if (scales) qflags |= BRQ_SCALES;
-	hipStream_t sq = b->s_scales_ext ? b->s_scales_ext : b->s_scales;
-	if (qflags) {
-		// ---- scales branch, concurrent with the LSD of the markers branch.  It forks after the map pass: both
-		// are HBM streaming passes and gain nothing from sharing the chip, while the LSD launch (one workgroup
-		// per frame, VALU/LDS-bound) ends with a tail of idle CUs that the quadrant pass fills.
-		HIPCHK(hipEventRecord(b->ev_fork, s));
-		HIPCHK(hipStreamWaitEvent(sq, b->ev_fork, 0));
-		STAGE_BEGIN(2, sq);
-		HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, sq));
-		STAGE_END(2, sq);
-		STAGE_BEGIN(4, sq);
-		if (scales) HIPCHK(launch_scale_ratio(g, bf, n, b->d_bars, sq));
-		STAGE_END(4, sq);
-		HIPCHK(hipEventRecord(b->ev_join, sq));
-	} else {
-		STAGE_BEGIN(2, s); STAGE_END(2, s); STAGE_BEGIN(4, s); STAGE_END(4, s);
-	}
+	STAGE_BEGIN(1, s);
+	if (mflags && qflags) HIPCHK(launch_map_brq_pass(g, bf, n, mflags, qflags, grayscale, 0, 1, s));
+	else if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
+	STAGE_END(1, s);
+	STAGE_BEGIN(2, s);
+	if (qflags && !mflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
+	STAGE_END(2, s);
+	HIPCHK(hipEventRecord(b->ev_map_done, s));
 	STAGE_BEGIN(3, s);
 	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, s, b->lsd_fork.s1 ? &b->lsd_fork : nullptr));
 	STAGE_END(3, s);
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, s));
-	if (qflags) HIPCHK(hipStreamWaitEvent(s, b->ev_join, 0));
-	HIPCHK(launch_finalize(g, bf, n, scales ? stages : (stages & ~SMHV_STAGE_SCALES), s));
+	STAGE_BEGIN(4, s);
+	if (scales) HIPCHK(launch_scales_finalize(g, bf, n, stages, b->d_bars, s));
+	else HIPCHK(launch_finalize(g, bf, n, stages & ~SMHV_STAGE_SCALES, s));
+	STAGE_END(4, s);
 #undef STAGE_BEGIN
 #undef STAGE_END
 	if (t) b->timed_runs++;
@@ -559,7 +552,7 @@ extern "C" SMHV_API int smhv_batch_wait_map_pass(smhv_batch *b, void *stream) {
 
 extern "C" SMHV_API int smhv_batch_set_scales_stream(smhv_batch *b, void *stream) {
 	if (!b) return fail(SMHV_E_INVALID, "null batch");
-	b->s_scales_ext = (hipStream_t)stream;                    // nullptr: back to the batch's own stream
+	(void)stream;                                             // kept for source compatibility: there is no scales branch stream any more
 	return SMHV_OK;
 }
 
@@ -652,6 +645,113 @@ extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t
 	default:
 		return fail(SMHV_E_INVALID, "unsupported image id %d", which);
 	}
+	return SMHV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pipeline: `depth` batches in flight, each on its own stream; the library owns the schedule
+// ------------------------------------------------------------------------------------------------
+struct smhv_pipeline {
+	smhv_ctx *ctx = nullptr;
+	uint32_t depth = 0;
+	std::vector<smhv_batch *> batch;
+	std::vector<hipStream_t> stream;
+	std::vector<hipEvent_t> done;       // end of the slot's most recent submission
+	hipEvent_t ev_after = nullptr;
+	uint64_t submitted = 0;             // submissions so far
+	uint64_t round_start = 0;           // index of the first submission after the pipeline last ran empty
+};
+
+extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
+	if (!p) return;
+	if (p->ctx) (void)hipSetDevice(p->ctx->device);
+	for (auto st : p->stream) if (st) (void)hipStreamSynchronize(st);
+	for (auto b : p->batch) if (b) smhv_batch_destroy(b);
+	for (auto e : p->done) if (e) (void)hipEventDestroy(e);
+	if (p->ev_after) (void)hipEventDestroy(p->ev_after);
+	for (auto st : p->stream) if (st) (void)hipStreamDestroy(st);
+	ctx_release(p->ctx);
+	delete p;
+}
+
+extern "C" SMHV_API int smhv_pipeline_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, smhv_pipeline **out) {
+	if (!c || !out || max_frames == 0 || depth == 0 || depth > 8) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..8)");
+	*out = nullptr;
+	CTX_OPEN(c);
+	HIPCHK(hipSetDevice(c->device));
+	smhv_pipeline *p = new (std::nothrow) smhv_pipeline();
+	if (!p) return fail(SMHV_E_INVALID, "out of host memory");
+	c->refs.fetch_add(1, std::memory_order_relaxed);
+	p->ctx = c; p->depth = depth;
+	p->batch.assign(depth, nullptr); p->stream.assign(depth, nullptr); p->done.assign(depth, nullptr);
+	// The streams are created back to back, before any other object of the pipeline: HIP deals streams onto the
+	// hardware queues in creation order, so consecutive streams never share one, whatever the host created earlier.
+	for (uint32_t i = 0; i < depth; ++i) {
+		hipError_t e = hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking);
+		if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline stream: %s", hipGetErrorString(e)); }
+	}
+	hipError_t e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
+	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
+	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline events: %s", hipGetErrorString(e)); }
+	for (uint32_t i = 0; i < depth; ++i) {
+		int rc = smhv_batch_create(c, W, H, max_frames, &p->batch[i]);
+		if (rc) { smhv_pipeline_destroy(p); return rc; }
+	}
+	*out = p;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                                             const smhv_anchors *anchors, void *after_stream, uint32_t *slot_out) {
+	if (!p) return fail(SMHV_E_INVALID, "null pipeline");
+	CTX_OPEN(p->ctx);
+	HIPCHK(hipSetDevice(p->ctx->device));
+	const uint32_t slot = (uint32_t)(p->submitted % p->depth);
+	// the slot's previous submission (depth submissions ago) owns its output buffers until it has finished: this is the
+	// only place the call can wait, and only when more than `depth` submissions would be in flight
+	HIPCHK(hipEventSynchronize(p->done[slot]));
+	bool idle = true;
+	for (uint32_t i = 0; i < p->depth && idle; ++i) idle = hipEventQuery(p->done[i]) == hipSuccess;
+	if (idle) p->round_start = p->submitted;
+	hipStream_t st = p->stream[slot];
+	if (after_stream) {                                       // e.g. the producer of d_frames
+		HIPCHK(hipEventRecord(p->ev_after, (hipStream_t)after_stream));
+		HIPCHK(hipStreamWaitEvent(st, p->ev_after, 0));
+	}
+	// Stagger: in the first round after the device ran empty, submission k starts its streaming pass when submission k-1
+	// has finished its own, so the batches run half a period apart from the outset -- the streaming pass of one underneath
+	// the line-segment search of the other -- instead of locking into streaming together and then searching together.
+	const uint64_t k = p->submitted - p->round_start;
+	if (k > 0 && k < p->depth) {
+		const uint32_t prev = (uint32_t)((p->submitted - 1) % p->depth);
+		HIPCHK(hipStreamWaitEvent(st, p->batch[prev]->ev_map_done, 0));
+	}
+	int rc = smhv_batch_run(p->batch[slot], d_frames, n, stages, grayscale, max_gap, anchors, st);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(p->done[slot], st));
+	p->submitted++;
+	if (slot_out) *slot_out = slot;
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_pipeline_wait(smhv_pipeline *p, uint32_t slot) {
+	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_wait: bad arguments");
+	HIPCHK(hipSetDevice(p->ctx->device));
+	HIPCHK(hipEventSynchronize(p->done[slot]));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
+	if (!p) return fail(SMHV_E_INVALID, "null pipeline");
+	HIPCHK(hipSetDevice(p->ctx->device));
+	for (uint32_t i = 0; i < p->depth; ++i) HIPCHK(hipEventSynchronize(p->done[i]));
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv_batch **batch, void **stream) {
+	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_slot: bad arguments");
+	if (batch) *batch = p->batch[slot];
+	if (stream) *stream = (void *)p->stream[slot];
 	return SMHV_OK;
 }
 

@@ -370,6 +370,266 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_map_brq_pass: k_map_pass and k_brq_pass in ONE pass over the map ROI (the batched pipeline with the OCR / scales
+// stages selected).  The bottom-right quadrant is part of the ROI and both kernels walk the same quad grid (quads are
+// aligned to frame x % 4 == 0), so a thread whose quad column crosses the quadrant evaluates ocr_preprocess /
+// find_scales_preprocess on the pixels it has already loaded for ui_map and the marker mask: the quadrant is not read a
+// second time (k_brq_pass re-read 2 x 126 MB per 256 frames) and one launch and the branch stream go away.
+// Column masks are indexed from row r0 - 3 (the OCR neighbourhood reaches 3 rows up; the marker dilation 1), so a band
+// holds at most 58 output rows: 3 + 58 + 3 = 64 bits.
+// ------------------------------------------------------------------------------------------------
+#define MAPQ_RB_MAX 58
+
+template <bool GRAY>
+__global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start) {
+	const uint32_t f = blockIdx.y;
+	if (!b.aux[f].open) return;
+	uint32_t start_y = fixed_start_y;
+	bool do_scales = (qflags & BRQ_SCALES) != 0;
+	if (use_anchor_start && do_scales) {
+		const smhv_anchors an = b.anchors[f];
+		start_y = an.scales_start_y;
+		// src/vision/mod.rs:196-198: no labels => the scales branch returns before find_scales_preprocess
+		if (an.n == 0 || start_y > g.qh) do_scales = false;
+	}
+	const bool do_ocr = (qflags & BRQ_OCR) != 0;
+	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
+	const int r0 = (int)(blockIdx.x * RB);
+	const int r1 = min(r0 + (int)RB, (int)g.rh);
+	const bool qact = q < g.m_quads;
+	uint32_t vmask = 0;
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+		if ((uint32_t)(4 * q + c - g.m_xoff) < g.rw) vmask |= 1u << c;
+	if (!qact) vmask = 0;
+	// ---- the quadrant as this thread sees it: quad index in the quadrant's own (padded) rows, valid / neighbour pixels ----
+	const int qy0 = (int)(g.qy - g.ry);                          // first quadrant row, ROI coordinates
+	const int qq = (int)q - (int)((g.q_ax - g.m_ax) >> 2);       // quad index in the quadrant's output rows
+	const bool in_q = qq >= 0 && (uint32_t)qq < g.q_quads && qact;
+	uint32_t qv = 0, qw_ = 0;                                    // valid pixel / pixel allowed as a "white neighbour" (x <= w - 3)
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint32_t x = (uint32_t)(4 * qq + c) - g.q_xoff;
+		if (in_q && x < g.qw) qv |= 1u << c;
+		if (in_q && x + SMH_OCR_DILATE_RADIUS <= g.qw) qw_ |= 1u << c;
+	}
+	qw_ &= qv;
+	const int qr0 = max(r0 - qy0, 0), qr1 = min(r1 - qy0, (int)g.qh);     // quadrant rows this band writes: [qr0, qr1)
+	const bool band_q = qr1 > qr0 && (do_ocr || do_scales);               // uniform: the band touches the quadrant
+
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax + 4 * q) * 4;
+	uint8_t *uip = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
+	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
+	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
+	const size_t row_bytes = (size_t)g.W * 4;
+
+	uint64_t P[4] = {0, 0, 0, 0}, Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
+	// rows walked: the marker dilation needs r0-1 .. r1, the OCR neighbourhood (quadrant rows only) r0-3 .. r1+2
+	int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
+	if (band_q && do_ocr) { rs = max(min(rs, max(r0 - 3, qy0)), 0); re = min(max(re, min(r1 + 2, qy0 + (int)g.qh - 1)), (int)g.rh - 1); }
+	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
+	const int base = r0 - 3;                                     // row of bit 0 of every column mask
+
+	const uint8_t *lp = qact ? fp : fp - (size_t)q * 16;
+	uint4 nx[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
+	extern __shared__ __attribute__((aligned(16))) uint32_t s_hits[];
+	for (int r = rs; r <= re; r += 4) {
+		uint4 px[4];
+		uint32_t prehits = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) px[k] = nx[k];
+		if (r + 4 <= re) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(r + 4 + k, re) * row_bytes);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int row = r + k;
+			if (row > re) break;
+			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+			const bool out_row = row >= r0 && row < r1;
+			uint32_t lum[4] = {0, 0, 0, 0};
+			if ((do_ui && GRAY && out_row) || band_q) {
+#pragma unroll
+				for (int c = 0; c < 4; ++c) lum[c] = luma8((pv[c] >> 16) & 255u, (pv[c] >> 8) & 255u, pv[c] & 255u);
+			}
+			if (do_ui && out_row && qact) {
+				uint4 o;
+				uint32_t ov[4];
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+					if (GRAY) ov[c] = lum[c] * 0x00010101u | 0xFF000000u;                  // Bgra::to_luma -> (l,l,l,255)
+					else ov[c] = rr8 | (gg << 8) | (bb << 16) | 0xFF000000u;               // (r,g,b,255)
+				}
+				o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
+				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
+			}
+			if (do_mask && row >= r0 - 1 && row <= r1) {
+				uint32_t pre = 0;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
+				prehits |= (pre & vmask) << (4 * k);
+			}
+			const int qrow = row - qy0;                              // quadrant row
+			if (band_q && qrow >= 0 && qrow < (int)g.qh) {
+				const int bit = row - base;
+				const bool q_out = qrow >= qr0 && qrow < qr1;
+				const bool nb_row = (uint32_t)qrow + SMH_OCR_DILATE_RADIUS <= g.qh;   // y <= h - 3
+				uint32_t ocr_w = 0, sc_w = 0;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+					const uint32_t mx = max(rr8, max(gg, bb)), mn = min(rr8, min(gg, bb));
+					const bool w = (mx == mn) && mn >= SMH_OCR_BRIGHTNESS_THRESHOLD;
+					const bool e = (4u * (mx - mn) <= SMH_OCR_SIMILARITY_EDGE_THRESHOLD) && mn >= SMH_OCR_BRIGHTNESS_EDGE_THRESHOLD && !w;
+					const bool valid = (qv >> c) & 1u;
+					Wb[c] |= (uint64_t)((w && nb_row && ((qw_ >> c) & 1u)) ? 1u : 0u) << bit;
+					Eb[c] |= (uint64_t)((e && valid && q_out) ? 1u : 0u) << bit;
+					ocr_w |= ((w && valid) ? (255u - lum[c]) : 255u) << (8 * c);
+					sc_w |= (lum[c] != 0u ? 255u : 0u) << (8 * c);
+				}
+				if (q_out && in_q) {
+					if (do_ocr) *(uint32_t *)(op + (size_t)qrow * g.ocr_pitch) = ocr_w;
+					if (do_scales && (uint32_t)qrow >= start_y) *(uint32_t *)(sp + (size_t)qrow * g.ocr_pitch) = sc_w;
+				}
+			}
+		}
+		// ---- exact f32 HSV test for the pre-filter hits of this wave, one hit per lane (see k_map_pass) ----
+		if (do_mask && __any(prehits != 0u)) {
+			uint32_t *hpx = s_hits + wave * 160u;
+			uint32_t *hres = hpx + 64;
+			unsigned short *hid = (unsigned short *)(hres + 64);
+			const uint32_t cnt = (uint32_t)__popc(prehits);
+			uint32_t incl = cnt;
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
+			const uint32_t total = __shfl(incl, 63);
+			const uint32_t off = incl - cnt;
+			hres[lane] = 0u;
+			for (uint32_t hb = 0; hb < total; hb += 64u) {
+				uint32_t o = off - hb;                             // may wrap: compared unsigned below
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const uint32_t pk[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
+#pragma unroll
+					for (int c = 0; c < 4; ++c)
+						if ((prehits >> (4 * k + c)) & 1u) {
+							if (o < 64u) { hpx[o] = pk[c]; hid[o] = (unsigned short)((lane << 4) | (uint32_t)(4 * k + c)); }
+							++o;
+						}
+				}
+				__builtin_amdgcn_wave_barrier();
+				const uint32_t e = hb + lane;
+				if (e < total) {
+					const uint32_t p = hpx[lane];
+					if (marker_exact((p >> 16) & 255u, (p >> 8) & 255u, p & 255u)) {
+						const uint32_t id = hid[lane];
+						atomicOr(&hres[id >> 4], 1u << (id & 15u));
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+			const uint32_t res = hres[lane];                       // bit 4k+c: pixel c of row r+k is a marker colour
+			if (res) {
+				const int sh = r - base;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					uint32_t y = (res >> c) & 0x1111u;                 // rows k = 0..3 at bits 0,4,8,12
+					y = (y | (y >> 3) | (y >> 6) | (y >> 9)) & 0xFu;   // -> bits 0..3
+					P[c] |= (uint64_t)y << sh;
+				}
+			}
+		}
+	}
+
+	// ---- lane / wave neighbours of the column masks: marker dilation (P) and the 7-row-dilated white masks (V) ----
+	uint64_t V[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint64_t w = Wb[c];
+		V[c] = w | (w << 1) | (w << 2) | (w << 3) | (w >> 1) | (w >> 2) | (w >> 3);
+	}
+	__shared__ uint64_t s_edge_first[16], s_edge_last[16], s_first[16][4], s_last[16][4];
+	if (lane == 0) { s_edge_first[wave] = P[0]; s_first[wave][0] = V[0]; s_first[wave][1] = V[1]; s_first[wave][2] = V[2]; s_first[wave][3] = V[3]; }
+	if (lane == 63) { s_edge_last[wave] = P[3]; s_last[wave][0] = V[0]; s_last[wave][1] = V[1]; s_last[wave][2] = V[2]; s_last[wave][3] = V[3]; }
+	__syncthreads();
+	if (do_mask) {
+		uint64_t left = __shfl_up(P[3], 1), right = __shfl_down(P[0], 1);
+		if (lane == 0) left = wave > 0 ? s_edge_last[wave - 1] : 0ull;
+		if (lane == 63) right = wave + 1 < nwave ? s_edge_first[wave + 1] : 0ull;
+		const int nrows = r1 - r0;
+		const uint64_t rowmask = ((nrows >= 61 ? ~0ull : ((1ull << nrows) - 1ull)) << 3);   // bits 3..3+nrows-1
+		uint64_t D[4];
+#define SMH_VERT(p) ((p) | ((p) << 1) | ((p) >> 1))
+		D[0] = SMH_VERT(P[0]) | left | P[1];
+		D[1] = SMH_VERT(P[1]) | P[0] | P[2];
+		D[2] = SMH_VERT(P[2]) | P[1] | P[3];
+		D[3] = SMH_VERT(P[3]) | P[2] | right;
+#undef SMH_VERT
+#pragma unroll
+		for (int c = 0; c < 4; ++c) D[c] = ((vmask >> c) & 1u) ? (D[c] & rowmask) : 0ull;
+		const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
+		if (q < quads_padded) {
+			uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
+			uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
+			for (int row = r0; row < r1; ++row) {
+				const int bit = row - base;
+				const uint32_t nib = (uint32_t)((D[0] >> bit) & 1ull) | ((uint32_t)((D[1] >> bit) & 1ull) << 1) |
+				                     ((uint32_t)((D[2] >> bit) & 1ull) << 2) | ((uint32_t)((D[3] >> bit) & 1ull) << 3);
+				*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;
+				uint32_t v = nib;
+				v |= __shfl_down(v, 1) << 4;
+				v |= __shfl_down(v, 2) << 8;
+				v |= __shfl_down(v, 4) << 16;
+				if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
+			}
+		}
+		const uint64_t any = D[0] | D[1] | D[2] | D[3];
+		const uint64_t lanes_set = __ballot(any != 0ull);
+		if (lanes_set) {
+			const uint64_t rows_set = wave_or64(any);
+			const uint32_t cnt = wave_sum32(__popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]));
+			if (lane == 0) {
+				FrameAux *a = &b.aux[f];
+				atomicMin(&a->y_min, (uint32_t)(base + __builtin_ctzll(rows_set)));
+				atomicMax(&a->y_max, (uint32_t)(base + 63 - __builtin_clzll(rows_set)));
+				atomicMin(&a->w_min, (wave * 64u + (uint32_t)__builtin_ctzll(lanes_set)) >> 3);
+				atomicMax(&a->w_max, (wave * 64u + 63u - (uint32_t)__builtin_clzll(lanes_set)) >> 3);
+				atomicAdd(&a->n_mask_px, cnt);
+			}
+		}
+	}
+	if (!(band_q && do_ocr)) return;
+	// ---- ocr_preprocess: edge pixels with a white pixel in their 7x7 neighbourhood (see k_brq_pass) ----
+	uint64_t X[12];   // columns -4..7 relative to this quad
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		uint64_t l = __shfl_up(V[c], 1), r = __shfl_down(V[c], 1);
+		if (lane == 0) l = wave > 0 ? s_last[wave - 1][c] : 0ull;
+		if (lane == 63) r = wave + 1 < nwave ? s_first[wave + 1][c] : 0ull;
+		X[c] = l; X[4 + c] = V[c]; X[8 + c] = r;
+	}
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		uint64_t d = 0;
+#pragma unroll
+		for (int k = -3; k <= 3; ++k) d |= X[4 + c + k];
+		uint64_t kk = Eb[c] & d;
+		// rare (anti-aliased glyph edges): re-read just those pixels for their luma and patch the byte written above
+		while (kk) {
+			const int bit = __builtin_ctzll(kk);
+			kk &= kk - 1;
+			const int row = base + bit;
+			const uint32_t p = *(const uint32_t *)(fp + (size_t)row * row_bytes + 4 * c);
+			const uint32_t l = luma8((p >> 16) & 255u, (p >> 8) & 255u, p & 255u);
+			op[(size_t)(row - qy0) * g.ocr_pitch + c] = (uint8_t)(255u - l);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s) {
@@ -385,6 +645,16 @@ hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 	const unsigned lds = (g.m_block / 64u) * 640u;             // 64 x (pixel, verdict, id) per wave
 	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, RB);
 	else hipLaunchKernelGGL(k_map_pass<false>, grid, dim3(g.m_block), lds, s, g, b, flags, RB);
+	return hipGetLastError();
+}
+
+hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s) {
+	uint32_t RB = MAPQ_RB_MAX;
+	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
+	const dim3 grid((g.rh + RB - 1) / RB, n);
+	const unsigned lds = (g.m_block / 64u) * 640u;
+	if (grayscale) hipLaunchKernelGGL(k_map_brq_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start);
+	else hipLaunchKernelGGL(k_map_brq_pass<false>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start);
 	return hipGetLastError();
 }
 

@@ -54,3 +54,38 @@ def records_from_bytes(buf):
     arr = (L.FrameResult * n)()
     C.memmove(arr, buf.ctypes.data, n * RECORD_BYTES)
     return arr
+
+
+def device_records_view(results_ptr, n):
+    """uint8 CUDA tensor over the library's device result records (no copy): what the RCCL gather sends."""
+    import torch
+
+    class _Rec:
+        __cuda_array_interface__ = {"shape": (n * RECORD_BYTES,), "typestr": "|u1", "data": (int(results_ptr), False), "version": 2}
+    return torch.as_tensor(_Rec(), device="cuda")
+
+
+class RecordGather:
+    """Gather of the fixed-size per-frame records of equal shards to rank 0, with every buffer allocated once: one set of
+    receive buffers per pipeline slot on rank 0 (so a gather in flight is never overwritten by the next pass of another
+    slot), none elsewhere.  `dist` is torch.distributed with an initialised process group (nccl = RCCL, or gloo)."""
+
+    def __init__(self, dist, n_local, world, rank, device="cuda", slots=8, dst=0):
+        import torch
+        self.dist, self.world, self.rank, self.dst = dist, world, rank, dst
+        self.nbytes = n_local * RECORD_BYTES
+        self.bufs = None
+        if rank == dst:
+            self.bufs = [[torch.empty(self.nbytes, dtype=torch.uint8, device=device) for _ in range(world)] for _ in range(slots)]
+
+    def run(self, local_records, slot=0):
+        """Asynchronous with respect to the host for nccl: ordered after the work already on the current stream."""
+        assert local_records.numel() == self.nbytes
+        self.dist.gather(local_records, self.bufs[slot % len(self.bufs)] if self.rank == self.dst else None, dst=self.dst)
+
+    def records(self, slot=0):
+        """rank 0, after synchronising: ctypes array of all world * n_local records in rank order."""
+        import torch
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        flat = np.concatenate([b.cpu().numpy() for b in self.bufs[slot % len(self.bufs)]])
+        return records_from_bytes(flat)

@@ -281,6 +281,106 @@ def test_fuzz_stream_slice(vision):
         assert np.array_equal(colour[0][..., :3], frame[y:y + rh, x:x + rw, 2::-1])
 
 
+def test_fused_streaming_pass_on_threshold_frames(vision):
+    """The batched pipeline computes ui_map, the marker mask and the two bottom-right-quadrant images in ONE pass over
+    the ROI (k_map_brq_pass).  Frames whose pixels sit around every decision threshold (tools/fuzz_stream.py), at sizes
+    whose quadrant starts at different phases of the 4-pixel quad grid and of the 58-row bands; every image against the
+    oracle, for all stage subsets that select the fused kernel, grey and colour ui_map."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from fuzz_scenes import random_frame
+    rng = np.random.default_rng(17)
+    for (W, H) in [(1920, 1080), (2560, 1440), (1024, 768), (1366, 768), (1680, 1050), (1280, 1024), (1600, 1024), (3840, 2160)]:
+        N = 3
+        frames = np.stack([random_frame(rng, W, H) for _ in range(N)])
+        bx, by, bw, bh = smh.button_bounds(W, H)
+        frames[:, by:by + bh, bx:bx + bw, :3] = (49, 67, 217)                       # map open
+        start = [int(rng.integers(0, 60)) for _ in range(N)]
+        per = [(start[i], [(100, 10, start[i])]) for i in range(N)]
+        per[1] = (per[1][0], [])                                                     # no labels: scales image must stay untouched
+        d = torch.from_numpy(frames).cuda()
+        fb = smh.FrameBatch(vision, W, H, N)
+        s = torch.cuda.current_stream().cuda_stream
+        x, y, rw, rh = smh.map_bounds(W, H)
+        for stages, gray in ((0xF, True), (0xF, False), (0x7, True), (0xD, True), (0xE, True), (0x6, False)):
+            fb.run(d.data_ptr(), N, stages=stages, grayscale=gray, anchors=smh.make_anchors(per), stream=s)
+            torch.cuda.synchronize()
+            for i in range(N):
+                ref = o.process_frame(frames[i], grayscale=gray, stages=0xF, anchors=per[i][1] or None, scales_start_y=per[i][0], want_images=True)
+                if stages & 0x2:
+                    assert np.array_equal(fb.read_image(smh._lib.IMAGE_UI_MAP, i), ref["ui_map"]), (W, H, stages, i)
+                if stages & 0x1:
+                    assert np.array_equal(fb.read_image(smh._lib.VIEW_LSD_INPUT, i), ref["lsd"]), (W, H, stages, i)
+                if stages & 0x4:
+                    assert np.array_equal(fb.read_image(smh._lib.VIEW_OCR_INPUT, i), ref["ocr"]), (W, H, stages, i)
+                if (stages & 0x8) and per[i][1]:
+                    assert np.array_equal(fb.read_image(smh._lib.VIEW_FIND_SCALES_INPUT, i)[per[i][0]:], ref["scales"][per[i][0]:]), (W, H, stages, i)
+        fb.close()
+
+
+def test_pipeline_object_gives_the_records_of_plain_runs(vision):
+    """smhv_pipeline_*: depth 1..4, interleaved with idle streams the host created beforehand; every submission's records
+    equal those of a plain smhv_batch_run of the same frames, the slot hand-back is round robin, submit never loses a
+    batch when more than `depth` are pushed back to back."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N = 1920, 1080, 24
+    sets = []
+    for k in range(3):
+        fr, inf = synth.make_batch(W, H, N, first_idx=9000 + 100 * k, n_lines=2 + k)
+        sets.append((torch.from_numpy(fr).cuda(), smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in inf])))
+    fb = smh.FrameBatch(vision, W, H, N)
+    want = []
+    for d, a in sets:
+        fb.run(d.data_ptr(), N, anchors=a, stream=torch.cuda.current_stream().cuda_stream)
+        want.append(bytes(fb.read_results(0, N)))
+    fb.close()
+    assert len(set(want)) == 3
+    idle = [torch.cuda.Stream() for _ in range(3)]                  # streams created before the pipeline: must not matter
+    for depth in (1, 2, 3, 4):
+        pipe = smh.Pipeline(vision, W, H, N, depth)
+        order = [0, 1, 2, 2, 1, 0, 1, 1, 0, 2, 0, 1]
+        slots = []
+        for j, k in enumerate(order):
+            slot = pipe.submit(sets[k][0].data_ptr(), N, anchors=sets[k][1])
+            assert slot == j % depth
+            slots.append((slot, k, j))
+            if j >= depth - 1:                                          # the oldest submission still in flight
+                s_old, k_old, j_old = slots[j - (depth - 1)]
+                pipe.wait(s_old)
+                assert bytes(pipe.slots[s_old].read_results(0, N)) == want[k_old], (depth, j_old)
+        pipe.wait()
+        # a producer stream: the frames are written on another stream right before the submission
+        prod = torch.cuda.Stream()
+        with torch.cuda.stream(prod):
+            tmp = sets[2][0].clone()
+        slot = pipe.submit(tmp.data_ptr(), N, anchors=sets[2][1], after_stream=prod.cuda_stream)
+        pipe.wait(slot)
+        assert bytes(pipe.slots[slot].read_results(0, N)) == want[2]
+        pipe.close()
+    del idle
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo(vision):
+    """bench.py's N > 1 path (block shard, per-pass gather of the records on the slot's stream, MAX-over-ranks timing) with
+    two ranks sharing this GPU over gloo: the JSON line must report both ranks' frames."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29741",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-gpu", "16", "--rounds-per-step", "2",
+           "--dist-backend", "gloo", "--force-device", "0", "--cpu-sample", "0", "--ingest-frames", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0 and out["value_depth1"] > 0
+    assert out["config"]["frames_per_step"] == 64 and out["scaling"] == "weak"
+
+
 def test_lsd_helpers_do_not_change_any_record(vision):
     """SMHV_STAGE_LSD_HELPERS: workgroups that have finished their frame ray-cast candidates for the frames still being
     searched.  Ray casting is a pure function of (mask, pixel), so every record must stay byte-identical -- on a batch

@@ -120,6 +120,17 @@ if rank == 0:
 out2 = gather_records(buf[:3 * RECORD_BYTES].contiguous(), dist, sizes=[3 * RECORD_BYTES] * world)
 if rank == 0:
     assert [t.numel() for t in out2] == [3 * RECORD_BYTES] * world
+# the pre-allocated gather bench.py uses per pass (equal shards, one receive buffer set per pipeline slot)
+from squad_mortar_helper_amd.dist import RecordGather
+g = RecordGather(dist, 3, world, rank, device="cpu", slots=2)
+for slot in (0, 1, 0):
+    mine = buf[:3 * RECORD_BYTES].clone()
+    mine[0] = 10 * slot + rank + 1                       # first byte of map_open: marks (slot, rank)
+    g.run(mine, slot)
+    if rank == 0:
+        got = g.records(slot)
+        assert len(got) == 3 * world and [got[3 * r].map_open & 0xFF for r in range(world)] == [10 * slot + r + 1 for r in range(world)]
+if rank == 0:
     print("GATHER_OK")
 dist.destroy_process_group()
 '''
