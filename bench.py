@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="batches in flight (smhv_pipeline_create depth)")
+    ap.add_argument("--stream-cus", type=int, default=None,
+                    help="CUs of every 32 reserved for the streaming kernels (smhv_pipeline_create_partitioned); default: the library's choice")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
@@ -205,7 +207,7 @@ def main():
 
     vision = smh.HipVision.init(local_rank)
     depth = max(1, args.pipeline_depth)
-    pipe = smh.Pipeline(vision, W, H, n, depth)
+    pipe = smh.Pipeline(vision, W, H, n, depth, stream_cus=args.stream_cus)
     anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 0x8 else None
     fptr = frames.data_ptr()
 
@@ -214,14 +216,15 @@ def main():
     gather = None
     if world > 1:
         gather = sdist.RecordGather(dist, n, world, rank, device=("cuda" if nccl else "cpu"))
-        slot_streams = [torch.cuda.ExternalStream(s) for s in pipe.streams]
         rec_views = [sdist.device_records_view(b.device_ptrs()["results"], n) for b in pipe.slots]
 
     def one_pass(p):
         slot = p.submit(fptr, n, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
         if gather is not None and p is pipe:
-            with torch.cuda.stream(slot_streams[slot]):
+            st = p.stream_of(slot)
+            with torch.cuda.stream(torch.cuda.ExternalStream(st)):
                 gather.run(rec_views[slot] if nccl else rec_views[slot].cpu(), slot)
+            p.hold(slot, st)                           # the gather reads the slot's records: its next pass waits for it
         return slot
 
     def step(p=pipe):

@@ -226,7 +226,16 @@ SMHV_API int smhv_debug_lsd_classic(int on);
  *            after_stream (optional): a stream whose already enqueued work (e.g. the producer of d_frames) must finish
  *            first.  *slot receives the slot index.
  *   wait   : host waits for the slot's most recent submission.
- *   slot   : the slot's batch object (results, device pointers, images) and stream (to order a consumer after it). */
+ *   slot   : the slot's batch object (results, device pointers, images) and the stream its most recent record kernel ran
+ *            on (to order a consumer, e.g. an RCCL gather, after it).
+ *   hold   : a consumer reads the slot's outputs on `stream` (work already enqueued there): the slot's next submission
+ *            is ordered behind it.
+ * CU partition (MI355X: 256 CUs in 8 XCDs): with depth >= 2 the streaming kernels (button test, the fused map / quadrant
+ * pass: HBM-bound) and the line-segment search (LDS-latency-bound, one 146 KB workgroup per CU) do not overlap well on the
+ * same CUs -- a search workgroup leaves room for one streaming wave per SIMD.  smhv_pipeline_create_partitioned gives the
+ * streaming kernels `stream_cus_of_32` CUs out of every 32 (hipExtStreamCreateWithCUMask; all passes' streaming kernels
+ * go through one stream) and the search the rest (two streams, so consecutive launches overlap).  0 = no partition.
+ * smhv_pipeline_create uses the library's default (environment SMHV_PIPELINE_STREAM_CUS overrides it). */
 typedef struct smhv_pipeline smhv_pipeline;
 SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth, smhv_pipeline **out);
 SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p);
@@ -235,6 +244,9 @@ SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_frames, uint32
 SMHV_API int smhv_pipeline_wait(smhv_pipeline *p, uint32_t slot);
 SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p);
 SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv_batch **batch, void **stream);
+SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream);
+SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
+                                              uint32_t stream_cus_of_32, smhv_pipeline **out);
 
 /* exhaustive colour-predicate check support: writes 2^24/32 words, bit (r<<16|g<<8|b) = device
  * is_any_map_marker_color(r,g,b) (vision-common/src/markers/mod.rs:40-54) */

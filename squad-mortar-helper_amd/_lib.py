@@ -93,6 +93,8 @@ SIGNATURES = {
     "smhv_batch_lsd_coop_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "smhv_batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "smhv_pipeline_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "smhv_pipeline_create_partitioned": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "smhv_pipeline_hold": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "smhv_pipeline_destroy": (None, [C.c_void_p]),
     "smhv_pipeline_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "smhv_pipeline_wait": (C.c_int, [C.c_void_p, C.c_uint32]),

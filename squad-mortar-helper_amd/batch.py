@@ -129,19 +129,32 @@ class Pipeline:
     """`depth` batches in flight on library-owned streams (smhv_pipeline_*): submit() is asynchronous and returns the slot;
     the library starts consecutive submissions half a period apart and owns every stream of the schedule."""
 
-    def __init__(self, vision, frame_w, frame_h, max_frames, depth=2):
+    def __init__(self, vision, frame_w, frame_h, max_frames, depth=2, stream_cus=None):
+        """stream_cus: CUs of every 32 reserved for the streaming kernels (None: the library default, 0: no partition)."""
         self._lib = L.load()
         self._vision = vision
         p = C.c_void_p()
-        L.check(self._lib.smhv_pipeline_create(vision._ctx, frame_w, frame_h, max_frames, depth, C.byref(p)))
+        if stream_cus is None:
+            L.check(self._lib.smhv_pipeline_create(vision._ctx, frame_w, frame_h, max_frames, depth, C.byref(p)))
+        else:
+            L.check(self._lib.smhv_pipeline_create_partitioned(vision._ctx, frame_w, frame_h, max_frames, depth, int(stream_cus), C.byref(p)))
         self._p = p
         self.depth = depth
-        self.slots, self.streams = [], []
+        self.slots = []
         for i in range(depth):
-            b, st = C.c_void_p(), C.c_void_p()
-            L.check(self._lib.smhv_pipeline_slot(self._p, i, C.byref(b), C.byref(st)))
+            b = C.c_void_p()
+            L.check(self._lib.smhv_pipeline_slot(self._p, i, C.byref(b), None))
             self.slots.append(FrameBatch(vision, frame_w, frame_h, max_frames, _handle=b))
-            self.streams.append(st.value or 0)
+
+    def stream_of(self, slot):
+        """HIP stream on which the slot's most recent record kernel runs (order consumers after it)."""
+        st = C.c_void_p()
+        L.check(self._lib.smhv_pipeline_slot(self._p, slot, None, C.byref(st)))
+        return st.value or 0
+
+    def hold(self, slot, stream):
+        """The slot's outputs are read by work already enqueued on `stream`: its next submission waits for that."""
+        L.check(self._lib.smhv_pipeline_hold(self._p, slot, C.c_void_p(stream)))
 
     def submit(self, frames_ptr, n, stages=L.STAGE_ALL, grayscale=True, max_gap=15, anchors=None, after_stream=0):
         if anchors is not None and len(anchors) < n:

@@ -86,8 +86,13 @@ struct Buffers {
 	//   [SMH_CULL_CELLS words] cell (row oy + R) * 4 + j: mask of the annulus pixels among offsets ox = -R + 32 j + [0, 32)
 	//   [(2R+1)^2 bytes, row-major] unit range of each annulus pixel: first_unit | (n_units - 1) << 6, 0xFF = every unit
 	const uint32_t *cull_tab;
+	// x/y offsets of every ray after 32 j additions of its direction, j = 0..SMH_RAY_OFF_BATCHES (float2 [3600][SMH_RAY_OFF_BATCHES + 1];
+	// built on the device with the reference's own repeated f32 addition): lets several lanes walk different 32-sample
+	// batches of ONE long ray at the same time (k_lsd_wave).  null: long rays are walked batch after batch.
+	const float *ray_off;
 	LsdCoopBufs co;
 };
+#define SMH_RAY_OFF_BATCHES 168u     // 5376 steps: longer than the diagonal of the largest supported ROI (4096 x 3300)
 
 // Sector culling table as k_build_sector_table writes it: (2R+1)^2 entries, entry (oy+R)*(2R+1) + (ox+R) = bit mask of the
 // 64-ray units that can sample the pixel at offset (ox, oy) from floor(start point) at a step in [50 - T, 50].  The host
@@ -124,6 +129,7 @@ hipError_t launch_scales_finalize(const Geom &g, const Buffers &b, uint32_t n, u
 hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s);
 hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
+hipError_t launch_build_ray_offsets(float *d_off, hipStream_t s);   // 3600 x (SMH_RAY_OFF_BATCHES + 1) float2
 size_t lsd_lds_bytes();
 // diagnostic: find_lines on the workgroup-synchronous k_lsd for every frame instead of k_lsd_wave (also SMH_LSD_CLASSIC=1)
 void lsd_set_classic(bool on);

@@ -1325,6 +1325,24 @@ hipError_t set_ray_table(const float *dx, const float *dy) {
 	return hipMemcpyToSymbol(HIP_SYMBOL(g_ray_table), host, sizeof host, 0, hipMemcpyHostToDevice);
 }
 
+// offsets of ray i at the start of batch j: exactly what `x_offset += dx` (vision-cpu/src/lib.rs:411-413) has accumulated after 32 j steps
+__global__ void k_build_ray_offsets(float *off) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= SMH_LSD_RAYS) return;
+	const float dx = __uint_as_float(g_ray_table[i].dx), dy = __uint_as_float(g_ray_table[i].dy);
+	float xo = 0.0f, yo = 0.0f;
+	float2 *o = (float2 *)off + (size_t)i * (SMH_RAY_OFF_BATCHES + 1u);
+	for (uint32_t j = 0; j <= SMH_RAY_OFF_BATCHES; ++j) {
+		o[j] = make_float2(xo, yo);
+		for (int k = 0; k < 32; ++k) { xo += dx; yo += dy; }
+	}
+}
+
+hipError_t launch_build_ray_offsets(float *d_off, hipStream_t s) {
+	hipLaunchKernelGGL(k_build_ray_offsets, dim3((SMH_LSD_RAYS + 63) / 64), dim3(64), 0, s, d_off);
+	return hipGetLastError();
+}
+
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s) {
 	static_assert(LSD_GROUPS == LSD_GROUPS_HOST && LSD_GROUPS <= 64, "sector masks are 64-bit");
 	hipLaunchKernelGGL(k_build_sector_table, dim3((SMH_SECTOR_ENTRIES + 255) / 256), dim3(256), 0, s, d_tab, T);

@@ -202,7 +202,11 @@ __device__ __forceinline__ void finalize_body(const Geom &g, const Buffers &b, u
 			ang = atan2f(ln.y0 - ln.y1, ln.x0 - ln.x1);
 		}
 		res->lines[l] = ln;
-		res->length_px[l] = len; res->angle[l] = ang;
+#ifdef SMH_LSD_PROFILE
+		if (l < 20)
+#endif
+		res->length_px[l] = len;
+		res->angle[l] = ang;
 #ifdef SMH_LSD_PROFILE
 		if (l < 20)
 #endif

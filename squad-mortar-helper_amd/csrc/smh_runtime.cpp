@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -22,6 +23,10 @@
 
 #include "smh_consts.h"
 #include "smh_kernels.h"
+
+#ifndef SMH_PIPELINE_STREAM_CUS_DEFAULT
+#define SMH_PIPELINE_STREAM_CUS_DEFAULT 0u   // CUs of every 32 reserved for the streaming kernels of a pipeline (0: none)
+#endif
 
 using namespace smh;
 
@@ -178,6 +183,7 @@ struct smhv_ctx {
 	uint32_t sector_T[SECTOR_CACHE] = {};
 	uint32_t *sector_tab[SECTOR_CACHE] = {};
 	int sector_n = 0;
+	float *d_ray_off = nullptr;         // Buffers::ray_off (built at init, rebuilt by smhv_set_ray_table)
 	std::mutex mu;                      // serialises (re)allocation only
 	// Lifetime: batches and ingest queues hold a reference, so smhv_shutdown with children still alive releases the
 	// context's own resources and marks it closed, and the object itself goes with the last child (their destroy
@@ -258,6 +264,7 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
 	bf.cull_tab = nullptr;
+	bf.ray_off = b->ctx->d_ray_off;
 	bf.frames = frames;
 	bf.ui = b->d_ui; bf.mask = b->d_mask; bf.ocr = b->d_ocr; bf.scales = b->d_scales;
 	bf.bits = b->d_bits; bf.aux = b->d_aux;
@@ -300,6 +307,9 @@ extern "C" SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out) {
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_res, sizeof(smhv_frame_result) * 4);
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_aux, sizeof(FrameAux));
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4);
+	if (he == hipSuccess) he = hipMalloc((void **)&c->d_ray_off, sizeof(float) * 2 * SMH_LSD_RAYS * (SMH_RAY_OFF_BATCHES + 1));
+	if (he == hipSuccess) he = launch_build_ray_offsets(c->d_ray_off, c->s_main);
+	if (he == hipSuccess) he = hipStreamSynchronize(c->s_main);
 	if (he != hipSuccess) {
 		smhv_shutdown(c);                                    // releases whatever was created
 		return fail(SMHV_E_HIP, "context setup failed: %s", hipGetErrorString(he));
@@ -317,6 +327,7 @@ extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
 	c->have_frame = false; c->cropped = false; c->map_open = false; c->mask_valid = false; c->scales_valid = false;
 	for (int i = 0; i < c->sector_n; ++i) (void)hipFree(c->sector_tab[i]);
 	c->sector_n = 0;
+	if (c->d_ray_off) { (void)hipFree(c->d_ray_off); c->d_ray_off = nullptr; }
 	if (c->d_frame) (void)hipFree(c->d_frame);
 	if (c->h_ocr) (void)hipHostFree(c->h_ocr);
 	if (c->h_scales) (void)hipHostFree(c->h_scales);
@@ -357,13 +368,26 @@ extern "C" SMHV_API int smhv_set_ray_table(smhv_ctx *c, const float *dx, const f
 	HIPCHK(hipSetDevice(c->device));
 	HIPCHK(hipDeviceSynchronize());                           // no k_lsd launch may be reading the table
 	HIPCHK(set_ray_table(dx, dy));
+	HIPCHK(launch_build_ray_offsets(c->d_ray_off, c->s_main));   // note: other contexts on this device keep their (now stale) tables: call it on each
+	HIPCHK(hipStreamSynchronize(c->s_main));
 	return SMHV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // batch objects
 // ------------------------------------------------------------------------------------------------
+static hipError_t create_stream(hipStream_t *st, const uint32_t *cu_mask) {
+	// (hipExtStreamCreateWithCUMask streams are non-blocking with respect to the null stream as well)
+	return cu_mask ? hipExtStreamCreateWithCUMask(st, 8, cu_mask) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
+static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, const uint32_t *lsd_cu_mask, smhv_batch **out);
+
 extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, smhv_batch **out) {
+	return batch_create_impl(c, W, H, max_frames, nullptr, out);
+}
+
+static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, const uint32_t *lsd_cu_mask, smhv_batch **out) {
 	if (!c || !out || max_frames == 0) return fail(SMHV_E_INVALID, "bad arguments");
 	*out = nullptr;
 	CTX_OPEN(c);
@@ -400,8 +424,8 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 		// Only for frame sizes that need them: a process has few hardware queues, and every extra stream makes it more
 		// likely that two independent branches share one (measured: 10 % off the pipelined 1080p throughput).
 		if (max_frames > 1 && !lsd_rows_only(b->g)) {
-			if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->lsd_fork.s1, hipStreamNonBlocking);
-			if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->lsd_fork.s2, hipStreamNonBlocking);
+			if (e == hipSuccess) e = create_stream(&b->lsd_fork.s1, lsd_cu_mask);
+			if (e == hipSuccess) e = create_stream(&b->lsd_fork.s2, lsd_cu_mask);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&b->lsd_fork.fork, hipEventDisableTiming);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&b->lsd_fork.join1, hipEventDisableTiming);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&b->lsd_fork.join2, hipEventDisableTiming);
@@ -471,14 +495,15 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 	return SMHV_OK;
 }
 
-extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
-                                       const smhv_anchors *anchors, void *stream) {
+// s: the streaming kernels (button test, the fused map / quadrant pass); sl: the line-segment search and the record kernel.
+// sl == s for a plain smhv_batch_run; a pipeline with partitioned CUs passes two streams (sl waits for the streaming pass).
+static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                          const smhv_anchors *anchors, hipStream_t s, hipStream_t sl) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
 	CTX_OPEN(b->ctx);
 	if ((stages & (SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP)) == 0) return fail(SMHV_E_INVALID, "no stage selected");
 	stages &= SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP | SMHV_STAGE_EXACT_STATS | SMHV_STAGE_LSD_HELPERS;
 	HIPCHK(hipSetDevice(b->ctx->device));
-	hipStream_t s = (hipStream_t)stream;
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
 	if (stages & SMHV_STAGE_LSD_HELPERS) bf.co.ctl = (LsdCtl *)b->d_lsd_ctl;
@@ -529,18 +554,24 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	if (qflags && !mflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
 	STAGE_END(2, s);
 	HIPCHK(hipEventRecord(b->ev_map_done, s));
-	STAGE_BEGIN(3, s);
-	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, s, b->lsd_fork.s1 ? &b->lsd_fork : nullptr));
-	STAGE_END(3, s);
-	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, s));
-	STAGE_BEGIN(4, s);
-	if (scales) HIPCHK(launch_scales_finalize(g, bf, n, stages, b->d_bars, s));
-	else HIPCHK(launch_finalize(g, bf, n, stages & ~SMHV_STAGE_SCALES, s));
-	STAGE_END(4, s);
+	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
+	STAGE_BEGIN(3, sl);
+	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr));
+	STAGE_END(3, sl);
+	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
+	STAGE_BEGIN(4, sl);
+	if (scales) HIPCHK(launch_scales_finalize(g, bf, n, stages, b->d_bars, sl));
+	else HIPCHK(launch_finalize(g, bf, n, stages & ~SMHV_STAGE_SCALES, sl));
+	STAGE_END(4, sl);
 #undef STAGE_BEGIN
 #undef STAGE_END
 	if (t) b->timed_runs++;
 	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                                       const smhv_anchors *anchors, void *stream) {
+	return batch_run_impl(b, d_frames, n, stages, grayscale, max_gap, anchors, (hipStream_t)stream, (hipStream_t)stream);
 }
 
 extern "C" SMHV_API int smhv_batch_wait_map_pass(smhv_batch *b, void *stream) {
@@ -654,9 +685,16 @@ extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t
 struct smhv_pipeline {
 	smhv_ctx *ctx = nullptr;
 	uint32_t depth = 0;
+	uint32_t stream_cus = 0;            // CUs (of every 32) reserved for the streaming kernels; 0: no partition
 	std::vector<smhv_batch *> batch;
+	// no partition: stream[slot] carries the slot's whole pass.  partition: s_stream carries every pass's streaming kernels,
+	// s_lsd[k % 2] the line-segment search + record kernel of pass k (two, so that the tail of one launch overlaps the next)
 	std::vector<hipStream_t> stream;
+	hipStream_t s_stream = nullptr, s_lsd[2] = {nullptr, nullptr};
 	std::vector<hipEvent_t> done;       // end of the slot's most recent submission
+	std::vector<hipEvent_t> hold;       // smhv_pipeline_hold: a consumer of the slot's outputs on some other stream
+	std::vector<char> held;
+	std::vector<hipStream_t> last_sl;   // stream on which the slot's most recent record kernel ran
 	hipEvent_t ev_after = nullptr;
 	uint64_t submitted = 0;             // submissions so far
 	uint64_t round_start = 0;           // index of the first submission after the pipeline last ran empty
@@ -665,40 +703,67 @@ struct smhv_pipeline {
 extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (!p) return;
 	if (p->ctx) (void)hipSetDevice(p->ctx->device);
-	for (auto st : p->stream) if (st) (void)hipStreamSynchronize(st);
+	(void)hipDeviceSynchronize();
 	for (auto b : p->batch) if (b) smhv_batch_destroy(b);
 	for (auto e : p->done) if (e) (void)hipEventDestroy(e);
+	for (auto e : p->hold) if (e) (void)hipEventDestroy(e);
 	if (p->ev_after) (void)hipEventDestroy(p->ev_after);
 	for (auto st : p->stream) if (st) (void)hipStreamDestroy(st);
+	if (p->s_stream) (void)hipStreamDestroy(p->s_stream);
+	for (auto st : p->s_lsd) if (st) (void)hipStreamDestroy(st);
 	ctx_release(p->ctx);
 	delete p;
 }
 
-extern "C" SMHV_API int smhv_pipeline_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, smhv_pipeline **out) {
-	if (!c || !out || max_frames == 0 || depth == 0 || depth > 8) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..8)");
+// stream_cus: 0 = every kernel may use every CU; 1..31 = the streaming kernels get that many CUs of every 32 (of each XCD's
+// share), the line-segment search the rest (hipExtStreamCreateWithCUMask).
+static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, uint32_t stream_cus, smhv_pipeline **out) {
+	if (!c || !out || max_frames == 0 || depth == 0 || depth > 8 || stream_cus > 31) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..8, stream CUs 0..31 of 32)");
 	*out = nullptr;
 	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
+	if (depth == 1) stream_cus = 0;                           // nothing overlaps: every kernel gets the whole chip
 	smhv_pipeline *p = new (std::nothrow) smhv_pipeline();
 	if (!p) return fail(SMHV_E_INVALID, "out of host memory");
 	c->refs.fetch_add(1, std::memory_order_relaxed);
-	p->ctx = c; p->depth = depth;
-	p->batch.assign(depth, nullptr); p->stream.assign(depth, nullptr); p->done.assign(depth, nullptr);
-	// The streams are created back to back, before any other object of the pipeline: HIP deals streams onto the
-	// hardware queues in creation order, so consecutive streams never share one, whatever the host created earlier.
-	for (uint32_t i = 0; i < depth; ++i) {
-		hipError_t e = hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking);
-		if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline stream: %s", hipGetErrorString(e)); }
+	p->ctx = c; p->depth = depth; p->stream_cus = stream_cus;
+	p->batch.assign(depth, nullptr); p->done.assign(depth, nullptr); p->hold.assign(depth, nullptr); p->held.assign(depth, 0); p->last_sl.assign(depth, nullptr);
+	uint32_t m_stream[8], m_lsd[8];
+	uint32_t word = stream_cus ? ((1u << stream_cus) - 1u) : 0xFFFFFFFFu;
+	if (stream_cus) if (const char *e = getenv("SMHV_PIPELINE_STREAM_MASK")) { const uint32_t w = (uint32_t)strtoul(e, nullptr, 0); if (w && ~w) word = w; }   // diagnostic: raw per-XCD pattern
+	for (int i = 0; i < 8; ++i) { m_stream[i] = word; m_lsd[i] = ~word; }
+	hipError_t e = hipSuccess;
+	if (stream_cus) {
+		e = create_stream(&p->s_stream, m_stream);
+		if (e == hipSuccess) e = create_stream(&p->s_lsd[0], m_lsd);
+		if (e == hipSuccess) e = create_stream(&p->s_lsd[1], m_lsd);
+	} else {
+		// The streams are created back to back, before any other object of the pipeline: HIP deals streams onto the
+		// hardware queues in creation order, so consecutive streams never share one, whatever the host created earlier.
+		p->stream.assign(depth, nullptr);
+		for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking);
 	}
-	hipError_t e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
 	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
-	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline events: %s", hipGetErrorString(e)); }
+	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->hold[i], hipEventDisableTiming);
+	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline streams / events: %s", hipGetErrorString(e)); }
 	for (uint32_t i = 0; i < depth; ++i) {
-		int rc = smhv_batch_create(c, W, H, max_frames, &p->batch[i]);
+		int rc = batch_create_impl(c, W, H, max_frames, stream_cus ? m_lsd : nullptr, &p->batch[i]);
 		if (rc) { smhv_pipeline_destroy(p); return rc; }
 	}
 	*out = p;
 	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_pipeline_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, smhv_pipeline **out) {
+	// default partition: measured best on MI355X; SMHV_PIPELINE_STREAM_CUS overrides (0 = no partition)
+	uint32_t cus = SMH_PIPELINE_STREAM_CUS_DEFAULT;
+	if (const char *e = getenv("SMHV_PIPELINE_STREAM_CUS")) cus = (uint32_t)atoi(e);
+	return pipeline_create_impl(c, W, H, max_frames, depth, cus > 31 ? 0 : cus, out);
+}
+
+extern "C" SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, uint32_t stream_cus_of_32, smhv_pipeline **out) {
+	return pipeline_create_impl(c, W, H, max_frames, depth, stream_cus_of_32, out);
 }
 
 extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
@@ -710,25 +775,38 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 	// the slot's previous submission (depth submissions ago) owns its output buffers until it has finished: this is the
 	// only place the call can wait, and only when more than `depth` submissions would be in flight
 	HIPCHK(hipEventSynchronize(p->done[slot]));
-	bool idle = true;
-	for (uint32_t i = 0; i < p->depth && idle; ++i) idle = hipEventQuery(p->done[i]) == hipSuccess;
-	if (idle) p->round_start = p->submitted;
-	hipStream_t st = p->stream[slot];
+	hipStream_t st, sl;
+	if (p->stream_cus) {
+		st = p->s_stream; sl = p->s_lsd[p->submitted & 1u];
+		// (the wait above also orders the streaming stream behind the slot's previous record kernel: its event has completed)
+	} else {
+		st = sl = p->stream[slot];
+		bool idle = true;
+		for (uint32_t i = 0; i < p->depth && idle; ++i) idle = hipEventQuery(p->done[i]) == hipSuccess;
+		if (idle) p->round_start = p->submitted;
+		// Stagger: in the first round after the device ran empty, submission k starts its streaming pass when submission k-1
+		// has finished its own, so the batches run half a period apart from the outset -- the streaming pass of one underneath
+		// the line-segment search of the other -- instead of locking into streaming together and then searching together.
+		const uint64_t k = p->submitted - p->round_start;
+		if (k > 0 && k < p->depth) {
+			const uint32_t prev = (uint32_t)((p->submitted - 1) % p->depth);
+			HIPCHK(hipStreamWaitEvent(st, p->batch[prev]->ev_map_done, 0));
+		}
+	}
 	if (after_stream) {                                       // e.g. the producer of d_frames
 		HIPCHK(hipEventRecord(p->ev_after, (hipStream_t)after_stream));
 		HIPCHK(hipStreamWaitEvent(st, p->ev_after, 0));
 	}
-	// Stagger: in the first round after the device ran empty, submission k starts its streaming pass when submission k-1
-	// has finished its own, so the batches run half a period apart from the outset -- the streaming pass of one underneath
-	// the line-segment search of the other -- instead of locking into streaming together and then searching together.
-	const uint64_t k = p->submitted - p->round_start;
-	if (k > 0 && k < p->depth) {
-		const uint32_t prev = (uint32_t)((p->submitted - 1) % p->depth);
-		HIPCHK(hipStreamWaitEvent(st, p->batch[prev]->ev_map_done, 0));
+	if (p->held[slot]) {                                      // a consumer of the slot's previous outputs (smhv_pipeline_hold)
+		HIPCHK(hipStreamWaitEvent(st, p->hold[slot], 0));
+		p->held[slot] = 0;
 	}
-	int rc = smhv_batch_run(p->batch[slot], d_frames, n, stages, grayscale, max_gap, anchors, st);
+	// one batch in flight: nothing else can use the CUs of the frames that finish early, so they help the heavy frames
+	if (p->depth == 1) stages |= SMHV_STAGE_LSD_HELPERS;
+	int rc = batch_run_impl(p->batch[slot], d_frames, n, stages, grayscale, max_gap, anchors, st, sl);
 	if (rc) return rc;
-	HIPCHK(hipEventRecord(p->done[slot], st));
+	HIPCHK(hipEventRecord(p->done[slot], sl));
+	p->last_sl[slot] = sl;
 	p->submitted++;
 	if (slot_out) *slot_out = slot;
 	return SMHV_OK;
@@ -748,10 +826,19 @@ extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
 	return SMHV_OK;
 }
 
+extern "C" SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream) {
+	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_hold: bad arguments");
+	HIPCHK(hipSetDevice(p->ctx->device));
+	HIPCHK(hipEventRecord(p->hold[slot], (hipStream_t)stream));
+	p->held[slot] = 1;
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv_batch **batch, void **stream) {
 	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_slot: bad arguments");
 	if (batch) *batch = p->batch[slot];
-	if (stream) *stream = (void *)p->stream[slot];
+	// the stream on which the slot's most recent record kernel runs (what a consumer has to order itself after)
+	if (stream) *stream = (void *)(p->last_sl[slot] ? p->last_sl[slot] : (p->stream_cus ? p->s_lsd[0] : p->stream[slot]));
 	return SMHV_OK;
 }
 

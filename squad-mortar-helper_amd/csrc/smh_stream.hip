@@ -424,11 +424,32 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	const size_t row_bytes = (size_t)g.W * 4;
 
 	uint64_t P[4] = {0, 0, 0, 0}, Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
-	// rows walked: the marker dilation needs r0-1 .. r1, the OCR neighbourhood (quadrant rows only) r0-3 .. r1+2
-	int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
-	if (band_q && do_ocr) { rs = max(min(rs, max(r0 - 3, qy0)), 0); re = min(max(re, min(r1 + 2, qy0 + (int)g.qh - 1)), (int)g.rh - 1); }
+	// rows walked by the streaming loop: r0-1 .. r1, as in k_map_pass (the marker dilation's halo)
+	const int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
 	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
 	const int base = r0 - 3;                                     // row of bit 0 of every column mask
+	const bool my_q = band_q && in_q;                            // this thread has quadrant pixels in this band
+
+	// ---- the OCR neighbourhood reaches 3 rows up and 2 down: the four rows beyond the loop's halo contribute their "white"
+	// bits only, and only the threads of the quadrant's columns look at them
+	if (my_q && do_ocr) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int row = k < 2 ? r0 - 3 + k : r1 + k - 1;          // r0-3, r0-2, r1+1, r1+2
+			const int qrow = row - qy0;
+			if (qrow < 0 || qrow >= (int)g.qh || row < 0 || row >= (int)g.rh) continue;
+			if ((uint32_t)qrow + SMH_OCR_DILATE_RADIUS > g.qh) continue;             // y <= h - 3
+			const uint4 v = *(const uint4 *)(fp + (size_t)row * row_bytes);
+			const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+				const uint32_t mx = max(rr8, max(gg, bb)), mn = min(rr8, min(gg, bb));
+				const bool w = (mx == mn) && mn >= SMH_OCR_BRIGHTNESS_THRESHOLD && ((qw_ >> c) & 1u);
+				Wb[c] |= (uint64_t)(w ? 1u : 0u) << (row - base);
+			}
+		}
+	}
 
 	const uint8_t *lp = qact ? fp : fp - (size_t)q * 16;
 	uint4 nx[4];
@@ -438,6 +459,7 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	for (int r = rs; r <= re; r += 4) {
 		uint4 px[4];
 		uint32_t prehits = 0;
+		uint32_t wn[4] = {0, 0, 0, 0}, en[4] = {0, 0, 0, 0};        // white / edge flags of the 4 rows of this group, per pixel column
 #pragma unroll
 		for (int k = 0; k < 4; ++k) px[k] = nx[k];
 		if (r + 4 <= re) {
@@ -450,8 +472,10 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 			if (row > re) break;
 			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 			const bool out_row = row >= r0 && row < r1;
+			const int qrow = row - qy0;                              // quadrant row
+			const bool q_here = my_q && qrow >= 0 && qrow < (int)g.qh;
 			uint32_t lum[4] = {0, 0, 0, 0};
-			if ((do_ui && GRAY && out_row) || band_q) {
+			if ((do_ui && GRAY && out_row && qact) || q_here) {
 #pragma unroll
 				for (int c = 0; c < 4; ++c) lum[c] = luma8((pv[c] >> 16) & 255u, (pv[c] >> 8) & 255u, pv[c] & 255u);
 			}
@@ -467,15 +491,13 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 				o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
 				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
 			}
-			if (do_mask && row >= r0 - 1 && row <= r1) {
+			if (do_mask) {
 				uint32_t pre = 0;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
 				prehits |= (pre & vmask) << (4 * k);
 			}
-			const int qrow = row - qy0;                              // quadrant row
-			if (band_q && qrow >= 0 && qrow < (int)g.qh) {
-				const int bit = row - base;
+			if (q_here) {
 				const bool q_out = qrow >= qr0 && qrow < qr1;
 				const bool nb_row = (uint32_t)qrow + SMH_OCR_DILATE_RADIUS <= g.qh;   // y <= h - 3
 				uint32_t ocr_w = 0, sc_w = 0;
@@ -486,16 +508,21 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 					const bool w = (mx == mn) && mn >= SMH_OCR_BRIGHTNESS_THRESHOLD;
 					const bool e = (4u * (mx - mn) <= SMH_OCR_SIMILARITY_EDGE_THRESHOLD) && mn >= SMH_OCR_BRIGHTNESS_EDGE_THRESHOLD && !w;
 					const bool valid = (qv >> c) & 1u;
-					Wb[c] |= (uint64_t)((w && nb_row && ((qw_ >> c) & 1u)) ? 1u : 0u) << bit;
-					Eb[c] |= (uint64_t)((e && valid && q_out) ? 1u : 0u) << bit;
+					wn[c] |= ((w && nb_row && ((qw_ >> c) & 1u)) ? 1u : 0u) << k;
+					en[c] |= ((e && valid && q_out) ? 1u : 0u) << k;
 					ocr_w |= ((w && valid) ? (255u - lum[c]) : 255u) << (8 * c);
 					sc_w |= (lum[c] != 0u ? 255u : 0u) << (8 * c);
 				}
-				if (q_out && in_q) {
+				if (q_out) {
 					if (do_ocr) *(uint32_t *)(op + (size_t)qrow * g.ocr_pitch) = ocr_w;
 					if (do_scales && (uint32_t)qrow >= start_y) *(uint32_t *)(sp + (size_t)qrow * g.ocr_pitch) = sc_w;
 				}
 			}
+		}
+		if (my_q) {                                                  // the group's four rows into the column masks, one shift each
+			const int sh = r - base;
+#pragma unroll
+			for (int c = 0; c < 4; ++c) { Wb[c] |= (uint64_t)wn[c] << sh; Eb[c] |= (uint64_t)en[c] << sh; }
 		}
 		// ---- exact f32 HSV test for the pre-filter hits of this wave, one hit per lane (see k_map_pass) ----
 		if (do_mask && __any(prehits != 0u)) {

@@ -319,7 +319,8 @@ def test_fused_streaming_pass_on_threshold_frames(vision):
 
 
 def test_pipeline_object_gives_the_records_of_plain_runs(vision):
-    """smhv_pipeline_*: depth 1..4, interleaved with idle streams the host created beforehand; every submission's records
+    """smhv_pipeline_*: depth 1..4, with and without the CU partition (streaming kernels on their own CUs, the line-segment
+    search on the rest), with idle streams the host created beforehand; every submission's records
     equal those of a plain smhv_batch_run of the same frames, the slot hand-back is round robin, submit never loses a
     batch when more than `depth` are pushed back to back."""
     import torch
@@ -338,8 +339,8 @@ def test_pipeline_object_gives_the_records_of_plain_runs(vision):
     fb.close()
     assert len(set(want)) == 3
     idle = [torch.cuda.Stream() for _ in range(3)]                  # streams created before the pipeline: must not matter
-    for depth in (1, 2, 3, 4):
-        pipe = smh.Pipeline(vision, W, H, N, depth)
+    for depth, cus in ((1, None), (2, None), (3, 0), (4, None), (2, 8), (3, 12), (4, 10), (1, 8)):
+        pipe = smh.Pipeline(vision, W, H, N, depth, stream_cus=cus)
         order = [0, 1, 2, 2, 1, 0, 1, 1, 0, 2, 0, 1]
         slots = []
         for j, k in enumerate(order):
@@ -349,7 +350,7 @@ def test_pipeline_object_gives_the_records_of_plain_runs(vision):
             if j >= depth - 1:                                          # the oldest submission still in flight
                 s_old, k_old, j_old = slots[j - (depth - 1)]
                 pipe.wait(s_old)
-                assert bytes(pipe.slots[s_old].read_results(0, N)) == want[k_old], (depth, j_old)
+                assert bytes(pipe.slots[s_old].read_results(0, N)) == want[k_old], (depth, cus, j_old)
         pipe.wait()
         # a producer stream: the frames are written on another stream right before the submission
         prod = torch.cuda.Stream()

@@ -10,6 +10,7 @@ host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
 _, infos = synth.make_batch(W, H, N, out=host.numpy())
 d = host.cuda()
 v = smh.HipVision.init(0)
+smh._lib.load().smhv_debug_lsd_classic(0)
 fb = smh.FrameBatch(v, W, H, N)
 fb.enable_timing(True)
 for _ in range(3):
@@ -24,6 +25,9 @@ rounds = np.array([raw[i].rounds for i in range(N)])
 tot = P[:, 7].sum()
 print("share of wave-cycles: " + ", ".join("%s %.1f%%" % (names[k], 100 * P[:, k].sum() / tot) for k in range(7)))
 print("per frame: units cast %.1f, candidates set up %.1f, skipped at retire %.1f, rounds %.1f" % (D[:, 0].mean(), D[:, 1].mean(), D[:, 2].mean(), rounds.mean()))
+L = np.array([[raw[i].length_px[28 + k] for k in range(4)] for i in range(N)])
+print("dispatch->retire latency: accepted %.3g cycles (%.1f per frame), rejected %.3g cycles (%.1f per frame)" % (
+    L[:, 0].sum() / max(L[:, 1].sum(), 1), L[:, 1].mean(), L[:, 2].sum() / max(L[:, 3].sum(), 1), L[:, 3].mean()))
 ft = P[:, 7] / 16
 print("frame cycles (wave total / 16): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
 for i in np.argsort(-ft)[:4]:
