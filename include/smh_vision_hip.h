@@ -248,6 +248,24 @@ SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream);
 SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
                                               uint32_t stream_cus_of_32, smhv_pipeline **out);
 
+/* ---- node: every GPU of a machine from ONE process -------------------------------------------
+ * Frames are independent: a global batch is block-sharded over the devices (smhv_shard_range), each device runs the
+ * single-GPU pipeline on its resident shard, and the only exchange is one ncclGather (RCCL over xGMI, rccl.h:745) of the
+ * per-frame result records to devices[0].  RCCL is dlopen'ed by smhv_node_create (SMHV_E_NO_DEVICE if it is absent).
+ *   run    : asynchronous; d_frames[i] = n[i] resident frames on devices[i] (n[i] <= max_frames_per_device, may be 0),
+ *            anchors[i] (optional) the shard's anchors.
+ *   gather : all records of the most recent run in device order (sum of n[i]) into `out`; synchronises.
+ *   ctx    : the per-device context / pipeline (for uploads, images, device pointers). */
+typedef struct smhv_node smhv_node;
+SMHV_API void smhv_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
+SMHV_API int smhv_node_create(const int *devices, uint32_t n_devices, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames_per_device,
+                              uint32_t depth, smhv_log_fn log, smhv_node **out);
+SMHV_API void smhv_node_destroy(smhv_node *node);
+SMHV_API int smhv_node_ctx(smhv_node *node, uint32_t i, smhv_ctx **ctx, smhv_pipeline **pipe);
+SMHV_API int smhv_node_run(smhv_node *node, const void *const *d_frames, const uint32_t *n, uint32_t stages, int grayscale, uint32_t max_gap,
+                           const smhv_anchors *const *anchors);
+SMHV_API int smhv_node_gather(smhv_node *node, smhv_frame_result *out, uint32_t *n_total);
+
 /* exhaustive colour-predicate check support: writes 2^24/32 words, bit (r<<16|g<<8|b) = device
  * is_any_map_marker_color(r,g,b) (vision-common/src/markers/mod.rs:40-54) */
 SMHV_API int smhv_debug_marker_table(smhv_ctx *ctx, uint32_t *bits);

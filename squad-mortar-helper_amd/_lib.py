@@ -100,6 +100,12 @@ SIGNATURES = {
     "smhv_pipeline_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "smhv_pipeline_wait_all": (C.c_int, [C.c_void_p]),
     "smhv_pipeline_slot": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "smhv_shard_range": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "smhv_node_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, LOG_FN, C.POINTER(C.c_void_p)]),
+    "smhv_node_destroy": (None, [C.c_void_p]),
+    "smhv_node_ctx": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "smhv_node_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "smhv_node_gather": (C.c_int, [C.c_void_p, C.POINTER(FrameResult), C.POINTER(C.c_uint32)]),
     "smhv_debug_lsd_classic": (C.c_int, [C.c_int]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),

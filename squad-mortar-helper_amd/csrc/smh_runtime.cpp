@@ -45,6 +45,17 @@ static int fail(int code, const char *fmt, ...) {
 	return code;
 }
 
+// (for the other host translation units of the library)
+extern "C" int smhv_internal_fail(int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	t_last_error = buf;
+	return code;
+}
+
 #define HIPCHK(expr)                                                                                          \
 	do {                                                                                                      \
 		hipError_t _e = (expr);                                                                               \

@@ -382,6 +382,47 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(vision):
     assert out["config"]["frames_per_step"] == 64 and out["scaling"] == "weak"
 
 
+def test_node_entry_points_on_one_gpu(vision):
+    """smhv_node_*: the single-process multi-GPU driver (ncclCommInitAll + one ncclGather of the records to the root) on the
+    one GPU this box has: world = 1 communicator, gathered records == the pipeline's own, several runs, a short shard."""
+    import ctypes as C
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    lib = smh._lib.load()
+    W, H, N = 1920, 1080, 20
+    frames, infos = synth.make_batch(W, H, N, first_idx=12000)
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
+    want = bytes(fb.read_results(0, N))
+    fb.close()
+    node = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    smh._lib.check(lib.smhv_node_create(devs, 1, W, H, N, 2, smh._lib.LOG_FN(), C.byref(node)))
+    try:
+        sz = C.sizeof(smh._lib.FrameResult)
+        for n_run in (N, N, 7, N):
+            ptrs = (C.c_void_p * 1)(d.data_ptr())
+            ns = (C.c_uint32 * 1)(n_run)
+            anc = (C.c_void_p * 1)(C.cast(anchors, C.c_void_p))
+            smh._lib.check(lib.smhv_node_run(node, ptrs, ns, smh.STAGE_ALL, 1, 15, anc))
+            out = (smh._lib.FrameResult * N)()
+            tot = C.c_uint32(0)
+            smh._lib.check(lib.smhv_node_gather(node, out, C.byref(tot)))
+            assert tot.value == n_run and bytes(out)[:n_run * sz] == want[:n_run * sz]
+    finally:
+        lib.smhv_node_destroy(node)
+    lo, hi = C.c_uint64(), C.c_uint64()
+    covered = []
+    for r in range(8):
+        lib.smhv_shard_range(8192 + 5, r, 8, C.byref(lo), C.byref(hi))
+        covered.append((lo.value, hi.value))
+    assert covered[0][0] == 0 and covered[-1][1] == 8197 and all(covered[i][1] == covered[i + 1][0] for i in range(7))
+    assert max(h - l for l, h in covered) - min(h - l for l, h in covered) <= 1
+
+
 def test_lsd_helpers_do_not_change_any_record(vision):
     """SMHV_STAGE_LSD_HELPERS: workgroups that have finished their frame ray-cast candidates for the frames still being
     searched.  Ray casting is a pure function of (mask, pixel), so every record must stay byte-identical -- on a batch
