@@ -2,7 +2,7 @@
 # tools/profile_round.sh <tag> -- run ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence
 # behind bench.py's roofline object for the current build and writes the summaries that get
 # committed under profiles/ into gpurun_out/<tag>_*.
-#   kernel stats  : rocprofv3 --kernel-trace --stats   (depth 1 and depth 2)
+#   kernel stats  : rocprofv3 --kernel-trace --stats   (depth 1 and depth 2; config 2 and config 3)
 #   HBM traffic   : rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes, never combined
 #                   with any other trace domain (MI355X_MICROARCH.md, HBM section)
 set -u
@@ -11,12 +11,17 @@ R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-stream-tuning"   # profiled runs: only warm-up, timed and isolated launches
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_d1 -- $B --steps 10 --warmup 2 --pipeline-depth 1 > $OUT/${TAG}_bench_profiled_d1.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_d2 -- $B --steps 10 --warmup 2 > $OUT/${TAG}_bench_profiled_d2.json 2>/dev/null
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_fetch -- $B --steps 2 --warmup 1 --pipeline-depth 1 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_write -- $B --steps 2 --warmup 1 --pipeline-depth 1 > /dev/null 2>&1
+B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1"   # profiled runs: only warm-up, timed and isolated passes
+for C in 2 3; do
+  P=""; [ $C = 3 ] && P="c3_"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${P}d1 -- $B --config $C --steps 3 --warmup 1 --pipeline-depth 1 > $OUT/${TAG}_${P}bench_profiled_d1.json 2>/dev/null
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${P}d2 -- $B --config $C --steps 3 --warmup 1 > $OUT/${TAG}_${P}bench_profiled_d2.json 2>/dev/null
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_${P}fetch -- $B --config $C --steps 1 --warmup 1 --rounds-per-step 2 --pipeline-depth 1 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_${P}write -- $B --config $C --steps 1 --warmup 1 --rounds-per-step 2 --pipeline-depth 1 > /dev/null 2>&1
+done
 cd $R
-timeout 600 python bench.py --pipeline-depth 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench_depth1.json
-timeout 600 python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
-python tools/pmc_summary.py "$TAG"
+python tools/pmc_summary.py "$TAG" c2
+python tools/pmc_summary.py "$TAG" c3
+cp $OUT/traffic.json profiles/traffic.json 2>/dev/null
+for C in 1 2 3; do timeout 600 python bench.py --config $C 2>/dev/null | tail -1 > $OUT/${TAG}_bench_config$C.json; done
+timeout 600 python bench.py --pipeline-depth 1 --cpu-sample 0 --ingest-frames 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_depth1.json
