@@ -444,7 +444,11 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 			}
 		}
 		const bool fin = valid && status != RAY_CONTINUE;
-		if (fin && !exact && status == RAY_LEFT_IMAGE) { ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye); exact = true; }
+		// find_lines (always_exact == false): a ray whose gap starts at step K >= 50 gets its exact end point right here, and
+		// the second pass below is not needed -- a ray with K <= 49 is shorter than 50 px (it ends K - 1 unit steps from the
+		// start, +-0.25), so it never wins in a candidate find_lines keeps (len^2 > 2500, lsd.rs:94), and for one it rejects
+		// nobody asks which ray was the longest.  Vision::find_longest_line still takes the second pass (exact shorter rays).
+		if (fin && !exact && (status == RAY_LEFT_IMAGE || (!always_exact && s.gk0 + s.gj > SMH_LSD_REJECT_K))) { ray_endpoint(m, status, s, xs, ys, dx, dy, xe, ye); exact = true; }
 		// exactly evaluated rays (rare) compete right away
 		if (__any(fin && exact)) {
 			unsigned long long key = 0;
@@ -513,8 +517,8 @@ __device__ void ray_engine(const Win &m, LsdShared &sh, uint32_t *queue, uint32_
 	__syncthreads();
 	PROF_MARK(4);
 
-	// ---- pass 2: exact end points for the units that can still hold the winner ----
-	if (fast_gap) {
+	// ---- pass 2 (Vision::find_longest_line only): exact end points for the units that can still hold the winner ----
+	if (fast_gap && always_exact) {
 		for (uint32_t p2 = wave; p2 < nlive; p2 += LSD_NW) {
 			const uint32_t u2 = sh.ulist[p2], c = u2 / LSD_GROUPS;
 			const uint32_t kbar = sh.cand_kmax[c];
@@ -659,7 +663,7 @@ __device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uin
 		const uint32_t pitch = v.wwords, gp = g.bits_pitch_w;          // odd LDS pitch: consecutive rows fall on different banks
 		// [2 pad words][row y_min-1 = zeros][rows y_min..y_max, shifted right by xoff bits][row y_max+1 = zeros][2 pad words]
 		const uint32_t total = (wrows + 2u) * pitch + 4u;
-		for (uint32_t idx = tid; idx < total; idx += LSD_BS) {
+		for (uint32_t idx = tid; idx < total; idx += blockDim.x) {
 			uint32_t val = 0;
 			if (idx >= 2u + pitch && idx < 2u + (wrows + 1u) * pitch) {
 				const uint32_t k = idx - 2u - pitch, r = k / pitch, c = k - r * pitch;
@@ -685,7 +689,7 @@ __device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uin
 		m.y_lo = (int)wy0 - 1; m.rows_hi = wrows + 1u;
 		m.xbias = (int)g.m_xoff - 32 * ((int)ww0 - 1); m.cols_hi = wwords + 1u;
 		const uint32_t total = (wrows + 2u) * pitch;
-		for (uint32_t idx = tid; idx < total; idx += LSD_BS) {
+		for (uint32_t idx = tid; idx < total; idx += blockDim.x) {
 			const uint32_t r = idx / pitch, c = idx - r * pitch;
 			uint32_t val = 0;
 			if (r >= 1u && r <= wrows && c >= 1u && c <= wwords) val = gbits[(size_t)(wy0 + r - 1u) * g.bits_pitch_w + ww0 + c - 1u];
@@ -1136,24 +1140,27 @@ __device__ void lsd_help(const Geom &g, const Buffers &b, uint32_t n_frames, flo
 // once (launch_lsd runs them side by side, or only the ROWS one when the frame size guarantees it).  Split this way
 // the common ROWS kernel carries no call to the rarely used variants: 113 VGPRs and no scratch, where a kernel
 // holding all three needed 128 and spilled at its call sites.
-__device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux) {
+__device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux, uint32_t cap = LSD_WIN_WORDS_CAP) {
 	int lmode = LSD_MODE_GLOBAL;                           // also the empty-mask single-round case
 	if (aux.n_mask_px != 0) {
 		const uint32_t wrows = aux.y_max - aux.y_min + 1u, wwords = aux.w_max - aux.w_min + 1u;
-		if ((wrows + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_ROWS;
-		else if ((wrows + 2u) * ((wwords + 2u) | 1u) <= LSD_WIN_WORDS_CAP) lmode = LSD_MODE_XWIN;
+		if ((wrows + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= cap) lmode = LSD_MODE_ROWS;
+		else if ((wrows + 2u) * ((wwords + 2u) | 1u) <= cap) lmode = LSD_MODE_XWIN;
 	}
 	return lmode;
 }
 
 // grid = n_frames owner workgroups (+ extra workgroups that only help, for batches smaller than the chip)
-template <int MODE>
+// COOP: the instantiation with the helper machinery (SMHV_STAGE_LSD_HELPERS); the plain one carries none of it (its
+// second copy of the ray engine costs the register allocator of the hot loops dearly: 40 -> 676 bytes of scratch in the
+// global-memory mode)
+template <int MODE, bool COOP>
 __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy, uint32_t n_frames) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ LsdShared sh;
 	__shared__ uint32_t cull_tab[SMH_CULL_TAB_WORDS];
 	const uint32_t f = blockIdx.x;
-	const bool coop = mode == 0 && b.co.ctl != nullptr;
+	const bool coop = COOP && mode == 0 && b.co.ctl != nullptr;
 	bool have_tab = false;
 	if (f < n_frames) {
 		if (coop && threadIdx.x == 0) __hip_atomic_fetch_add(&b.co.ctl->started[MODE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1172,9 +1179,9 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 		if (mine) {
 			const bool cull = mode == 0 && b.cull_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
 			if (cull) { for (uint32_t i = threadIdx.x; i < SMH_CULL_TAB_WORDS; i += LSD_BS) cull_tab[i] = b.cull_tab[i]; have_tab = true; }   // visible after the barrier in frame_setup
-			lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh, cull_tab, coop ? &b.co.coop[f] : nullptr);
+			lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh, cull_tab, (COOP && coop) ? &b.co.coop[f] : nullptr);
 		}
-		if (!coop) return;
+		if (!COOP || !coop) return;
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			if (mine) { st_relaxed(&b.co.coop[f].remaining, 0u); st_release(&b.co.coop[f].done, 1u); }
@@ -1190,7 +1197,7 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 	} else if (!coop) {
 		return;
 	}
-	lsd_help<MODE>(g, b, n_frames, max_gap, smem, sh, cull_tab, have_tab);
+	if (COOP) lsd_help<MODE>(g, b, n_frames, max_gap, smem, sh, cull_tab, have_tab);
 }
 
 #include "smh_lsd_wave.inc"
@@ -1261,9 +1268,10 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	hipError_t e0 = hipGetDevice(&dev);
 	if (e0 != hipSuccess) return e0;
 	if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
-		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
-		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd<LSD_MODE_GLOBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+		hipError_t e = hipSuccess;
+		const void *fns[] = {(const void *)k_lsd<LSD_MODE_ROWS, false>, (const void *)k_lsd<LSD_MODE_XWIN, false>, (const void *)k_lsd<LSD_MODE_GLOBAL, false>,
+		                     (const void *)k_lsd<LSD_MODE_ROWS, true>, (const void *)k_lsd<LSD_MODE_XWIN, true>, (const void *)k_lsd<LSD_MODE_GLOBAL, true>};
+		for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_wave<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_DYN_LDS_BYTES);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_wave<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_DYN_LDS_BYTES);
 		if (e != hipSuccess) return e;
@@ -1300,12 +1308,21 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	// task-based k_lsd_wave (SMH_LSD_WAVE=1); Vision::find_longest_line, the global-memory mask mode and the helper workgroups
 	// are k_lsd only.
 	const bool wave = mode == 0 && !coop && !lsd_classic_flag().load(std::memory_order_relaxed);
-	if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_ROWS>, dim3(n), dim3(LSD_BS), W_DYN_LDS_BYTES, s, g, b, max_gap);
-	else hipLaunchKernelGGL(k_lsd<LSD_MODE_ROWS>, dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
+	// diagnostic knobs of k_lsd_wave: threads per workgroup and the LDS mask window (words); a smaller window lets several
+	// workgroups share a CU (only sound for frames whose window fits: experiments on small frames)
+	static const uint32_t w_bs = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= LSD_BS && v % 64 == 0) ? (uint32_t)v : (uint32_t)LSD_BS; }();
+	static const uint32_t w_cap = [] { const char *e = getenv("SMH_W_CAP"); const int v = e ? atoi(e) : 0; return (v >= 1024 && v <= (int)LSD_WIN_WORDS_CAP) ? (uint32_t)v : (uint32_t)LSD_WIN_WORDS_CAP; }();
+	const uint32_t w_cap_eff = ((g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= w_cap) ? w_cap : (uint32_t)LSD_WIN_WORDS_CAP;
+	const unsigned w_lds = (w_cap_eff + 2u * LSD_LIST_CAP) * 4u;
+	if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_ROWS>, dim3(n), dim3(w_bs), w_lds, s, g, b, max_gap, w_cap_eff);
+	else if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, true>), dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
+	else hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, false>), dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	if (!rows_only) {
-		if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), W_DYN_LDS_BYTES, s1, g, b, max_gap);
-		else hipLaunchKernelGGL(k_lsd<LSD_MODE_XWIN>, dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
-		hipLaunchKernelGGL(k_lsd<LSD_MODE_GLOBAL>, dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py, n);
+		if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_XWIN>, dim3(n), dim3(w_bs), w_lds, s1, g, b, max_gap, w_cap_eff);
+		else if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_XWIN, true>), dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
+		else hipLaunchKernelGGL((k_lsd<LSD_MODE_XWIN, false>), dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
+		if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_GLOBAL, true>), dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py, n);
+		else hipLaunchKernelGGL((k_lsd<LSD_MODE_GLOBAL, false>), dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py, n);
 		if (fk) {
 			hipError_t e = hipEventRecord(fk->join1, s1);
 			if (e == hipSuccess) e = hipEventRecord(fk->join2, s2);
