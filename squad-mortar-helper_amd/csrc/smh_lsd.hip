@@ -77,6 +77,7 @@ __device__ RayDir g_ray_table[SMH_LSD_RAYS] = {
 // 0 without a branch.  In the global-memory fallback (box larger than LDS) it is the whole mask.
 typedef __attribute__((address_space(3))) uint32_t LdsWord;
 typedef __attribute__((address_space(3))) char LdsByte;
+typedef __attribute__((address_space(3))) unsigned char LdsU8;
 
 struct Win {
 	const uint32_t *p;
@@ -93,6 +94,13 @@ struct Win {
 	// the long rays of phase B ever fall through to global memory.  c_rows == 0: no cache.
 	const LdsWord *c_p;               // explicitly an LDS pointer: its reads must stay ds_read, apart from the global ones
 	uint32_t c_y0, c_rows, c_pitch4;
+	// LSD_MODE_TILE only: the mask as 32 x 8 px tiles.  t_idx points at the entry of tile (0, 0) of a byte table with
+	// t_pitch entries per tile row (two columns of padding on either side, one row above and below): 0 = an empty tile,
+	// k = tile k of t_tiles (8 words, one per row; tile 0 is all zeros).
+	const LdsU8 *t_idx;
+	const LdsWord *t_tiles;
+	uint32_t t_pitch;
+	bool tiled;
 };
 
 // Mask residency modes of k_lsd, chosen per frame from the bounding box of the set bits:
@@ -103,7 +111,10 @@ struct Win {
 //   XWIN   bounding box (+ zero border) in LDS, coordinates clamped into it (narrow, tall boxes)
 //   GLOBAL the whole bit-packed mask in global memory (box larger than LDS: 1440p, 4K), with a sliding cache of as
 //          many whole rows as LDS holds around the candidates in flight (they come in raster order)
-enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2 };
+//   TILE   (k_lsd_tile only) the non-empty 32 x 8 px tiles of the mask plus a byte index over the whole ROI: a marker
+//          mask is a few thin lines, 1-4 % of its tiles hold a set bit, so a frame takes 15-25 KB of LDS instead of
+//          110 KB and several frames share a CU.  One more dependent LDS read per sample.
+enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2, LSD_MODE_TILE = 3 };
 
 // One sample.  Coordinates below/left of the window wrap to huge unsigned values and clamp to the far
 // (zero) border just like coordinates beyond it, so each axis costs one v_min_u32.  24-bit multiply:
@@ -119,12 +130,28 @@ __device__ __forceinline__ uint32_t win_raw(const Win &m, int xi, int yi) {   //
 	else word = *(const uint32_t *)((const char *)m.p + __umul24(ry, m.pitch4) + (rc << 2));
 	return word >> ((uint32_t)X & 31u);
 }
+// LSD_MODE_TILE: word `wq` (pixels 32 wq .. 32 wq + 31) of image row yi; -2 <= wq < t_pitch - 2, -8 <= yi < 8 (tile rows + 1)
+__device__ __forceinline__ uint32_t tile_word(const Win &m, int wq, int yi) {
+	const uint32_t t = m.t_idx[__mul24(yi >> 3, (int)m.t_pitch) + wq];
+	return m.t_tiles[(t << 3) + ((uint32_t)yi & 7u)];
+}
+// LSD_MODE_TILE sample straight from the float position (bit 0 = the pixel): rows clamped onto the zero rows -1 and h in
+// the float domain; x needs no clamp (a batch never strays more than 33 px from the image: two padding columns)
+__device__ __forceinline__ uint32_t tile_raw(const Win &m, float x, float y) {
+	const int yi = (int)__builtin_amdgcn_fmed3f(y, -1.0f, m.hf);
+	const int xi = (int)x;
+	return tile_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u);
+}
 // (not on the hot path: the cache test is a run-time one here)
-__device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) { return (m.c_rows ? win_raw<true>(m, xi, yi) : win_raw<false>(m, xi, yi)) & 1u; }
+__device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) {
+	if (m.tiled) return (tile_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u)) & 1u;      // callers pass in-image coordinates
+	return (m.c_rows ? win_raw<true>(m, xi, yi) : win_raw<false>(m, xi, yi)) & 1u;
+}
 
 // The 32 mask bits of word `wq` (in the view's own bit coordinate B = x + xbias) of image row yi; 0 outside the
 // window / image.  Works for all three residency modes (ROWS: xbias = 0).
 __device__ __forceinline__ uint32_t win_word(const Win &m, int wq, int yi) {
+	if (m.tiled) return ((uint32_t)yi < m.h && (uint32_t)(wq + 2) < m.t_pitch) ? tile_word(m, wq, yi) : 0u;
 	const uint32_t ry = (uint32_t)(yi - m.y_lo), rc = (uint32_t)wq;
 	uint32_t v = 0;
 	if (ry <= m.rows_hi && rc <= m.cols_hi) {
@@ -202,6 +229,7 @@ __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float
 			x = xo + xs; y = yo + ys;                   // x = x_offset + x_start
 			// shifts in bit 0 of its first operand
 			if (MODE == LSD_MODE_ROWS) Wm = __builtin_amdgcn_alignbit(win_raw_rows(m, x, y), Wm, 1);
+			else if (MODE == LSD_MODE_TILE) Wm = __builtin_amdgcn_alignbit(tile_raw(m, x, y), Wm, 1);
 			else Wm = __builtin_amdgcn_alignbit(win_raw<MODE == LSD_MODE_GLOBAL>(m, (int)x, (int)y), Wm, 1);
 			xo += dx; yo += dy;                         // x_offset += dx
 		}
@@ -656,6 +684,7 @@ __device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uin
 	m.w = g.rw; m.h = g.rh; m.wf = (float)g.rw; m.hf = (float)g.rh;
 	m.rows0 = nullptr; m.ylo_f = 0.0f; m.yhi_f = 0.0f;
 	m.c_p = (const LdsWord *)smem; m.c_y0 = 0u; m.c_rows = 0u; m.c_pitch4 = 0u;
+	m.t_idx = nullptr; m.t_tiles = nullptr; m.t_pitch = 0u; m.tiled = false;
 	v.c_pitch = g.bits_pitch_w | 1u; v.c_cap_rows = min(g.rh, LSD_WIN_WORDS_CAP / v.c_pitch);
 	if (MODE == LSD_MODE_ROWS) {
 		const uint32_t wy0 = aux.y_min, wrows = aux.y_max - aux.y_min + 1u;
@@ -1156,6 +1185,9 @@ __device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux, 
 // global-memory mode)
 template <int MODE, bool COOP>
 __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy, uint32_t n_frames) {
+#ifdef SMH_LSD_PRIO
+	__builtin_amdgcn_s_setprio(SMH_LSD_PRIO);
+#endif
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ LsdShared sh;
 	__shared__ uint32_t cull_tab[SMH_CULL_TAB_WORDS];
@@ -1314,6 +1346,15 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	static const uint32_t w_cap = [] { const char *e = getenv("SMH_W_CAP"); const int v = e ? atoi(e) : 0; return (v >= 1024 && v <= (int)LSD_WIN_WORDS_CAP) ? (uint32_t)v : (uint32_t)LSD_WIN_WORDS_CAP; }();
 	const uint32_t w_cap_eff = ((g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= w_cap) ? w_cap : (uint32_t)LSD_WIN_WORDS_CAP;
 	const unsigned w_lds = (w_cap_eff + 2u * LSD_LIST_CAP) * 4u;
+	static const bool tile_env = [] { const char *e = getenv("SMH_LSD_TILE"); return e && e[0] == '1'; }();
+	static const uint32_t t_cap = [] { const char *e = getenv("SMH_T_CAP"); const int v = e ? atoi(e) : 0; return (v >= 8 && v <= 255) ? (uint32_t)v : 255u; }();
+	if (mode == 0 && !coop && tile_env) {
+		const uint32_t bs = std::min<uint32_t>(w_bs, LSD_TILE_BS);
+		const unsigned t_lds = (tile_mask_words(g.rw, g.rh, t_cap) + 2u * LSD_LIST_CAP) * 4u;
+		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, t_cap);
+		hipLaunchKernelGGL(k_lsd_wave_global, dim3(n), dim3(bs), 2u * LSD_LIST_CAP * 4u, s, g, b, max_gap);
+		return hipGetLastError();
+	}
 	if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_ROWS>, dim3(n), dim3(w_bs), w_lds, s, g, b, max_gap, w_cap_eff);
 	else if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, true>), dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	else hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, false>), dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);

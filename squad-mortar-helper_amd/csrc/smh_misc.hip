@@ -206,6 +206,9 @@ __device__ __forceinline__ void finalize_body(const Geom &g, const Buffers &b, u
 		if (l < 20)
 #endif
 		res->length_px[l] = len;
+#ifdef SMH_LSD_PROFILE
+		if (l < 16)
+#endif
 		res->angle[l] = ang;
 #ifdef SMH_LSD_PROFILE
 		if (l < 20)

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_ope
 		FrameAux a;
 		a.open = (force_open || !(ratio < SMH_BUTTON_RED_PIXEL_THRESHOLD)) ? 1u : 0u;
 		a.red = red; a.n_mask_px = 0;
-		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.pad = 0;
+		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.tile_overflow = 0;
 		b.aux[f] = a;
 	}
 }
@@ -380,6 +380,44 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 // ------------------------------------------------------------------------------------------------
 #define MAPQ_RB_MAX 58
 
+// ---- small pieces of the fused pass ----
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// A 16-byte load the compiler does not track (uniform row base + 32-bit lane offset) and the wait that releases a set of four
+// of them: the streaming loop of k_map_brq_pass places its own waits (see there).  Nothing may read a destination before
+// SMH_WAIT_SET has named it; tools/check_untracked_loads.py checks the compiled code for that.
+#define SMH_LD128(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+// stores in the same addressing form (a per-lane 64-bit pointer per output would cost the loop six registers it does not have)
+#define SMH_ST128(voff, data, sbase) asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff), "v"(data), "s"(sbase) : "memory")
+#define SMH_ST32(voff, data, sbase) asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(data), "s"(sbase) : "memory")
+#define SMH_WAIT_SET(n, X) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"((X)[0]), "+v"((X)[1]), "+v"((X)[2]), "+v"((X)[3]) : : "memory")
+// image 0.23.14 rgb_to_luma of a BGRA dword, without luma8()'s clamp: the f32 sum is at most 255.0 (r = g = b = 255; the
+// sum is monotonic in every channel), so the truncation cannot exceed 255.
+__device__ __forceinline__ uint32_t luma_bgra(uint32_t p) {
+	const float l = SMH_LUMA_R * (float)((p >> 16) & 255u) + SMH_LUMA_G * (float)((p >> 8) & 255u) + SMH_LUMA_B * (float)(p & 255u);
+	return (uint32_t)l;
+}
+// Necessary condition of marker_prefilter for four pixels at once: some colour channel is >= 178 (bit 7 set and the low
+// seven bits >= 50; bytes are tested in place, the alpha byte is masked out).  Terrain darker than that -- most of a map
+// -- skips the per-pixel test altogether.
+__device__ __forceinline__ uint32_t bright4(const uint32_t pv[4]) {
+	uint32_t acc = 0;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) acc |= ((pv[c] & 0x007F7F7Fu) + 0x004E4E4Eu) & pv[c];
+	return acc & 0x00808080u;
+}
+// bytes of 0x00 / 0x01 -> bytes of 0x00 / 0xFF: as a v_perm_b32 selector, 0x0C yields the constant 0x00 and 0x0D the constant
+// 0xFF (the compiler turns (x << 8) - x back into a full-width multiply by 255, four times the issue cost)
+__device__ __forceinline__ uint32_t ones_to_bytes(uint32_t ones) { return __builtin_amdgcn_perm(0u, 0u, ones + 0x0C0C0C0Cu); }
+// 4 flag bits -> 4 bytes of 0x00 / 0xFF
+__device__ __forceinline__ uint32_t nib_to_bytes(uint32_t nib) {
+	return ones_to_bytes((nib * 0x00204081u) & 0x01010101u);
+}
+// rows k = 0..3 of a group as nibbles (bit 4k + c = pixel column c of row k) -> bits 0..3 of column c
+__device__ __forceinline__ uint32_t rows_of_col(uint32_t nibbles, int c) {
+	const uint32_t y = (nibbles >> c) & 0x1111u;
+	return (y | (y >> 3) | (y >> 6) | (y >> 9)) & 0xFu;
+}
+
 template <bool GRAY>
 __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start) {
 	const uint32_t f = blockIdx.y;
@@ -417,10 +455,14 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	const int qr0 = max(r0 - qy0, 0), qr1 = min(r1 - qy0, (int)g.qh);     // quadrant rows this band writes: [qr0, qr1)
 	const bool band_q = qr1 > qr0 && (do_ocr || do_scales);               // uniform: the band touches the quadrant
 
-	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax + 4 * q) * 4;
-	uint8_t *uip = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
-	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
-	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
+	// addresses: a uniform 64-bit base per row plus a 32-bit lane offset (inactive lanes re-read quad 0: no divergent load)
+	const uint8_t *fbase = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax) * 4;
+	const uint32_t loff = qact ? q * 16u : 0u;
+	const uint8_t *fp = fbase + (size_t)q * 16;                  // (patch loop below)
+	uint8_t *uibase = b.ui + (size_t)f * g.ui_stride;
+	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride;
+	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride;
+	const uint32_t qoff = (uint32_t)(in_q ? qq : 0) * 4u;
 	const size_t row_bytes = (size_t)g.W * 4;
 
 	uint64_t P[4] = {0, 0, 0, 0}, Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
@@ -451,21 +493,11 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 		}
 	}
 
-	const uint8_t *lp = qact ? fp : fp - (size_t)q * 16;
-	uint4 nx[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(rs + k, re) * row_bytes);
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_hits[];
-	for (int r = rs; r <= re; r += 4) {
-		uint4 px[4];
-		uint32_t prehits = 0;
-		uint32_t wn[4] = {0, 0, 0, 0}, en[4] = {0, 0, 0, 0};        // white / edge flags of the 4 rows of this group, per pixel column
-#pragma unroll
-		for (int k = 0; k < 4; ++k) px[k] = nx[k];
-		if (r + 4 <= re) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) nx[k] = *(const uint4 *)(lp + (size_t)min(r + 4 + k, re) * row_bytes);
-		}
+	// One group = four rows r .. r+3 held in px.  Everything that depends on the row only (band membership, quadrant
+	// membership) is a uniform branch; lanes outside the ROI / the quadrant compute along and are masked at the end.
+	auto group = [&](const u32x4 (&px)[4], int r) {
+		uint32_t prehits = 0, wrows = 0, erows = 0;                // bit 4k + c: pixel column c of row r + k
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const int row = r + k;
@@ -473,56 +505,62 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 			const bool out_row = row >= r0 && row < r1;
 			const int qrow = row - qy0;                              // quadrant row
-			const bool q_here = my_q && qrow >= 0 && qrow < (int)g.qh;
-			uint32_t lum[4] = {0, 0, 0, 0};
-			if ((do_ui && GRAY && out_row && qact) || q_here) {
-#pragma unroll
-				for (int c = 0; c < 4; ++c) lum[c] = luma8((pv[c] >> 16) & 255u, (pv[c] >> 8) & 255u, pv[c] & 255u);
-			}
-			if (do_ui && out_row && qact) {
-				uint4 o;
-				uint32_t ov[4];
-#pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
-					if (GRAY) ov[c] = lum[c] * 0x00010101u | 0xFF000000u;                  // Bgra::to_luma -> (l,l,l,255)
-					else ov[c] = rr8 | (gg << 8) | (bb << 16) | 0xFF000000u;               // (r,g,b,255)
-				}
-				o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
-				*(uint4 *)(uip + (size_t)row * g.ui_pitch) = o;
-			}
-			if (do_mask) {
-				uint32_t pre = 0;
-#pragma unroll
-				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
-				prehits |= (pre & vmask) << (4 * k);
-			}
-			if (q_here) {
-				const bool q_out = qrow >= qr0 && qrow < qr1;
-				const bool nb_row = (uint32_t)qrow + SMH_OCR_DILATE_RADIUS <= g.qh;   // y <= h - 3
-				uint32_t ocr_w = 0, sc_w = 0;
+			const bool q_row = band_q && qrow >= 0 && qrow < (int)g.qh;   // uniform
+			uint32_t wnib = 0, enib = 0;                             // white / edge pixels of this row (quadrant rows only)
+			if (q_row) {
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
 					const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
 					const uint32_t mx = max(rr8, max(gg, bb)), mn = min(rr8, min(gg, bb));
 					const bool w = (mx == mn) && mn >= SMH_OCR_BRIGHTNESS_THRESHOLD;
 					const bool e = (4u * (mx - mn) <= SMH_OCR_SIMILARITY_EDGE_THRESHOLD) && mn >= SMH_OCR_BRIGHTNESS_EDGE_THRESHOLD && !w;
-					const bool valid = (qv >> c) & 1u;
-					wn[c] |= ((w && nb_row && ((qw_ >> c) & 1u)) ? 1u : 0u) << k;
-					en[c] |= ((e && valid && q_out) ? 1u : 0u) << k;
-					ocr_w |= ((w && valid) ? (255u - lum[c]) : 255u) << (8 * c);
-					sc_w |= (lum[c] != 0u ? 255u : 0u) << (8 * c);
+					wnib |= (w ? 1u : 0u) << c;
+					enib |= (e ? 1u : 0u) << c;
 				}
-				if (q_out) {
-					if (do_ocr) *(uint32_t *)(op + (size_t)qrow * g.ocr_pitch) = ocr_w;
-					if (do_scales && (uint32_t)qrow >= start_y) *(uint32_t *)(sp + (size_t)qrow * g.ocr_pitch) = sc_w;
+				const bool nb_row = (uint32_t)qrow + SMH_OCR_DILATE_RADIUS <= g.qh;   // y <= h - 3
+				if (nb_row) wrows |= (wnib & qw_) << (4 * k);
+				if (out_row) erows |= (enib & qv) << (4 * k);           // (a band row inside the quadrant is a row this band writes)
+			}
+			if (out_row) {
+				uint32_t lum[4] = {0, 0, 0, 0};
+				if (GRAY || q_row) {
+#pragma unroll
+					for (int c = 0; c < 4; ++c) lum[c] = luma_bgra(pv[c]);
+				}
+				if (do_ui && qact) {
+					u32x4 o;
+					uint32_t ov[4];
+#pragma unroll
+					for (int c = 0; c < 4; ++c) {
+						const uint32_t p = pv[c], bb = p & 255u, gg = (p >> 8) & 255u, rr8 = (p >> 16) & 255u;
+						if (GRAY) ov[c] = __builtin_amdgcn_perm(0u, lum[c], 0x0D000000u);       // Bgra::to_luma -> (l,l,l,255): bytes 0..2 = l, byte 3 = 0xFF
+						else ov[c] = rr8 | (gg << 8) | (bb << 16) | 0xFF000000u;               // (r,g,b,255)
+					}
+					o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
+					SMH_ST128(loff, o, uibase + (size_t)row * g.ui_pitch);                   // (an active quad's lane offset is q * 16)
+				}
+				if (q_row && in_q) {
+					// ocr_preprocess keeps a white pixel as 255 - luma and blanks the rest (edge pixels are patched at the end);
+					// find_scales_preprocess is luma != 0.  Four pixels at a time on the packed luma bytes.
+					const uint32_t l4 = lum[0] | (lum[1] << 8) | (lum[2] << 16) | (lum[3] << 24);
+					if (do_ocr) SMH_ST32(qoff, ~(l4 & nib_to_bytes(wnib & qv)), op + (size_t)qrow * g.ocr_pitch);
+					if (do_scales && (uint32_t)qrow >= start_y) {
+						const uint32_t nz = ((((l4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | l4) >> 7) & 0x01010101u;     // bytes != 0
+						SMH_ST32(qoff, ones_to_bytes(nz), sp + (size_t)qrow * g.ocr_pitch);
+					}
 				}
 			}
+			if (do_mask && __any(bright4(pv) != 0u)) {
+				uint32_t pre = 0;
+#pragma unroll
+				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
+				prehits |= (pre & vmask) << (4 * k);
+			}
 		}
-		if (my_q) {                                                  // the group's four rows into the column masks, one shift each
+		if (band_q && __any((wrows | erows) != 0u)) {                // the group's four rows into the column masks
 			const int sh = r - base;
 #pragma unroll
-			for (int c = 0; c < 4; ++c) { Wb[c] |= (uint64_t)wn[c] << sh; Eb[c] |= (uint64_t)en[c] << sh; }
+			for (int c = 0; c < 4; ++c) { Wb[c] |= (uint64_t)rows_of_col(wrows, c) << sh; Eb[c] |= (uint64_t)rows_of_col(erows, c) << sh; }
 		}
 		// ---- exact f32 HSV test for the pre-filter hits of this wave, one hit per lane (see k_map_pass) ----
 		if (do_mask && __any(prehits != 0u)) {
@@ -562,14 +600,44 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 			if (res) {
 				const int sh = r - base;
 #pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					uint32_t y = (res >> c) & 0x1111u;                 // rows k = 0..3 at bits 0,4,8,12
-					y = (y | (y >> 3) | (y >> 6) | (y >> 9)) & 0xFu;   // -> bits 0..3
-					P[c] |= (uint64_t)y << sh;
-				}
+				for (int c = 0; c < 4; ++c) P[c] |= (uint64_t)rows_of_col(res, c) << sh;
 			}
 		}
+	};
+
+	// Software pipeline, three register sets, prefetch distance two groups: the loads of set n are issued before group n - 2
+	// is processed, so two groups' worth of loads (8 KB per wave) are in flight while a group is processed, and the wait for
+	// set n is "at most the eight younger loads outstanding".  vmcnt counts stores too and a store's acknowledgement can
+	// overtake an older load (measured: crediting the stores issued since, which an in-order counter would allow, hands out
+	// stale pixels), so the wait also covers the stores of the two groups before -- two groups old by then, and cheaper
+	// than what the compiler makes of tracked loads here: its waits assume the fewest stores any path could have issued,
+	// none, and every group then waits for the stores of the group right before it.  0.49 -> 0.44 ms per 256 frames.
+	// Rows beyond the band's last are clamped onto it (always four loads per set, the count stays static; the extra loads
+	// hit the same cache lines).
+	auto load4 = [&](u32x4 (&dst)[4], int r) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { const uint8_t *rowp = fbase + (size_t)min(r + k, re) * row_bytes; SMH_LD128(dst[k], loff, rowp); }
+	};
+	u32x4 S0[4], S1[4], S2[4];
+	load4(S0, rs);
+	load4(S1, rs + 4);
+	for (int r = rs; ; r += 12) {
+		load4(S2, r + 8);
+		SMH_WAIT_SET(8, S0);
+		group(S0, r);
+		if (r + 4 > re) break;
+		load4(S0, r + 12);
+		SMH_WAIT_SET(8, S1);
+		group(S1, r + 4);
+		if (r + 8 > re) break;
+		load4(S1, r + 16);
+		SMH_WAIT_SET(8, S2);
+		group(S2, r + 8);
+		if (r + 12 > re) break;
 	}
+	// the clamped loads of the sets nobody consumed are still in flight: their registers must not be reused before they land
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(S1[0]), "+v"(S1[1]), "+v"(S1[2]), "+v"(S1[3]),
+	             "+v"(S2[0]), "+v"(S2[1]), "+v"(S2[2]), "+v"(S2[3]) : : "memory");
 
 	// ---- lane / wave neighbours of the column masks: marker dilation (P) and the 7-row-dilated white masks (V) ----
 	uint64_t V[4];
@@ -599,18 +667,27 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 		for (int c = 0; c < 4; ++c) D[c] = ((vmask >> c) & 1u) ? (D[c] & rowmask) : 0ull;
 		const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
 		if (q < quads_padded) {
-			uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
-			uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
-			for (int row = r0; row < r1; ++row) {
-				const int bit = row - base;
-				const uint32_t nib = (uint32_t)((D[0] >> bit) & 1ull) | ((uint32_t)((D[1] >> bit) & 1ull) << 1) |
-				                     ((uint32_t)((D[2] >> bit) & 1ull) << 2) | ((uint32_t)((D[3] >> bit) & 1ull) << 3);
-				*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;
-				uint32_t v = nib;
-				v |= __shfl_down(v, 1) << 4;
-				v |= __shfl_down(v, 2) << 8;
-				v |= __shfl_down(v, 4) << 16;
-				if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
+			// u8 mask rows and bit-packed rows.  The column masks are walked one 32-row half at a time (32-bit bit-field
+			// extracts on a uniform bit index); eight lanes' nibbles meet in one dword through three DPP row shifts
+			// (lane l supplies bits 4 (l % 8) ..): no LDS round trip, nothing to wait for.
+			uint8_t *mbase = b.mask + (size_t)f * g.mask_stride;
+			uint32_t *bbase = b.bits + (size_t)f * g.bits_stride_w;
+			const uint32_t moff = q * 4u, boff = (q >> 3) * 4u;
+			const bool bit_lane = (lane & 7u) == 0;
+#pragma unroll
+			for (int half = 0; half < 2; ++half) {
+				const uint32_t d0 = (uint32_t)(D[0] >> (32 * half)), d1 = (uint32_t)(D[1] >> (32 * half)), d2 = (uint32_t)(D[2] >> (32 * half)), d3 = (uint32_t)(D[3] >> (32 * half));
+				const int row_lo = max(r0, base + 32 * half), row_hi = min(r1, base + 32 * half + 32);
+				for (int row = row_lo; row < row_hi; ++row) {
+					const uint32_t bit = (uint32_t)(row - base) & 31u;
+					const uint32_t nib = ((d0 >> bit) & 1u) | (((d1 >> bit) & 1u) << 1) | (((d2 >> bit) & 1u) << 2) | (((d3 >> bit) & 1u) << 3);
+					*(uint32_t *)(mbase + (size_t)row * g.mask_pitch + moff) = nib_to_bytes(nib);
+					uint32_t v = nib;
+					v |= SMH_DPP(v, 0x101) << 4;                    // row_shl:1 -- lane l reads lane l + 1 (0 beyond the 16-lane row)
+					v |= SMH_DPP(v, 0x102) << 8;
+					v |= SMH_DPP(v, 0x104) << 16;
+					if (bit_lane) *(uint32_t *)((uint8_t *)bbase + (size_t)row * g.bits_pitch_w * 4u + boff) = v;
+				}
 			}
 		}
 		const uint64_t any = D[0] | D[1] | D[2] | D[3];
@@ -650,8 +727,8 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 			kk &= kk - 1;
 			const int row = base + bit;
 			const uint32_t p = *(const uint32_t *)(fp + (size_t)row * row_bytes + 4 * c);
-			const uint32_t l = luma8((p >> 16) & 255u, (p >> 8) & 255u, p & 255u);
-			op[(size_t)(row - qy0) * g.ocr_pitch + c] = (uint8_t)(255u - l);
+			const uint32_t l = luma_bgra(p);
+			op[(size_t)(row - qy0) * g.ocr_pitch + qoff + c] = (uint8_t)(255u - l);
 		}
 	}
 }

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Static check of k_map_brq_pass's hand-placed waits (squad-mortar-helper_amd/csrc/smh_stream.hip).
+
+The streaming loop issues its pixel loads through inline asm (SMH_LD128), which the compiler does not track: it will not
+wait for them, and it is free to copy or spill their destination registers like any other value.  A copy made while the
+load is still in flight would copy garbage.  This script compiles the translation unit, takes the kernel's ISA and checks,
+for each of the three register sets, that no instruction touches the set between the loads that fill it and the
+`s_waitcnt vmcnt(8)` that releases it (the loop is cyclic: a set reloaded late in the body is released early in the next
+trip), and that the kernel uses no scratch.  Exit code 0 = fine.  Run after any change to that kernel or to the compiler.
+"""
+import os, re, subprocess, sys, tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "..", "squad-mortar-helper_amd", "csrc", "smh_stream.hip")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+         "-fno-fast-math", "-fno-slp-vectorize"]
+
+
+def regs_in(text):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if m.group(1):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def check_kernel(name, lines):
+    code = [l.split(";")[0].rstrip() for l in lines]
+    loads = [(i, regs_in(code[i].split(",")[0])) for i in range(len(code)) if re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[", code[i])]
+    waits = [i for i in range(len(code)) if re.search(r"s_waitcnt vmcnt\(8\)", code[i])]
+    errors = []
+    if len(loads) != 20 or len(waits) != 3:
+        return ["%s: expected 20 untracked loads (2 sets before the loop, 3 in it) and 3 waits, found %d and %d" % (name, len(loads), len(waits))]
+    sets = [(min(i for i, _ in loads[k:k + 4]), max(i for i, _ in loads[k:k + 4]), set().union(*[r for _, r in loads[k:k + 4]])) for k in range(0, 20, 4)]
+    pro0, pro1, in2, in0, in1 = sets
+    if pro0[2] != in0[2] or pro1[2] != in1[2]:
+        errors.append("%s: a set is reloaded into other registers than it was first loaded into" % name)
+    if not (in2[0] < waits[0] < in0[0] < waits[1] < in1[0] < waits[2]):
+        errors.append("%s: loads and waits are not in the expected order" % name)
+    # loop body in layout order: from the header label before the first in-loop load to the last branch back to it
+    hdr = max(i for i in range(in2[0]) if re.match(r"\.LBB\d+_\d+:", code[i]) and "Loop Header" in lines[i])
+    label = code[hdr].split(":")[0]
+    back = max(i for i in range(len(code)) if re.search(r"s_cbranch\w*\s+%s\b|s_branch\s+%s\b" % (re.escape(label), re.escape(label)), code[i]))
+
+    def scan(lo, hi, regs, what):
+        for i in range(lo, hi):
+            c = code[i].strip()
+            if not c or c.startswith(".") or c.endswith(":"):
+                continue
+            if regs & regs_in(c):
+                errors.append("%s: line %d touches a register of %s while its loads are in flight: %s" % (name, i + 1, what, c))
+
+    scan(pro0[1] + 1, waits[0], pro0[2], "set 0 (first fill)")
+    scan(pro1[1] + 1, waits[1], pro1[2], "set 1 (first fill)")
+    scan(in2[1] + 1, waits[2], in2[2], "set 2")
+    scan(in0[1] + 1, back + 1, in0[2], "set 0 (refill, rest of the trip)")
+    scan(in1[1] + 1, back + 1, in1[2], "set 1 (refill, rest of the trip)")
+    # start of the next trip: up to the wait that releases the set (the in-loop loads of set 2 sit in that range and must not alias)
+    scan(hdr, waits[0], in0[2], "set 0 (refill, start of the next trip)")
+    scan(hdr, waits[1], in1[2], "set 1 (refill, start of the next trip)")
+    return errors
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-x", "hip", os.path.realpath(SRC), "-c", "--save-temps", "-o", "out.o"], cwd=tmp, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        asm = [f for f in os.listdir(tmp) if f.endswith(".s") and "gfx950" in f]
+        text = open(os.path.join(tmp, asm[0])).read().split("\n")
+    errors, found = [], 0
+    i = 0
+    while i < len(text):
+        m = re.match(r"(_ZN3smh14k_map_brq_passILb[01]E\w*):", text[i])
+        if m:
+            j = next(k for k in range(i, len(text)) if "s_endpgm" in text[k])
+            found += 1
+            errors += check_kernel(m.group(1)[:40], text[i:j + 1])
+            i = j
+        i += 1
+    meta = "\n".join(text)
+    for km in re.finditer(r"\.name:\s+(_ZN3smh14k_map_brq_pass\w+)\s*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s*(\d+)", meta):
+        if int(km.group(2)) != 0:
+            errors.append("%s uses %s bytes of scratch: a spilled load destination would be spilled before its data has arrived" % (km.group(1)[:40], km.group(2)))
+    if found != 2:
+        errors.append("expected two instantiations of k_map_brq_pass, found %d" % found)
+    for e in errors:
+        print("FAIL:", e)
+    print("k_map_brq_pass: %d instantiations checked, %d problems" % (found, len(errors)))
+    return 1 if errors else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

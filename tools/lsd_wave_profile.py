@@ -24,11 +24,14 @@ D = np.array([[raw[i].meters[28 + k] for k in range(4)] for i in range(N)])
 rounds = np.array([raw[i].rounds for i in range(N)])
 tot = P[:, 7].sum()
 print("share of wave-cycles: " + ", ".join("%s %.1f%%" % (names[k], 100 * P[:, k].sum() / tot) for k in range(7)))
+U = np.array([[raw[i].angle[16 + k] for k in range(4)] for i in range(N)], dtype=np.float64)
+print("inside unit (share of wave-cycles): first batches %.1f%%, long rays %.1f%%, end points %.1f%%, merge %.1f%%" % tuple(100 * U[:, k].sum() / tot for k in range(4)))
 print("per frame: units cast %.1f, candidates set up %.1f, skipped at retire %.1f, rounds %.1f" % (D[:, 0].mean(), D[:, 1].mean(), D[:, 2].mean(), rounds.mean()))
 L = np.array([[raw[i].length_px[28 + k] for k in range(4)] for i in range(N)])
 print("dispatch->retire latency: accepted %.3g cycles (%.1f per frame), rejected %.3g cycles (%.1f per frame)" % (
     L[:, 0].sum() / max(L[:, 1].sum(), 1), L[:, 1].mean(), L[:, 2].sum() / max(L[:, 3].sum(), 1), L[:, 3].mean()))
-ft = P[:, 7] / 16
-print("frame cycles (wave total / 16): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
+NWV = int(os.environ.get('SMH_W_BS', '1024')) // 64
+ft = P[:, 7] / NWV
+print("frame cycles (wave total / waves): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
 for i in np.argsort(-ft)[:4]:
     print("  frame %d rounds %d units %d cands %d: %.3g cycles; shares %s" % (i, rounds[i], D[i, 0], D[i, 1], ft[i], ["%.0f%%" % (100 * P[i, k] / P[i, 7]) for k in range(7)]))
