@@ -13,7 +13,7 @@ inside the timed step.
 
 One "step" = --rounds-per-step passes of the hot path over the resident batch (default 8, so that the default 20-step
 region lasts ~0.1 s instead of 15 ms); `value` counts every frame of every pass.  The passes go through
-smhv_pipeline_submit: the library owns the streams and the schedule (--pipeline-depth batches in flight, default 2);
+smhv_pipeline_submit: the library owns the streams and the schedule (--pipeline-depth batches in flight, default 4);
 `value_depth1` is the same workload with ONE batch in flight, timed right after the main region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--stages", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
-    ap.add_argument("--pipeline-depth", type=int, default=2, help="batches in flight (smhv_pipeline_create depth)")
+    ap.add_argument("--pipeline-depth", type=int, default=4, help="batches in flight (smhv_pipeline_create depth)")
     ap.add_argument("--stream-cus", type=int, default=None,
                     help="CUs of every 32 reserved for the streaming kernels (smhv_pipeline_create_partitioned); default: the library's choice")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")

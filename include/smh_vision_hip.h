@@ -212,11 +212,16 @@ SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
 SMHV_API int smhv_batch_lsd_coop_stats(smhv_batch *b, uint32_t first, uint32_t n, uint32_t *out);
 SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
 
-/* diagnostic (process-wide): find_lines has two kernels -- the workgroup-synchronous k_lsd (on != 0; the default) and the
- * task-based k_lsd_wave (on == 0, or SMH_LSD_WAVE=1 in the environment): waves of a frame's workgroup claim 64-ray units of
- * the oldest candidate in flight, candidates retire in order through a reorder buffer.  Both produce the reference's
- * results bit for bit; the tests run every fuzz scene through both. */
+/* diagnostic (process-wide): find_lines has two kernels -- the task-based k_lsd_tile (on == 0; the default: waves of a frame's
+ * workgroup claim 64-ray units of the oldest candidate in flight, candidates retire in order through a reorder buffer; the mask
+ * sits in LDS as a sparse store of 32 x 8 px tiles) and the workgroup-synchronous k_lsd (on != 0, or SMH_LSD_KERNEL=classic in
+ * the environment; always used for Vision::find_longest_line and for batches run with SMHV_STAGE_LSD_HELPERS).  Both produce
+ * the reference's results bit for bit; the tests run every fuzz scene through both. */
 SMHV_API int smhv_debug_lsd_classic(int on);
+/* diagnostic (process-wide): k_lsd_tile keeps at most `cap` non-empty mask tiles of a frame in LDS (0 = as many as fit: 1023 up
+ * to 1440p, 541 at 4K; a marker scene has 40-260); a frame with more is searched on the mask in global memory by a second
+ * kernel.  The tests lower the cap to run frames through that path. */
+SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
 /* ---- pipeline: several batches in flight, scheduled by the library ----------------------------------------------
  * `depth` output buffer sets (smhv_batch objects) of max_frames frames, each with its own stream.  The streams are
  * created by the library, in a fixed order, and consecutive submissions are started half a period apart, so the

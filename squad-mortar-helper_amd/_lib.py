@@ -107,6 +107,7 @@ SIGNATURES = {
     "smhv_node_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]),
     "smhv_node_gather": (C.c_int, [C.c_void_p, C.POINTER(FrameResult), C.POINTER(C.c_uint32)]),
     "smhv_debug_lsd_classic": (C.c_int, [C.c_int]),
+    "smhv_debug_lsd_tile_cap": (C.c_int, [C.c_uint32]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "smhv_ingest_destroy": (None, [C.c_void_p]),

@@ -119,7 +119,11 @@ struct LsdFork { hipStream_t s1, s2; hipEvent_t fork, join1, join2; };
 bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame: find_lines launches one kernel
 // mode 0: find_lines (whole frame); mode 1: one find_longest_line round from (px,py), result in results[f].lines[0], len^2 in length_px[0]
 // b.co (if present) is zeroed on `s` before the launch; extra_helpers: additional workgroups that only help (small batches).
-hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk);
+// find_lines runs on k_lsd_tile unless the buffers carry the helper scheme (b.co), prefer_classic is set (the schedule knows
+// better: smhv_pipeline at depth 2 on frames up to 1080p) or the process-wide diagnostic switch is.
+// tile_bs: threads per workgroup of k_lsd_tile (0: 512, the pipelined default; a batch that runs alone takes 1024)
+hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs = 0,
+                      bool prefer_classic = false);
 size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocation, zeroed per launch)
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);
@@ -131,8 +135,10 @@ hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
 hipError_t launch_build_ray_offsets(float *d_off, hipStream_t s);   // 3600 x (SMH_RAY_OFF_BATCHES + 1) float2
 size_t lsd_lds_bytes();
-// diagnostic: find_lines on the workgroup-synchronous k_lsd for every frame instead of k_lsd_wave (also SMH_LSD_CLASSIC=1)
+// diagnostic: find_lines on the workgroup-synchronous k_lsd for every frame instead of k_lsd_tile (also SMH_LSD_KERNEL=classic)
 void lsd_set_classic(bool on);
+// diagnostic: cap the tile store of k_lsd_tile (0 = what fits), to exercise the path of frames with more tiles than that
+void lsd_set_tile_cap(uint32_t cap);
 // overwrite the 3600 ray directions of the current device's code object (synchronous)
 hipError_t set_ray_table(const float *dx, const float *dy);
 // CRC-32 of n_dwords 32-bit words at d_msg, xor-ed into *d_acc (zero it first) WITHOUT the init / final-xor terms:

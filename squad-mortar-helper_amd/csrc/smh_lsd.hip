@@ -77,7 +77,7 @@ __device__ RayDir g_ray_table[SMH_LSD_RAYS] = {
 // 0 without a branch.  In the global-memory fallback (box larger than LDS) it is the whole mask.
 typedef __attribute__((address_space(3))) uint32_t LdsWord;
 typedef __attribute__((address_space(3))) char LdsByte;
-typedef __attribute__((address_space(3))) unsigned char LdsU8;
+typedef __attribute__((address_space(3))) unsigned short LdsU16;
 
 struct Win {
 	const uint32_t *p;
@@ -94,10 +94,10 @@ struct Win {
 	// the long rays of phase B ever fall through to global memory.  c_rows == 0: no cache.
 	const LdsWord *c_p;               // explicitly an LDS pointer: its reads must stay ds_read, apart from the global ones
 	uint32_t c_y0, c_rows, c_pitch4;
-	// LSD_MODE_TILE only: the mask as 32 x 8 px tiles.  t_idx points at the entry of tile (0, 0) of a byte table with
+	// LSD_MODE_TILE only: the mask as 32 x 8 px tiles.  t_idx points at the entry of tile (0, 0) of a 16-bit table with
 	// t_pitch entries per tile row (two columns of padding on either side, one row above and below): 0 = an empty tile,
 	// k = tile k of t_tiles (8 words, one per row; tile 0 is all zeros).
-	const LdsU8 *t_idx;
+	const LdsU16 *t_idx;
 	const LdsWord *t_tiles;
 	uint32_t t_pitch;
 	bool tiled;
@@ -111,9 +111,10 @@ struct Win {
 //   XWIN   bounding box (+ zero border) in LDS, coordinates clamped into it (narrow, tall boxes)
 //   GLOBAL the whole bit-packed mask in global memory (box larger than LDS: 1440p, 4K), with a sliding cache of as
 //          many whole rows as LDS holds around the candidates in flight (they come in raster order)
-//   TILE   (k_lsd_tile only) the non-empty 32 x 8 px tiles of the mask plus a byte index over the whole ROI: a marker
-//          mask is a few thin lines, 1-4 % of its tiles hold a set bit, so a frame takes 15-25 KB of LDS instead of
-//          110 KB and several frames share a CU.  One more dependent LDS read per sample.
+//   TILE   (k_lsd_tile only) the non-empty 32 x 8 px tiles of the mask plus a 16-bit index over the whole ROI: a marker
+//          mask is a few thin lines, 1-4 % of its tiles hold a set bit, so a frame of ANY size takes 20-50 KB of LDS
+//          instead of 110 KB (1080p) or not fitting at all (1440p, 4K), and two frames share a CU.  One more dependent
+//          LDS read per sample.
 enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2, LSD_MODE_TILE = 3 };
 
 // One sample.  Coordinates below/left of the window wrap to huge unsigned values and clamp to the far
@@ -1283,16 +1284,17 @@ __global__ void k_build_sector_table(unsigned long long *tab, uint32_t T) {
 size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 
 static std::atomic<bool> &lsd_classic_flag() {
-	// default: the workgroup-synchronous kernel (it co-exists better with the streaming passes of a pipelined second batch);
-	// SMH_LSD_WAVE=1 or smhv_debug_lsd_classic(0) selects k_lsd_wave
-	static std::atomic<bool> flag{[] { const char *e = getenv("SMH_LSD_WAVE"); return !(e && e[0] == '1'); }()};
+	// default: k_lsd_tile; SMH_LSD_KERNEL=classic or smhv_debug_lsd_classic(1) selects the workgroup-synchronous k_lsd
+	static std::atomic<bool> flag{[] { const char *e = getenv("SMH_LSD_KERNEL"); return e && strcmp(e, "classic") == 0; }()};
 	return flag;
 }
 void lsd_set_classic(bool on) { lsd_classic_flag().store(on, std::memory_order_relaxed); }
+static std::atomic<uint32_t> g_tile_cap_override{0};
+void lsd_set_tile_cap(uint32_t cap) { g_tile_cap_override.store(cap, std::memory_order_relaxed); }
 
 bool lsd_rows_only(const Geom &g) { return (g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP; }
 
-hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk) {
+hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs, bool prefer_classic) {
 	const unsigned lds_full = LSD_DYN_LDS_BYTES;
 	// more than 64 KB of dynamic LDS has to be allowed per function and per device
 	static std::atomic<uint64_t> attr_devices{0};
@@ -1304,14 +1306,26 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		const void *fns[] = {(const void *)k_lsd<LSD_MODE_ROWS, false>, (const void *)k_lsd<LSD_MODE_XWIN, false>, (const void *)k_lsd<LSD_MODE_GLOBAL, false>,
 		                     (const void *)k_lsd<LSD_MODE_ROWS, true>, (const void *)k_lsd<LSD_MODE_XWIN, true>, (const void *)k_lsd<LSD_MODE_GLOBAL, true>};
 		for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
-		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_wave<LSD_MODE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_DYN_LDS_BYTES);
-		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_wave<LSD_MODE_XWIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_DYN_LDS_BYTES);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSD_TILE_DYN_LDS_MAX);
 		if (e != hipSuccess) return e;
 		if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 	}
 	// every non-empty frame of this size is a ROWS frame (lsd_mode_for): the other two kernels would only exit
 	const bool rows_only = mode == 0 && lsd_rows_only(g);
 	const bool coop = mode == 0 && b.co.ctl != nullptr;
+	// find_lines has two implementations: the task-based k_lsd_tile (default: any frame size, two frames per CU) and the
+	// workgroup-synchronous k_lsd (with helper workgroups when the batch asks for them, for Vision::find_longest_line, and
+	// on request: smhv_debug_lsd_classic / SMH_LSD_KERNEL=classic).
+	if (mode == 0 && !coop && !prefer_classic && !lsd_classic_flag().load(std::memory_order_relaxed)) {
+		static const uint32_t bs_env = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= LSD_TILE_BS && v % 64 == 0) ? (uint32_t)v : 0u; }();
+		const uint32_t bs = bs_env ? bs_env : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u);
+		const uint32_t cap_o = g_tile_cap_override.load(std::memory_order_relaxed);
+		const uint32_t cap = cap_o ? std::min(cap_o, tile_cap_for(g)) : tile_cap_for(g);
+		const unsigned t_lds = (tile_mask_words(g.rw, g.rh, cap) + 2u * LSD_LIST_CAP) * 4u;
+		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap);
+		hipLaunchKernelGGL(k_lsd_wave_global, dim3(n), dim3(bs), 2u * LSD_LIST_CAP * 4u, s, g, b, max_gap);   // frames with more tiles than that (never seen)
+		return hipGetLastError();
+	}
 	if (coop) {
 		hipError_t e = hipMemsetAsync(b.co.ctl, 0, lsd_coop_ctl_bytes(n), s);
 		if (e != hipSuccess) return e;
@@ -1336,31 +1350,10 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		if (e != hipSuccess) return e;
 		s1 = fk->s1; s2 = fk->s2;
 	}
-	// find_lines has two implementations for the LDS-resident mask modes: the workgroup-synchronous k_lsd (default) and the
-	// task-based k_lsd_wave (SMH_LSD_WAVE=1); Vision::find_longest_line, the global-memory mask mode and the helper workgroups
-	// are k_lsd only.
-	const bool wave = mode == 0 && !coop && !lsd_classic_flag().load(std::memory_order_relaxed);
-	// diagnostic knobs of k_lsd_wave: threads per workgroup and the LDS mask window (words); a smaller window lets several
-	// workgroups share a CU (only sound for frames whose window fits: experiments on small frames)
-	static const uint32_t w_bs = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= LSD_BS && v % 64 == 0) ? (uint32_t)v : (uint32_t)LSD_BS; }();
-	static const uint32_t w_cap = [] { const char *e = getenv("SMH_W_CAP"); const int v = e ? atoi(e) : 0; return (v >= 1024 && v <= (int)LSD_WIN_WORDS_CAP) ? (uint32_t)v : (uint32_t)LSD_WIN_WORDS_CAP; }();
-	const uint32_t w_cap_eff = ((g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= w_cap) ? w_cap : (uint32_t)LSD_WIN_WORDS_CAP;
-	const unsigned w_lds = (w_cap_eff + 2u * LSD_LIST_CAP) * 4u;
-	static const bool tile_env = [] { const char *e = getenv("SMH_LSD_TILE"); return e && e[0] == '1'; }();
-	static const uint32_t t_cap = [] { const char *e = getenv("SMH_T_CAP"); const int v = e ? atoi(e) : 0; return (v >= 8 && v <= 255) ? (uint32_t)v : 255u; }();
-	if (mode == 0 && !coop && tile_env) {
-		const uint32_t bs = std::min<uint32_t>(w_bs, LSD_TILE_BS);
-		const unsigned t_lds = (tile_mask_words(g.rw, g.rh, t_cap) + 2u * LSD_LIST_CAP) * 4u;
-		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, t_cap);
-		hipLaunchKernelGGL(k_lsd_wave_global, dim3(n), dim3(bs), 2u * LSD_LIST_CAP * 4u, s, g, b, max_gap);
-		return hipGetLastError();
-	}
-	if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_ROWS>, dim3(n), dim3(w_bs), w_lds, s, g, b, max_gap, w_cap_eff);
-	else if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, true>), dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
+	if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, true>), dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	else hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, false>), dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	if (!rows_only) {
-		if (wave) hipLaunchKernelGGL(k_lsd_wave<LSD_MODE_XWIN>, dim3(n), dim3(w_bs), w_lds, s1, g, b, max_gap, w_cap_eff);
-		else if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_XWIN, true>), dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
+		if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_XWIN, true>), dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
 		else hipLaunchKernelGGL((k_lsd<LSD_MODE_XWIN, false>), dim3(n), dim3(LSD_BS), lds_full, s1, g, b, max_gap, mode, px, py, n);
 		if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_GLOBAL, true>), dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py, n);
 		else hipLaunchKernelGGL((k_lsd<LSD_MODE_GLOBAL, false>), dim3(n), dim3(LSD_BS), lds_full, s2, g, b, max_gap, mode, px, py, n);

@@ -166,6 +166,10 @@ struct smhv_batch {
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// the per-mode k_lsd kernels of frames larger than 1080p run side by side (smh_kernels.h, LsdFork)
 	LsdFork lsd_fork{};
+	// threads per workgroup of the line search (k_lsd_tile): 1024 for a batch that has the chip to itself, 512 for the batches of
+	// a pipeline (two workgroups per CU, and room for the streaming pass of the other batches beside them)
+	uint32_t lsd_bs = 1024;
+	bool lsd_prefer_classic = false;      // set by smhv_pipeline_create where the workgroup-synchronous k_lsd measures faster
 };
 
 struct smhv_ctx {
@@ -364,6 +368,11 @@ extern "C" SMHV_API int smhv_thread_ctx(smhv_ctx *c) {
 
 extern "C" SMHV_API int smhv_debug_lsd_classic(int on) {
 	lsd_set_classic(on != 0);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap) {
+	lsd_set_tile_cap(cap);
 	return SMHV_OK;
 }
 
@@ -567,7 +576,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	HIPCHK(hipEventRecord(b->ev_map_done, s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	STAGE_BEGIN(3, sl);
-	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr));
+	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic));
 	STAGE_END(3, sl);
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
 	STAGE_BEGIN(4, sl);
@@ -761,6 +770,10 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 	for (uint32_t i = 0; i < depth; ++i) {
 		int rc = batch_create_impl(c, W, H, max_frames, stream_cus ? m_lsd : nullptr, &p->batch[i]);
 		if (rc) { smhv_pipeline_destroy(p); return rc; }
+		// Measured on MI355X: frames whose mask window fits the LDS (<= 1080p) -- depth 1: k_lsd with
+		// helper workgroups, depth 2: k_lsd, depth >= 3: k_lsd_tile with 512-thread workgroups; larger frames: k_lsd_tile always.
+		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
+		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
 	}
 	*out = p;
 	return SMHV_OK;
@@ -812,8 +825,11 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 		HIPCHK(hipStreamWaitEvent(st, p->hold[slot], 0));
 		p->held[slot] = 0;
 	}
-	// one batch in flight: nothing else can use the CUs of the frames that finish early, so they help the heavy frames
-	if (p->depth == 1) stages |= SMHV_STAGE_LSD_HELPERS;
+	// one batch in flight: nothing else can use the CUs of the frames that finish early, so they help the heavy frames (the
+	// helper scheme belongs to the workgroup-synchronous k_lsd and to frames whose mask window fits the LDS: <= 1080p;
+	// larger frames are better off on the tile kernel)
+	static const bool d1_tile = [] { const char *e = getenv("SMH_LSD_D1"); return e && strcmp(e, "tile") == 0; }();
+	if (p->depth == 1 && lsd_rows_only(p->batch[slot]->g) && !d1_tile) stages |= SMHV_STAGE_LSD_HELPERS;
 	int rc = batch_run_impl(p->batch[slot], d_frames, n, stages, grayscale, max_gap, anchors, st, sl);
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(p->done[slot], sl));
@@ -1065,7 +1081,7 @@ extern "C" SMHV_API int smhv_find_marker_lines(smhv_ctx *c, uint32_t max_gap, sm
 	hipStream_t s = c->s_markers;
 	rc = sector_table_for(c, max_gap, s, &bf);
 	if (rc) return rc;
-	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s, nullptr));
+	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s, nullptr, 1024u));
 	HIPCHK(launch_finalize(b->g, bf, 1, SMHV_STAGE_MARKERS, s));
 	HIPCHK(hipMemcpyAsync(&c->h_res[0], b->d_results, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
@@ -1086,7 +1102,7 @@ extern "C" SMHV_API int smhv_lsd_stats(smhv_ctx *c, uint32_t max_gap, int exact,
 		rc = sector_table_for(c, max_gap, s, &bf);
 		if (rc) return rc;
 	}
-	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s, nullptr));
+	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s, nullptr, 1024u));
 	HIPCHK(hipMemcpyAsync(&c->h_res[2], b->d_results + 2, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
 	*rounds = c->h_res[2].rounds;
