@@ -219,8 +219,8 @@ SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
  * the reference's results bit for bit; the tests run every fuzz scene through both. */
 SMHV_API int smhv_debug_lsd_classic(int on);
 /* diagnostic (process-wide): k_lsd_tile keeps at most `cap` non-empty mask tiles of a frame in LDS (0 = as many as fit: 1023 up
- * to 1440p, 541 at 4K; a marker scene has 40-260); a frame with more is searched on the mask in global memory by a second
- * kernel.  The tests lower the cap to run frames through that path. */
+ * to 1440p, 541 at 4K; a marker scene has 40-260); a frame with more is searched on the mask in global memory (slow).  The
+ * tests lower the cap to run frames through that path. */
 SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
 /* ---- pipeline: several batches in flight, scheduled by the library ----------------------------------------------
  * `depth` output buffer sets (smhv_batch objects) of max_frames frames, each with its own stream.  The streams are

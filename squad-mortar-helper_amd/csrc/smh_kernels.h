@@ -35,7 +35,7 @@ struct FrameAux {
 	uint32_t red;         // red pixel count
 	uint32_t n_mask_px;   // popcount of the dilated mask
 	uint32_t y_min, y_max, w_min, w_max;  // bounding box of set bits: rows, and words of the bit-packed rows
-	uint32_t tile_overflow;               // written by k_lsd_tile: the frame is left to k_lsd_wave_global
+	uint32_t pad;
 };
 
 // ---- cooperation between the workgroups of one k_lsd launch (smh_lsd.hip) ---------------------------------------

@@ -1186,9 +1186,6 @@ __device__ __forceinline__ int lsd_mode_for(const Geom &g, const FrameAux &aux, 
 // global-memory mode)
 template <int MODE, bool COOP>
 __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lsd(Geom g, Buffers b, float max_gap, int mode, float spx, float spy, uint32_t n_frames) {
-#ifdef SMH_LSD_PRIO
-	__builtin_amdgcn_s_setprio(SMH_LSD_PRIO);
-#endif
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	__shared__ LsdShared sh;
 	__shared__ uint32_t cull_tab[SMH_CULL_TAB_WORDS];
@@ -1323,7 +1320,6 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		const uint32_t cap = cap_o ? std::min(cap_o, tile_cap_for(g)) : tile_cap_for(g);
 		const unsigned t_lds = (tile_mask_words(g.rw, g.rh, cap) + 2u * LSD_LIST_CAP) * 4u;
 		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap);
-		hipLaunchKernelGGL(k_lsd_wave_global, dim3(n), dim3(bs), 2u * LSD_LIST_CAP * 4u, s, g, b, max_gap);   // frames with more tiles than that (never seen)
 		return hipGetLastError();
 	}
 	if (coop) {

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_ope
 		FrameAux a;
 		a.open = (force_open || !(ratio < SMH_BUTTON_RED_PIXEL_THRESHOLD)) ? 1u : 0u;
 		a.red = red; a.n_mask_px = 0;
-		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.tile_overflow = 0;
+		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.pad = 0;
 		b.aux[f] = a;
 	}
 }

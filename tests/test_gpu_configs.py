@@ -225,7 +225,7 @@ def test_both_line_segment_kernels_agree_with_the_oracle(vision):
     """find_lines has two kernels (smhv_debug_lsd_classic): the task-based k_lsd_tile (the default: sparse tile store of the
     mask, reorder buffer, waves claim 64-ray units) and the workgroup-synchronous k_lsd.  Random scenes and synthetic frames
     through both, culled and exact; the tile kernel also with its tile store capped so low that some (cap 48) or all (cap 4)
-    frames overflow it and are searched by k_lsd_wave_global on the mask in global memory."""
+    frames overflow it and are searched on the mask in global memory."""
     import torch
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import synth

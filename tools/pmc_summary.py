@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/pmc_summary.py <tag> -- condense the rocprofv3 output of tools/profile_round.sh into the
-files committed under profiles/: <tag>_kernel_stats_depth{1,2}.csv, <tag>_pmc_summary.txt and
+files committed under profiles/: <tag>_kernel_stats_depth{1,4}.csv, <tag>_pmc_summary.txt and
 traffic.json (the k_map_pass HBM bytes bench.py quotes as roofline.traffic).
 
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch; on gfx950 FETCH_SIZE counts half of wide
@@ -43,7 +43,7 @@ def main():
     FRAMES, W, H, rw, rh = CFG[cfg]
     # ROI read as BGRA + ui_map RGBA + u8 mask + ocr_out + scales
     MAP_ALGO_BYTES_PER_FRAME = rw * rh * 4 * 2 + rw * rh + 2 * (rw // 2) * (rh // 2)
-    for d in ("d1", "d2"):
+    for d in ("d1", "d4"):
         src = find(tag, d if cfg == "c2" else f"{cfg}_{d}", "*kernel_stats.csv")
         if src:
             shutil.copy(src, os.path.join(OUT, f"{tag}_kernel_stats_depth{d[1]}.csv" if cfg == "c2" else f"{tag}_{cfg}_kernel_stats_depth{d[1]}.csv"))
