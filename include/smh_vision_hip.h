@@ -235,12 +235,15 @@ SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
  *            on (to order a consumer, e.g. an RCCL gather, after it).
  *   hold   : a consumer reads the slot's outputs on `stream` (work already enqueued there): the slot's next submission
  *            is ordered behind it.
- * CU partition (MI355X: 256 CUs in 8 XCDs): with depth >= 2 the streaming kernels (button test, the fused map / quadrant
- * pass: HBM-bound) and the line-segment search (LDS-latency-bound, one 146 KB workgroup per CU) do not overlap well on the
- * same CUs -- a search workgroup leaves room for one streaming wave per SIMD.  smhv_pipeline_create_partitioned gives the
- * streaming kernels `stream_cus_of_32` CUs out of every 32 (hipExtStreamCreateWithCUMask; all passes' streaming kernels
- * go through one stream) and the search the rest (two streams, so consecutive launches overlap).  0 = no partition.
- * smhv_pipeline_create uses the library's default (environment SMHV_PIPELINE_STREAM_CUS overrides it). */
+ * depth: 1..8.  4 is what the library is tuned for (HIP has four hardware queues: a fifth and a sixth stream share one with
+ * another batch, measured -25 %; 8 is fine again).  The pipeline also picks the line-search kernel and its workgroup size for
+ * the depth and the frame size (DESIGN.md sections 5 and 7).
+ * CU partition (MI355X: 256 CUs in 8 XCDs): smhv_pipeline_create_partitioned gives the streaming kernels (button test, the
+ * fused map / quadrant pass: HBM-bound) `stream_cus_of_32` CUs out of every 32 (hipExtStreamCreateWithCUMask; all passes'
+ * streaming kernels go through one stream) and the line-segment search the rest (two streams, so consecutive launches
+ * overlap).  0 = no partition.  Measured: never better than no partition (on half the CUs the streaming pass is limited by
+ * the bytes a CU can keep in flight).  smhv_pipeline_create uses the library's default, no partition (environment
+ * SMHV_PIPELINE_STREAM_CUS overrides it). */
 typedef struct smhv_pipeline smhv_pipeline;
 SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth, smhv_pipeline **out);
 SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p);

@@ -117,7 +117,7 @@ extern "C" SMHV_API int smhv_node_create(const int *devices, uint32_t n_devices,
 	nd->n_last.assign(n_devices, 0); nd->slot_last.assign(n_devices, 0);
 	for (uint32_t i = 0; i < n_devices && !rc; ++i) {
 		rc = smhv_init(devices[i], log, &nd->ctx[i]);
-		if (!rc) rc = smhv_pipeline_create(nd->ctx[i], frame_w, frame_h, max_frames_per_device, depth ? depth : 2, &nd->pipe[i]);
+		if (!rc) rc = smhv_pipeline_create(nd->ctx[i], frame_w, frame_h, max_frames_per_device, depth ? depth : 4, &nd->pipe[i]);
 		if (!rc) {
 			hipError_t e = hipSetDevice(devices[i]);
 			if (e == hipSuccess) e = hipStreamCreateWithFlags(&nd->gstream[i], hipStreamNonBlocking);

@@ -385,11 +385,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // A 16-byte load the compiler does not track (uniform row base + 32-bit lane offset) and the wait that releases a set of four
 // of them: the streaming loop of k_map_brq_pass places its own waits (see there).  Nothing may read a destination before
 // SMH_WAIT_SET has named it; tools/check_untracked_loads.py checks the compiled code for that.
-#define SMH_LD128(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+#define SMH_LD128(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2 ; smh-load" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
 // stores in the same addressing form (a per-lane 64-bit pointer per output would cost the loop six registers it does not have)
 #define SMH_ST128(voff, data, sbase) asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff), "v"(data), "s"(sbase) : "memory")
 #define SMH_ST32(voff, data, sbase) asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(data), "s"(sbase) : "memory")
-#define SMH_WAIT_SET(n, X) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"((X)[0]), "+v"((X)[1]), "+v"((X)[2]), "+v"((X)[3]) : : "memory")
+#define SMH_WAIT_SET(n, X) asm volatile("s_waitcnt vmcnt(" #n ") ; smh-release" : "+v"((X)[0]), "+v"((X)[1]), "+v"((X)[2]), "+v"((X)[3]) : : "memory")
 // image 0.23.14 rgb_to_luma of a BGRA dword, without luma8()'s clamp: the f32 sum is at most 255.0 (r = g = b = 255; the
 // sum is monotonic in every channel), so the truncation cannot exceed 255.
 __device__ __forceinline__ uint32_t luma_bgra(uint32_t p) {
@@ -611,12 +611,21 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	// overtake an older load (measured: crediting the stores issued since, which an in-order counter would allow, hands out
 	// stale pixels), so the wait also covers the stores of the two groups before -- two groups old by then, and cheaper
 	// than what the compiler makes of tracked loads here: its waits assume the fewest stores any path could have issued,
-	// none, and every group then waits for the stores of the group right before it.  0.49 -> 0.44 ms per 256 frames.
-	// Rows beyond the band's last are clamped onto it (always four loads per set, the count stays static; the extra loads
-	// hit the same cache lines).
+	// none, and every group then waits for the stores of the group right before it.  (Same-box A/B: no difference in time to
+	// the compiler-scheduled version -- the memory system sets the pace, DESIGN.md -- but fewer registers and no spills.)
+	// A set is always four loads (the count behind a wait has to be static; making the loads of the last sets conditional
+	// makes the compiler copy registers that still have a load in flight -- tools/check_untracked_loads.py caught it): the
+	// loads of rows beyond the band's last go, all lanes, to one 16-byte location that is always in the L2 (the frame's aux
+	// record) instead of re-reading pixel rows, which by then have been evicted by the pass's own stores (measured: 13 % more
+	// bytes fetched).  Their data is never looked at.
+	const uint8_t *dummy = (const uint8_t *)&b.aux[f];
 	auto load4 = [&](u32x4 (&dst)[4], int r) {
 #pragma unroll
-		for (int k = 0; k < 4; ++k) { const uint8_t *rowp = fbase + (size_t)min(r + k, re) * row_bytes; SMH_LD128(dst[k], loff, rowp); }
+		for (int k = 0; k < 4; ++k) {
+			const bool inside = r + k <= re;
+			const uint8_t *rowp = inside ? fbase + (size_t)(r + k) * row_bytes : dummy;
+			SMH_LD128(dst[k], inside ? loff : 0u, rowp);
+		}
 	};
 	u32x4 S0[4], S1[4], S2[4];
 	load4(S0, rs);

@@ -28,8 +28,9 @@ def regs_in(text):
 
 def check_kernel(name, lines):
     code = [l.split(";")[0].rstrip() for l in lines]
-    loads = [(i, regs_in(code[i].split(",")[0])) for i in range(len(code)) if re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[", code[i])]
-    waits = [i for i in range(len(code)) if re.search(r"s_waitcnt vmcnt\(8\)", code[i])]
+    # the asm statements carry comments: `; smh-load` on the untracked loads, `; smh-release` on the waits
+    loads = [(i, regs_in(code[i].split(",")[0])) for i in range(len(code)) if "smh-load" in lines[i]]
+    waits = [i for i in range(len(code)) if "smh-release" in lines[i]]
     errors = []
     if len(loads) != 20 or len(waits) != 3:
         return ["%s: expected 20 untracked loads (2 sets before the loop, 3 in it) and 3 waits, found %d and %d" % (name, len(loads), len(waits))]
