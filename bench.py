@@ -347,6 +347,24 @@ def main():
             a2 = n * kernel_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9
             out["roofline_isolated"] = {"kernel": kname, "achieved": a2, "frac": a2 / HBM_PEAK_GBS, "unit": "GB/s",
                                         "launch_ms": iso_ms["map_pass"], "stages_ms": iso_ms}
+            # calibration on THIS box (they differ by 10 %): a plain device-to-device copy moving the same number of bytes
+            # (half read, half written); outside every timed region
+            try:
+                half = int(n * kernel_bytes // 2)
+                ca = torch.empty(half, dtype=torch.uint8, device="cuda"); cb = torch.empty_like(ca)
+                for _ in range(3):
+                    cb.copy_(ca)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(10):
+                    cb.copy_(ca)
+                e1.record(); torch.cuda.synchronize()
+                copy_gbs = 2 * half / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
+                out["roofline_isolated"]["device_copy_GBps"] = copy_gbs
+                out["roofline_isolated"]["frac_of_device_copy"] = a2 / copy_gbs
+                del ca, cb
+            except RuntimeError:
+                pass
         out["stages_ms"] = stages_ms
         out["pipeline_algorithmic_GBps"] = value / world * full_bytes / 1e9
         out["pipeline_hbm_frac"] = value / world * full_bytes / 1e9 / HBM_PEAK_GBS
