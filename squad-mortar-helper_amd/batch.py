@@ -129,7 +129,7 @@ class Pipeline:
     """`depth` batches in flight on library-owned streams (smhv_pipeline_*): submit() is asynchronous and returns the slot;
     the library starts consecutive submissions half a period apart and owns every stream of the schedule."""
 
-    def __init__(self, vision, frame_w, frame_h, max_frames, depth=2, stream_cus=None):
+    def __init__(self, vision, frame_w, frame_h, max_frames, depth=4, stream_cus=None):
         """stream_cus: CUs of every 32 reserved for the streaming kernels (None: the library default, 0: no partition)."""
         self._lib = L.load()
         self._vision = vision

@@ -1,5 +1,5 @@
 """Throughput on the reference's own sample screenshots (tests/golden fixtures rebuilt into 2560x1440 frames), next
-to the synthetic workload of bench.py: a batch of 128 frames cycling the open-map 1440p fixtures, full marker pipeline
+to the synthetic workload of bench.py: a batch of 128 frames cycling the open-map 1440p fixtures through smhv_pipeline (depth 4), full marker pipeline
 (button, ui_map, mask + dilation, LSD); GPU results are checked against the C oracle on every distinct frame."""
 import os
 import sys
@@ -25,23 +25,20 @@ def main():
     k = len(frames)
     batch = np.stack([frames[i % k] for i in range(n)])
     vision = smh.HipVision.init(0)
-    fbs = [smh.FrameBatch(vision, 2560, 1440, n) for _ in range(2)]
+    depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth)
     d = torch.from_numpy(batch).cuda()
-    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
-    streams[1].wait_stream(streams[0])
-    def step(i):
-        with torch.cuda.stream(streams[i % 2]):
-            fbs[i % 2].run(d.data_ptr(), n, stages=0x3, max_gap=15, stream=streams[i % 2].cuda_stream)
-    for i in range(4):
-        step(i)
     torch.cuda.synchronize()
+    for i in range(2 * depth):
+        pipe.submit(d.data_ptr(), n, stages=0x3, max_gap=15)
+    pipe.wait()
     steps = 40
     t0 = time.perf_counter()
     for i in range(steps):
-        step(i)
-    torch.cuda.synchronize()
+        slot = pipe.submit(d.data_ptr(), n, stages=0x3, max_gap=15)
+    pipe.wait()
     dt = time.perf_counter() - t0
-    got = smh.results_to_dicts(fbs[0].read_results(0, n))
+    got = smh.results_to_dicts(pipe.slots[slot].read_results(0, n))
     t1 = time.perf_counter()
     ref = orc.process_batch(np.stack(frames), min(os.cpu_count() or 1, k), stages=0x3, max_gap=15)
     cdt = time.perf_counter() - t1
