@@ -1,5 +1,6 @@
 """Throughput on the reference's own sample screenshots (tests/golden fixtures rebuilt into 2560x1440 frames), next
-to the synthetic workload of bench.py: a batch of 128 frames cycling the open-map 1440p fixtures through smhv_pipeline (depth 4), full marker pipeline
+to the synthetic workload of bench.py: batches of 256 frames cycling the open-map 1440p fixtures through smhv_pipeline (depth 8; usage: [frames per batch] [depth]),
+full marker pipeline
 (button, ui_map, mask + dilation, LSD); GPU results are checked against the C oracle on every distinct frame."""
 import os
 import sys
@@ -16,7 +17,7 @@ from oracle import oracle as orc   # checker + CPU timing only
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     frames, stems = [], []
     for stem in fx.OPEN_STEMS:
         f, e, g = fx.load_fixture(stem)
@@ -25,7 +26,7 @@ def main():
     k = len(frames)
     batch = np.stack([frames[i % k] for i in range(n)])
     vision = smh.HipVision.init(0)
-    depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth)
     d = torch.from_numpy(batch).cuda()
     torch.cuda.synchronize()
@@ -49,7 +50,7 @@ def main():
         ok = ok and got[i]["n_lines"] == r.n_lines and np.array_equal(got[i]["lines"], rl) and got[i]["rounds"] == r.rounds
     print("%d distinct 2560x1440 sample frames (%s ...), batch %d, stages ui_map+markers" % (k, ", ".join(stems[:3]), n))
     print("rounds per frame: %s" % [int(r.rounds) for r in ref])
-    print("GPU: %.0f frames/s (%.3f ms per %d-frame step, two steps in flight); lines + rounds equal to the oracle: %s" % (n * steps / dt, dt / steps * 1e3, n, ok))
+    print("GPU: %.0f frames/s (%.3f ms per %d-frame step, smhv_pipeline depth %d); lines + rounds equal to the oracle: %s" % (n * steps / dt, dt / steps * 1e3, n, depth, ok))
     print("CPU oracle: %.1f frames/s on %d threads (%.2f s for %d frames)" % (k / cdt, min(os.cpu_count() or 1, k), cdt, k))
     sys.exit(0 if ok else 1)
 
