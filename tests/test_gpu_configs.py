@@ -257,6 +257,40 @@ def test_both_line_segment_kernels_agree_with_the_oracle(vision):
         lib.smhv_debug_lsd_tile_cap(0)
 
 
+def test_sample_screenshots_through_the_batch_path(vision):
+    """The reference's own sample screenshots (tests/golden fixtures), grouped by size and run as batches through
+    smhv_batch_run -- i.e. through k_lsd_tile, which the per-call trait path of test_gpu_parity does not use: lines, round
+    counts and (exact mode) sample counts against the goldens, and once more with the tile store capped at 64 tiles (the
+    larger scenes then take the global-memory path)."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    import fixtures as fx
+    lib = smh._lib.load()
+    by_size = {}
+    for stem in fx.OPEN_STEMS:
+        frame, e, g = fx.load_fixture(stem)
+        by_size.setdefault(frame.shape[:2], []).append((stem, frame, e, g))
+    try:
+        for (H, W), items in sorted(by_size.items()):
+            frames = np.stack([it[1] for it in items])
+            n = len(items)
+            fb = smh.FrameBatch(vision, W, H, n)
+            d = torch.from_numpy(frames).cuda()
+            for cap in (0, 64):
+                lib.smhv_debug_lsd_tile_cap(cap)
+                for exact in (0, smh.STAGE_EXACT_STATS):
+                    fb.run(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=15, stream=torch.cuda.current_stream().cuda_stream)
+                    got = smh.results_to_dicts(fb.read_results(0, n))
+                    for i, (stem, _, e, g) in enumerate(items):
+                        assert got[i]["n_lines"] == len(g["lines"]) and np.array_equal(got[i]["lines"], g["lines"]), (stem, cap, bool(exact))
+                        assert got[i]["rounds"] == e["rounds"], (stem, cap, bool(exact))
+                        if exact:
+                            assert got[i]["ray_steps"] == e["steps"], (stem, cap)
+            fb.close()
+    finally:
+        lib.smhv_debug_lsd_tile_cap(0)
+
+
 def test_fuzz_stream_slice(vision):
     """Bounded slice of tools/fuzz_stream.py: pixels drawn around every decision threshold of the streaming stages."""
     import squad_mortar_helper_amd as smh
