@@ -291,6 +291,32 @@ def test_sample_screenshots_through_the_batch_path(vision):
         lib.smhv_debug_lsd_tile_cap(0)
 
 
+def test_8k_frames_take_the_large_tile_index(vision):
+    """7680x4320: the 16-bit tile index of the map ROI alone is 106 KB, so k_lsd_tile runs one workgroup per CU with 140 KB of
+    dynamic LDS instead of two with 60 KB each.  Two synthetic frames, both line-search kernels, against the oracle."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, n = 7680, 4320, 2
+    frames = np.stack([synth.make_frame(W, H, 900 + i, n_lines=3)[0] for i in range(n)])
+    ref = o.process_batch(frames, n, stages=0x1, max_gap=15)
+    lib = smh._lib.load()
+    fb = smh.FrameBatch(vision, W, H, n)
+    d = torch.from_numpy(frames).cuda()
+    try:
+        for classic in (0, 1):
+            lib.smhv_debug_lsd_classic(classic)
+            fb.run(d.data_ptr(), n, stages=smh.STAGE_MARKERS, max_gap=15, stream=torch.cuda.current_stream().cuda_stream)
+            got = smh.results_to_dicts(fb.read_results(0, n))
+            for i in range(n):
+                assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (i, classic)
+                assert got[i]["rounds"] == ref[i].rounds, (i, classic)
+        assert sum(r.n_lines for r in ref) >= 4
+    finally:
+        lib.smhv_debug_lsd_classic(0)
+        fb.close()
+
+
 def test_fuzz_stream_slice(vision):
     """Bounded slice of tools/fuzz_stream.py: pixels drawn around every decision threshold of the streaming stages."""
     import squad_mortar_helper_amd as smh
