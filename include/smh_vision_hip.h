@@ -235,8 +235,9 @@ SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
  *            on (to order a consumer, e.g. an RCCL gather, after it).
  *   hold   : a consumer reads the slot's outputs on `stream` (work already enqueued there): the slot's next submission
  *            is ordered behind it.
- * depth: 1..8.  4 is what the library is tuned for; 8 measures the same, 5 and 6 measure 20-25 % lower (also with
- * GPU_MAX_HW_QUEUES=8, so it is not HIP's four hardware queues; not understood).  The pipeline also picks the line-search kernel and its workgroup size for
+ * depth: 1..8.  4 is what the library is tuned for; 8 measures the same, 5 and 6 measure 20-25 % lower: HIP deals the streams
+ * onto four hardware queues, and with five or six streams two of the queues carry two batches each (setting
+ * GPU_MAX_HW_QUEUES=8 does not change that on this runtime).  The pipeline also picks the line-search kernel and its workgroup size for
  * the depth and the frame size (DESIGN.md sections 5 and 7).
  * CU partition (MI355X: 256 CUs in 8 XCDs): smhv_pipeline_create_partitioned gives the streaming kernels (button test, the
  * fused map / quadrant pass: HBM-bound) `stream_cus_of_32` CUs out of every 32 (hipExtStreamCreateWithCUMask; all passes'

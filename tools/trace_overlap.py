@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""tools/trace_overlap.py <kernel_trace.csv> -- what runs beside what in a rocprofv3 --kernel-trace of bench.py: share of the time
+with a streaming pass / n line-search launches in flight, mean kernel durations, kernels per hardware queue."""
+import collections, csv, statistics, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = []
+for r in rows:
+    n = r["Kernel_Name"]
+    k = "map" if "k_map_brq" in n or "k_map_pass" in n else "search" if "k_lsd" in n else "button" if "k_button" in n else "record" if "finalize" in n else None
+    if k:
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k, r.get("Queue_Id")))
+ev.sort()
+maps = [e for e in ev if e[2] == "map"]
+skip = max(0, len(maps) // 4)                       # leave the warm-up out
+t0 = maps[skip][0]
+t1 = max(e[1] for e in ev if e[2] == "map")
+ev = [e for e in ev if e[0] >= t0 and e[1] <= t1]
+pts = []
+for s, e, k, q in ev:
+    pts.append((s, 1, k)); pts.append((e, -1, k))
+pts.sort()
+act, last, occ = collections.Counter(), t0, collections.Counter()
+for t, d, k in pts:
+    key = ("map%d" % act["map"] if act["map"] else "") + (" search%d" % act["search"] if act["search"] else "")
+    occ[key or "nothing"] += t - last
+    last = t
+    act[k] += d
+tot = sum(occ.values())
+print("region %.2f ms, %d streaming passes -> %.3f ms per pass" % ((t1 - t0) / 1e6, len([e for e in ev if e[2] == "map"]), (t1 - t0) / 1e6 / max(1, len([e for e in ev if e[2] == "map"]))))
+for k, v in occ.most_common(10):
+    print("  %-18s %5.1f %%" % (k, 100 * v / tot))
+for k in ("map", "search", "button", "record"):
+    d = [(e[1] - e[0]) / 1e3 for e in ev if e[2] == k]
+    if d:
+        print("  %-7s n %3d  mean %6.0f us  min %6.0f  max %6.0f" % (k, len(d), statistics.mean(d), min(d), max(d)))
+print("  kernels per queue:", dict(collections.Counter(e[3] for e in ev)))
