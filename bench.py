@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
     ap.add_argument("--pipeline-depth", type=int, default=4, help="batches in flight (smhv_pipeline_create depth)")
+    ap.add_argument("--tile-cap", type=int, default=0,
+                    help="diagnostic: cap the tile store of k_lsd_tile (smhv_debug_lsd_tile_cap): fewer tiles = less LDS = more workgroups per CU")
     ap.add_argument("--idle-streams", type=int, default=0,
                     help="diagnostic: create this many HIP streams before the pipeline (the schedule must not depend on them)")
     ap.add_argument("--stream-cus", type=int, default=None,
@@ -210,6 +212,8 @@ def main():
     vision = smh.HipVision.init(local_rank)
     depth = max(1, args.pipeline_depth)
     idle_streams = [torch.cuda.Stream() for _ in range(max(0, args.idle_streams))]   # noqa: F841 (kept alive on purpose)
+    if args.tile_cap > 0:
+        smh._lib.load().smhv_debug_lsd_tile_cap(args.tile_cap)
     pipe = smh.Pipeline(vision, W, H, n, depth, stream_cus=args.stream_cus)
     anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 0x8 else None
     fptr = frames.data_ptr()
