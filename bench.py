@@ -77,15 +77,28 @@ def cpu_model():
 
 
 def cpu_stage_split(orc, frames, infos, max_gap=15):
-    """Single-thread per-stage milliseconds of the C oracle, mean over the given frames."""
-    acc = dict(crop_to_map=0.0, threshold_dilate=0.0, lsd=0.0, ocr_preprocess=0.0, find_scales_preprocess=0.0)
+    """Single-thread per-stage milliseconds of the C oracle: median over the given frames, after one
+    untimed pass over the same frames (first-touch page faults in freshly mapped output arrays moved whole stages by 10-40x
+    between runs when it was a plain mean over cold calls)."""
+    names = ("crop_to_map", "threshold_dilate", "lsd", "ocr_preprocess", "find_scales_preprocess")
+    samples = {k: [] for k in names}
+
+    def one(fr, info, record):
+        t0 = time.perf_counter(); crop = orc.crop_to_map(fr, True)
+        t1 = time.perf_counter(); mask = orc.mask_marker_lines(crop["cropped_map"])
+        t2 = time.perf_counter(); orc.find_lines(mask, max_gap)
+        t3 = time.perf_counter(); orc.ocr_preprocess(crop["cropped_brq"])
+        t4 = time.perf_counter(); orc.find_scales_preprocess(crop["cropped_brq"], info["scales_start_y"])
+        t5 = time.perf_counter()
+        if record:
+            for k, dt in zip(names, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                samples[k].append(dt)
+
+    for fr, info in zip(frames, infos):                      # untimed pass: the allocator and the page cache settle
+        one(fr, info, False)
     for fr, info in zip(frames, infos):
-        t = time.perf_counter(); crop = orc.crop_to_map(fr, True); acc["crop_to_map"] += time.perf_counter() - t
-        t = time.perf_counter(); mask = orc.mask_marker_lines(crop["cropped_map"]); acc["threshold_dilate"] += time.perf_counter() - t
-        t = time.perf_counter(); orc.find_lines(mask, max_gap); acc["lsd"] += time.perf_counter() - t
-        t = time.perf_counter(); orc.ocr_preprocess(crop["cropped_brq"]); acc["ocr_preprocess"] += time.perf_counter() - t
-        t = time.perf_counter(); orc.find_scales_preprocess(crop["cropped_brq"], info["scales_start_y"]); acc["find_scales_preprocess"] += time.perf_counter() - t
-    return {k: v / len(frames) * 1e3 for k, v in acc.items()}
+        one(fr, info, True)
+    return {k: sorted(v)[len(v) // 2] * 1e3 for k, v in samples.items()}
 
 
 def ingest_leg(smh, vision, pipe, src, anchors, stages, frames_total, W, H, n):
@@ -405,11 +418,11 @@ def main():
         res = orc.process_batch(sub, cores, **kw)
         cdt = time.perf_counter() - t0
         same = n == 1 or all(res[i].n_lines == recs[i]["n_lines"] and res[i].rounds == recs[i]["rounds"] for i in range(k))
-        split = cpu_stage_split(orc, sub[:4], sinfo[:4])
+        split = cpu_stage_split(orc, sub[:8], sinfo[:8])
         out["cpu_baseline"] = {"value": k / cdt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
                                "single_thread_stage_ms": split, "single_thread_frames_per_s": 1e3 / max(sum(split.values()), 1e-9),
                                "sample": "%d frames of rank 0's workload, same stages, C oracle (gcc -O2, -ffp-contract=off), frames parallel across "
-                                         "%d threads; line/round counts match GPU: %s; stage split: mean of 4 frames on one thread" % (k, cores, same)}
+                                         "%d threads; line/round counts match GPU: %s; stage split: median of 8 frames on one thread after an untimed pass" % (k, cores, same)}
     print(json.dumps(out))
     pipe.close()
     if world > 1:
