@@ -76,6 +76,21 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited or unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_stage_split(orc, frames, infos, max_gap=15):
     """Single-thread per-stage milliseconds of the C oracle: median over the given frames, after one
     untimed pass over the same frames (first-touch page faults in freshly mapped output arrays moved whole stages by 10-40x
@@ -407,7 +422,10 @@ def main():
             sub, sinfo = synth.make_batch(W, H, k, first_idx=first, n_lines=args.lines)
         else:
             sub, sinfo = frames_host.numpy()[:k], infos[:k]
+        quota = cpu_quota_cores()
         cores = min(os.cpu_count() or 1, k)              # threads actually used: one frame per thread at a time
+        if quota:
+            cores = max(1, min(cores, int(quota + 0.5)))  # more threads than the container's CPU quota only time-slice
         a = np.zeros((k, 3, 3), np.uint32)
         for i in range(k):
             for j, s_ in enumerate(sinfo[i]["anchors"][:3]):
@@ -420,6 +438,7 @@ def main():
         same = n == 1 or all(res[i].n_lines == recs[i]["n_lines"] and res[i].rounds == recs[i]["rounds"] for i in range(k))
         split = cpu_stage_split(orc, sub[:8], sinfo[:8])
         out["cpu_baseline"] = {"value": k / cdt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+                               "cpu_quota_cores": cpu_quota_cores(),
                                "single_thread_stage_ms": split, "single_thread_frames_per_s": 1e3 / max(sum(split.values()), 1e-9),
                                "sample": "%d frames of rank 0's workload, same stages, C oracle (gcc -O2, -ffp-contract=off), frames parallel across "
                                          "%d threads; line/round counts match GPU: %s; stage split: median of 8 frames on one thread after an untimed pass" % (k, cores, same)}
