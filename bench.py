@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- map frames/s through the vision hot path on N MI355X GPUs (one process per GPU).
 
-Workloads (BASELINE.json `configs`; --config picks one, default 2 = the configuration the metric is quoted on):
+Workloads (BASELINE.json `configs`; --config picks one; default 2 = the configuration the metric is quoted on, 4 when
+--gpus > 1):
+  0  the reference's own CPU-runnable case: one real sample screenshot (the committed `point_intersect` fixture, 2560x1440,
+     vision-gpu/src/lib.rs:571) and its 1080p synthetic analogue through the C oracle -- single-thread ms/frame + stage
+     split + all-core frames/s -- beside the same frames' latency on the GPU through the per-call trait path
   1  batch = 1, 1920x1080 synthetic map, marker threshold + dilation + LSD only
   2  256 x 1920x1080 frames RESIDENT IN HBM per GPU, full pipeline: close-deployment button test, ui_map, marker
      threshold + dilation, ocr_preprocess, find_scales_preprocess + m/px, ray-cast line-segment detection, derived
      marker lengths / angles
   3  128 x 2560x1440 frames, full pipeline
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs the same workload on its own block of
-the global batch (frames are independent: weak scaling) and the per-frame result records are gathered to rank 0 over RCCL
-inside the timed step.
+  4  8192-frame batch block-sharded 1024 x 1920x1080 per GPU, full pipeline, the per-frame result records of every pass
+     gathered to rank 0 over RCCL inside the timed step (N = 1: the 1024-frame shard alone)
+Launch: `python bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run`, before anything touches
+the GPU) and relays rank 0's JSON line; under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  Every rank
+runs the same workload on its own block of the global batch (frames are independent: weak scaling).  `--node` drives the
+same workload from ONE process through the C ABI's smhv_node_run / smhv_node_gather (ncclCommInitAll + ncclGather).
 
-One "step" = --rounds-per-step passes of the hot path over the resident batch (default 8, so that the default 20-step
-region lasts ~0.1 s instead of 15 ms); `value` counts every frame of every pass.  The passes go through
-smhv_pipeline_submit: the library owns the streams and the schedule (--pipeline-depth batches in flight, default 4);
-`value_depth1` is the same workload with ONE batch in flight, timed right after the main region.
+One "step" = --rounds-per-step passes of the hot path over the resident batch (sized so that the default 20 steps last
+about a second); `value` counts every frame of every pass.  The K timed steps run as up to five sub-regions, each
+bracketed by barrier + synchronize, and `value` is the MEDIAN sub-region's rate (min / max / whole-region mean beside it).
+The passes go through smhv_pipeline_submit: the library owns the streams and the schedule (--pipeline-depth batches in
+flight, default 4); `value_depth1` is the same workload with ONE batch in flight, timed right after.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
   roofline     -- the dominant HBM streaming kernel: algorithmic bytes / hipEvent launch duration on the run's stream
@@ -26,26 +34,81 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 CONFIGS = {
-    1: dict(frames=1, width=1920, height=1080, stages=0x1, rounds=64,
+    0: dict(frames=1, width=2560, height=1440, stages=0xF, rounds=1,
+            name="BASELINE configs[0]: single vision-common/samples screenshot (point_intersect, 2560x1440) through the CPU path"),
+    1: dict(frames=1, width=1920, height=1080, stages=0x1, rounds=512,
             name="BASELINE configs[1]: batch=1 1920x1080 synthetic map, marker threshold + dilation + LSD only"),
-    2: dict(frames=256, width=1920, height=1080, stages=0xF, rounds=8,
+    2: dict(frames=256, width=1920, height=1080, stages=0xF, rounds=96,
             name="BASELINE configs[2]: 256 x 1920x1080 BGRA frames resident in HBM per GPU, full pipeline (button, ui_map, "
                  "marker mask+dilate, LSD, ocr_preprocess, scales+m/px)"),
-    3: dict(frames=128, width=2560, height=1440, stages=0xF, rounds=8,
+    3: dict(frames=128, width=2560, height=1440, stages=0xF, rounds=96,
             name="BASELINE configs[3]: 128 x 2560x1440 BGRA frames resident in HBM per GPU, full pipeline"),
+    4: dict(frames=1024, width=1920, height=1080, stages=0xF, rounds=24,
+            name="BASELINE configs[4]: 8192-frame batch block-sharded 1024 x 1920x1080 per GPU (8.5 GB resident per GPU), full "
+                 "pipeline, RCCL gather of the per-frame result records (segment lists, m/px) to rank 0 inside every pass"),
 }
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[] index of the workload (default: 2, or 4 when --gpus > 1)")
+    ap.add_argument("--frames-per-gpu", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--stages", type=lambda s: int(s, 0), default=None)
+    ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
+    ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
+    ap.add_argument("--pipeline-depth", type=int, default=4, help="batches in flight (smhv_pipeline_create depth)")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic frames per GPU (0 = every frame distinct); fewer are tiled on the device (quick runs)")
+    ap.add_argument("--node", action="store_true",
+                    help="ONE process drives all --gpus devices through the C ABI (smhv_node_run + smhv_node_gather) instead of one rank per GPU")
+    ap.add_argument("--tile-cap", type=int, default=0,
+                    help="diagnostic: cap the tile store of k_lsd_tile (smhv_debug_lsd_tile_cap): fewer tiles = less LDS = more workgroups per CU")
+    ap.add_argument("--idle-streams", type=int, default=0,
+                    help="diagnostic: create this many HIP streams before the pipeline (the schedule must not depend on them)")
+    ap.add_argument("--stream-cus", type=int, default=None,
+                    help="CUs of every 32 reserved for the streaming kernels (smhv_pipeline_create_partitioned); default: the library's choice")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-box testing of the N>1 code path)")
+    ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="testing only (no GPU needed): the ranks meet, reduce one number over the process group, rank 0 prints a JSON line")
+    ap.add_argument("--ingest-frames", type=int, default=512,
+                    help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1, config 2 only)")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher in front: start the N ranks as a CHILD process (never exec: this
+    process may not have touched the GPU, but a replaced process image is not worth the risk on this pool), relay their
+    output and leave with their exit code.  Nothing here imports torch or initialises HIP."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def algorithmic_bytes(roi_w, roi_h, btn_w, btn_h, stages):
@@ -91,6 +154,14 @@ def cpu_quota_cores():
         return None
 
 
+def cpu_threads(k):
+    quota = cpu_quota_cores()
+    cores = min(os.cpu_count() or 1, k)              # threads actually used: one frame per thread at a time
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))  # more threads than the container's CPU quota only time-slice
+    return cores
+
+
 def cpu_stage_split(orc, frames, infos, max_gap=15):
     """Single-thread per-stage milliseconds of the C oracle: median over the given frames, after one
     untimed pass over the same frames (first-touch page faults in freshly mapped output arrays moved whole stages by 10-40x
@@ -116,7 +187,14 @@ def cpu_stage_split(orc, frames, infos, max_gap=15):
     return {k: sorted(v)[len(v) // 2] * 1e3 for k, v in samples.items()}
 
 
-def ingest_leg(smh, vision, pipe, src, anchors, stages, frames_total, W, H, n):
+def records_equal_oracle(np, rec, ref):
+    """One GPU record (dict) against one oracle record: integer fields and line end points bit for bit."""
+    lines = np.array([[ref.lines[i][j] for j in range(4)] for i in range(ref.n_lines)], np.float32).reshape(-1, 4)
+    return (rec["n_lines"] == ref.n_lines and rec["rounds"] == ref.rounds and rec["n_mask_px"] == ref.n_mask_px
+            and np.array_equal(rec["lines"], lines) and rec["mpx"] == (ref.mpx if ref.has_mpx else None))
+
+
+def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, H, n):
     """PCIe-inclusive rate (never `value`): frames travel pinned host memory -> HBM through the ingest queue (async
     copy, device CRC-32 duplicate test, slab append) and every full slab goes through the same pipeline; two queues
     alternate so the uploads of one slab overlap the compute of the other.  The staging buffers are filled once; each
@@ -170,33 +248,190 @@ def ingest_leg(smh, vision, pipe, src, anchors, stages, frames_total, W, H, n):
                     "pipeline, two slabs in flight; push_frames_per_s adds the host memcpy from pageable memory (one thread)"}
 
 
+def upload_synthetic(torch, synth, W, H, n, first, lines, distinct, device, keep_host):
+    """n resident frames on `device`: generated in chunks through one pinned staging buffer (a 1024-frame shard is 8.5 GB:
+    no host copy of the whole batch).  distinct < n: that many frames, tiled.  -> (device tensor, infos, host copy of the
+    first `keep_host` frames, seconds spent in the H2D copies)."""
+    import numpy as np
+    k = n if distinct <= 0 else min(distinct, n)
+    chunk = min(64, k)
+    stage = torch.empty((chunk, H, W, 4), dtype=torch.uint8, pin_memory=True)
+    d = torch.empty((n, H, W, 4), dtype=torch.uint8, device=device)
+    infos, host = [], np.empty((min(keep_host, k), H, W, 4), np.uint8)
+    h2d = 0.0
+    for c0 in range(0, k, chunk):
+        c = min(chunk, k - c0)
+        _, inf = synth.make_batch(W, H, c, first_idx=first + c0, n_lines=lines, out=stage.numpy()[:c])
+        infos += inf
+        if c0 < len(host):
+            m = min(c, len(host) - c0)
+            host[c0:c0 + m] = stage.numpy()[:m]
+        t0 = time.perf_counter()
+        d[c0:c0 + c].copy_(stage[:c], non_blocking=True)
+        torch.cuda.synchronize(device)
+        h2d += time.perf_counter() - t0
+    for c0 in range(k, n, k):                                  # tile the distinct frames over the rest of the batch
+        c = min(k, n - c0)
+        d[c0:c0 + c].copy_(d[:c])
+    infos = [infos[i % k] for i in range(n)]
+    torch.cuda.synchronize(device)
+    return d, infos, host, h2d
+
+
+def sub_regions(steps):
+    k = min(5, steps)
+    return [steps * (i + 1) // k - steps * i // k for i in range(k)]
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def config0(args):
+    """SURVEY 8(d) "Config 1" (BASELINE configs[0]): the reference's own test image through the CPU path, with the same
+    frame's latency through the GPU trait path beside it.  One JSON line."""
+    import numpy as np
+    import torch  # noqa: F401  (HIP runtime first: see _lib.load)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixtures as fx
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    from oracle import oracle as orc   # this leg IS the CPU baseline; the GPU numbers beside it come from the product path
+
+    frame_s, e, _g = fx.load_fixture("point_intersect_png")
+    labels_s = [(300, 594, 433), (900, 594, 465)]               # the sample's scale labels as OCR would deliver them
+    frame_y, info_y = synth.make_frame(1920, 1080, 0, n_lines=args.lines)
+    cases = [("point_intersect.png (vision-common/samples, 2560x1440)", frame_s, labels_s, min(a[2] for a in labels_s)),
+             ("synthetic 1920x1080 (frame 0 of the bench generator)", frame_y, info_y["anchors"], info_y["scales_start_y"])]
+    have_gpu = torch.cuda.is_available()
+    vision = smh.HipVision.init(0) if have_gpu else None
+    state = smh.VisionState() if have_gpu else None
+    out_cases = []
+    for name, frame, labels, start_y in cases:
+        H, W = frame.shape[:2]
+        info = dict(scales_start_y=start_y)
+        split = cpu_stage_split(orc, [frame] * 5, [info] * 5)
+        for _ in range(2):
+            ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=start_y)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=start_y)
+        cpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        threads = cpu_threads(64)
+        k = max(threads * 2, 8)
+        batch = np.ascontiguousarray(np.broadcast_to(frame, (k,) + frame.shape))
+        a = np.zeros((k, 3, 3), np.uint32)
+        for j, s_ in enumerate(labels[:3]):
+            a[:, j] = s_
+        orc.process_batch(batch[:threads], threads, stages=0xF, anchors=a[:threads], n_anchors=len(labels), scales_start_y=start_y)
+        t0 = time.perf_counter()
+        orc.process_batch(batch, threads, stages=0xF, anchors=a, n_anchors=len(labels), scales_start_y=start_y)
+        all_core = k / (time.perf_counter() - t0)
+        c = {"frame": name, "size": [W, H], "rounds": int(ref["rounds"]), "lines": int(ref["n_lines"]), "ray_steps": int(ref["steps"]),
+             "cpu_single_thread_ms_per_frame": cpu_ms, "cpu_single_thread_stage_ms": split,
+             "cpu_all_core_frames_per_s": all_core, "cpu_threads": threads}
+        if have_gpu:
+            for _ in range(3):
+                res = state.process(vision, frame, ocr_labels=labels)
+            n = 20
+            t0 = time.perf_counter()
+            for _ in range(n):
+                res = state.process(vision, frame, ocr_labels=labels)
+            c["gpu_trait_path_ms_per_frame"] = (time.perf_counter() - t0) / n * 1e3
+            c["gpu_lines_equal_cpu"] = bool(res is not None and np.array_equal(res.markers, ref["lines"]) and res.meters_to_px_ratio == ref["mpx"])
+        out_cases.append(c)
+    first = out_cases[0]
+    out = {"metric": "map frames/sec (single 2560x1440 sample screenshot, full CV pipeline), CPU path", "value": 1e3 / first["cpu_single_thread_ms_per_frame"],
+           "unit": "frames/s", "n_gpus": 0, "steps": 5, "warmup": 2, "ms_per_step": first["cpu_single_thread_ms_per_frame"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32", "data": "vision-common/samples/point_intersect.png (committed fixture) + synthetic",
+           "config": {"workload": CONFIGS[0]["name"], "baseline_config": 0, "path": "C oracle (port of vision-cpu: gcc -O2 -ffp-contract=off), one thread; "
+                      "the Rust original cannot be built in this image"},
+           "cases": out_cases,
+           "cpu_baseline": {"value": first["cpu_all_core_frames_per_s"], "unit": "frames/s", "cores": first["cpu_threads"], "kind": "port", "cpu": cpu_model(),
+                            "cpu_quota_cores": cpu_quota_cores(), "sample": "copies of the sample frame spread over the host threads"}}
+    print(json.dumps(out))
+    if vision is not None:
+        vision.shutdown()
+
+
+def node_main(args, cfg, n, W, H, stages, rounds, custom):
+    """--node: ONE process, every device through smhv_node_run + smhv_node_gather (the C ABI's multi-GPU form).
+    Each pass = one asynchronous run on every device + one gather of all records to devices[0] (synchronous: the gather
+    ends the pass, so each device has one batch in flight -- compare with value_depth1 of the one-process-per-GPU leg)."""
+    import numpy as np
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    from squad_mortar_helper_amd.node import Node
+    devs = list(range(args.gpus)) if args.force_device is None else [args.force_device]
+    if args.force_device is not None and args.gpus > 1:
+        print("bench.py --node: a communicator cannot hold one device twice; --force-device runs a world of one", file=sys.stderr)
+    G = len(devs)
+    frames, anchors, infos0 = [], [], None
+    for i, dv in enumerate(devs):
+        d, infos, _, _ = upload_synthetic(torch, synth, W, H, n, i * n, args.lines, args.distinct, torch.device("cuda", dv), 0)
+        frames.append(d)
+        anchors.append(smh.make_anchors([(x["scales_start_y"], x["anchors"]) for x in infos]) if stages & 0x8 else None)
+        infos0 = infos0 or infos
+    node = Node(devs, W, H, n, depth=2)
+    ptrs = [d.data_ptr() for d in frames]
+    counts = [n] * G
+
+    def one_pass():
+        node.run(ptrs, counts, stages=stages, anchors=anchors if stages & 0x8 else None)
+        return node.gather()
+
+    def step():
+        for _ in range(rounds):
+            one_pass()
+
+    for _ in range(args.warmup):
+        step()
+    dts = []
+    for k in sub_regions(args.steps):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        dts.append((time.perf_counter() - t0, k))
+    recs, tot = one_pass()
+    assert tot == n * G, "node gather returned %d records, expected %d" % (tot, n * G)
+    per = smh.results_to_dicts(recs[:tot])
+    rates = [n * G * rounds * k / dt for dt, k in dts]
+    value = median(rates)
+    out = {"metric": "map frames/sec (%dx%d %s), whole job" % (W, H, "full CV pipeline" if stages == 0xF else "stages 0x%x" % stages),
+           "value": value, "unit": "frames/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": n * G * rounds / value * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8/f32", "data": "synthetic",
+           "value_min": min(rates), "value_max": max(rates), "value_whole_region": n * G * rounds * args.steps / sum(dt for dt, _ in dts),
+           "config": {"workload": (cfg["name"] if not custom else "custom: %d x %dx%d frames, stages 0x%x" % (n, W, H, stages)) +
+                                  "; ONE process, smhv_node_run + smhv_node_gather (ncclCommInitAll, one grouped ncclGather per pass)",
+                      "baseline_config": args.config, "frames_per_gpu": n, "global_batch": n * G, "frame": [W, H], "stages": stages,
+                      "passes_per_step": rounds, "frames_per_step": n * G * rounds, "parallelism": "frames block-sharded over %d devices, one process" % G,
+                      "schedule": "smhv_node (one pass in flight per device, records gathered after every pass)"},
+           "per_gpu_frames_per_s": value / G, "all_map_open": bool(all(r["map_open"] for r in per)),
+           "lsd": {"rounds_per_frame": float(np.mean([r["rounds"] for r in per])), "lines_per_frame": float(np.mean([r["n_lines"] for r in per]))}}
+    print(json.dumps(out))
+    node.close()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] index of the workload")
-    ap.add_argument("--frames-per-gpu", type=int, default=None)
-    ap.add_argument("--width", type=int, default=None)
-    ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--stages", type=lambda s: int(s, 0), default=None)
-    ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
-    ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
-    ap.add_argument("--pipeline-depth", type=int, default=4, help="batches in flight (smhv_pipeline_create depth)")
-    ap.add_argument("--tile-cap", type=int, default=0,
-                    help="diagnostic: cap the tile store of k_lsd_tile (smhv_debug_lsd_tile_cap): fewer tiles = less LDS = more workgroups per CU")
-    ap.add_argument("--idle-streams", type=int, default=0,
-                    help="diagnostic: create this many HIP streams before the pipeline (the schedule must not depend on them)")
-    ap.add_argument("--stream-cus", type=int, default=None,
-                    help="CUs of every 32 reserved for the streaming kernels (smhv_pipeline_create_partitioned); default: the library's choice")
-    ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
-    ap.add_argument("--no-stage-timing", action="store_true")
-    ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-box testing of the N>1 code path)")
-    ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
-    ap.add_argument("--ingest-frames", type=int, default=512,
-                    help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1, config 2 only)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.config is None:
+        args.config = 4 if args.gpus > 1 else 2
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.node and args.config != 0:
+        sys.exit(self_launch(args))                    # before anything has touched the GPU
+    if args.node:
+        world = 1
+    elif world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
     cfg = CONFIGS[args.config]
     n = args.frames_per_gpu or cfg["frames"]
     W, H = args.width or cfg["width"], args.height or cfg["height"]
@@ -204,14 +439,28 @@ def main():
     rounds = args.rounds_per_step or cfg["rounds"]
     custom = (n, W, H, stages) != (cfg["frames"], cfg["width"], cfg["height"], cfg["stages"])
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if args.rendezvous_only:                           # the launch / rendezvous path alone (CPU test of the self-launch)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "rank_sum": float(t.item()), "baseline_config": args.config,
+                              "frames_per_gpu": n, "global_batch": n * world}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.config == 0:
+        return config0(args)
+    if args.node:
+        return node_main(args, cfg, n, W, H, stages, rounds, custom)
+
+    import numpy as np
+    import torch
 
     if args.force_device is not None:
         local_rank = args.force_device
@@ -230,12 +479,8 @@ def main():
     from squad_mortar_helper_amd import synth
 
     first = rank * n                                   # block shard of the global batch
-    frames_host = torch.empty((n, H, W, 4), dtype=torch.uint8, pin_memory=True)
-    _, infos = synth.make_batch(W, H, n, first_idx=first, n_lines=args.lines, out=frames_host.numpy())
-    t0 = time.perf_counter()
-    frames = frames_host.cuda(non_blocking=True)
-    torch.cuda.synchronize()
-    h2d_s = time.perf_counter() - t0
+    keep = max(args.cpu_sample, 8) if (rank == 0 and world == 1) else 8
+    frames, infos, frames_host, h2d_s = upload_synthetic(torch, synth, W, H, n, first, args.lines, args.distinct, torch.device("cuda", local_rank), keep)
 
     vision = smh.HipVision.init(local_rank)
     depth = max(1, args.pipeline_depth)
@@ -271,46 +516,63 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()           # all streams of the device
 
+    def timed(p, steps):
+        """`steps` steps as up to five sub-regions, each bracketed by barrier + synchronize on both sides -> per-region
+        (seconds MAX over ranks, steps)."""
+        parts = sub_regions(steps)
+        barrier()
+        dts = []
+        for k in parts:
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step(p)
+            barrier()
+            dts.append(time.perf_counter() - t0)
+        t = torch.tensor(dts, dtype=torch.float64, device="cuda" if nccl else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [(float(x), k) for x, k in zip(t.tolist(), parts)]
+
     for _ in range(args.warmup):
         step()
     barrier()
     if not args.no_stage_timing:
         for b in pipe.slots:
             b.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    regions = timed(pipe, args.steps)
     stages_ms = None
     if not args.no_stage_timing:
         per = [b.stage_ms() for b in pipe.slots[:min(depth, args.steps * rounds)]]
         stages_ms = {k: float(np.mean([p[k] for p in per])) for k in per[0]}
         for b in pipe.slots:
             b.enable_timing(False)
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if nccl else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    frames_per_step = n * world * rounds
+    rates = [frames_per_step * k / dt for dt, k in regions]
+    value = median(rates)
+    dt_total = sum(dt for dt, _ in regions)
+
+    # ---- every slot of the pipeline must hold the same records (same frames, same stages): byte for byte ----
+    used = min(depth, args.steps * rounds + args.warmup * rounds)
+    slot_bytes = [bytes(pipe.slots[s].read_results(0, n)) for s in range(used)]
+    slots_identical = all(sb == slot_bytes[0] for sb in slot_bytes)
+    if not slots_identical:
+        bad = [s for s in range(used) if slot_bytes[s] != slot_bytes[0]]
+        raise SystemExit("bench.py: pipeline slots %s hold records that differ from slot 0's (same frames, same stages)" % bad)
 
     # ---- the same workload with ONE batch in flight, and one pass alone for the per-stage durations in isolation ----
-    value_d1 = ms_d1 = iso_ms = None
+    value_d1 = ms_d1 = iso_ms = d1_minmax = None
     if not args.no_depth1 or not args.no_stage_timing:
         pipe1 = smh.Pipeline(vision, W, H, n, 1)
         if not args.no_depth1:
             k1 = max(2, args.steps // 2)
             for _ in range(2):
                 step(pipe1)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(k1):
-                step(pipe1)
-            barrier()
-            d1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if nccl else "cpu")
-            if world > 1:
-                dist.all_reduce(d1, op=dist.ReduceOp.MAX)
-            ms_d1 = float(d1.item()) / k1 * 1e3
-            value_d1 = n * world * rounds * k1 / float(d1.item())
+            r1 = timed(pipe1, k1)
+            rates1 = [frames_per_step * k / dt for dt, k in r1]
+            value_d1 = median(rates1)
+            d1_minmax = [min(rates1), max(rates1)]
+            ms_d1 = frames_per_step / value_d1 * 1e3
+            assert bytes(pipe1.slots[0].read_results(0, n)) == slot_bytes[0], "the depth-1 pipeline's records differ from the depth-%d pipeline's" % depth
         if not args.no_stage_timing:
             pipe1.slots[0].enable_timing(True)
             for _ in range(3):
@@ -326,10 +588,14 @@ def main():
     ray_steps = float(np.mean([r["ray_steps"] for r in recs]))
     n_lines = float(np.mean([r["n_lines"] for r in recs]))
     all_open = all(r["map_open"] for r in recs)
+    gather_ok = None
     if gather is not None and rank == 0:
-        got = gather.records(0)
+        last_slot = (args.warmup * rounds + args.steps * rounds - 1) % depth
+        got = gather.records(last_slot)
         assert len(got) == n * world, "gather returned %d records, expected %d" % (len(got), n * world)
-        assert all(bytes(got[i]) == bytes(fb.read_results(i, 1)[0]) for i in (0, n - 1)), "rank 0's own block of the gather differs from its records"
+        sz = sdist.RECORD_BYTES
+        gather_ok = bytes(got)[:n * sz] == slot_bytes[0]
+        assert gather_ok, "rank 0's own block of the gather differs from its records"
 
     if rank != 0:
         if world > 1:
@@ -339,26 +605,31 @@ def main():
     x, y, rw, rh = fb.roi
     bw, bh = fb.layout.button[2], fb.layout.button[3]
     kernel_bytes, full_bytes = algorithmic_bytes(rw, rh, bw, bh, stages)
-    total_frames = n * world * rounds * args.steps
-    value = total_frames / dt
     what = "full CV pipeline" if stages == 0xF else ("marker threshold + LSD" if stages == 0x1 else "stages 0x%x" % stages)
     out = {
         "metric": "map frames/sec (%dx%d %s), whole job" % (W, H, what),
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": frames_per_step / value * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/f32", "data": "synthetic",
         "config": {"workload": (cfg["name"] if not custom else "custom: %d x %dx%d frames, stages 0x%x" % (n, W, H, stages)) +
-                               (", RCCL gather of result records" if world > 1 else ""),
+                               (", RCCL gather of result records" if world > 1 and args.config != 4 else ""),
                    "baseline_config": args.config, "frames_per_gpu": n, "global_batch": n * world, "frame": [W, H], "stages": stages,
-                   "passes_per_step": rounds, "frames_per_step": n * world * rounds,
+                   "distinct_frames_per_gpu": (n if args.distinct <= 0 else min(args.distinct, n)),
+                   "passes_per_step": rounds, "frames_per_step": frames_per_step,
                    "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world,
                    "pipeline_depth": depth, "schedule": "smhv_pipeline (library-owned streams, staggered start)"},
-        "ms_per_pass": dt / (args.steps * rounds) * 1e3,
+        "value_is": "median of %d sub-regions of the %d timed steps (each bracketed by barrier + synchronize)" % (len(regions), args.steps),
+        "value_min": min(rates), "value_max": max(rates), "value_whole_region": frames_per_step * args.steps / dt_total,
+        "timed_seconds": dt_total,
+        "ms_per_pass": frames_per_step / value * 1e3 / rounds,
         "per_gpu_frames_per_s": value / world,
-        "value_depth1": value_d1, "ms_per_pass_depth1": (ms_d1 / rounds if ms_d1 is not None else None),
+        "value_depth1": value_d1, "value_depth1_min_max": d1_minmax, "ms_per_pass_depth1": (ms_d1 / rounds if ms_d1 is not None else None),
         "h2d_seconds_for_batch": h2d_s,
         "all_map_open": bool(all_open),
+        "slots_identical": bool(slots_identical), "slots_compared": used,
     }
+    if gather_ok is not None:
+        out["gather_matches_rank0_records"] = bool(gather_ok)
     if stages_ms is not None:
         t_map = stages_ms["map_pass"] * 1e-3
         ach = n * kernel_bytes / t_map / 1e9 if t_map > 0 else 0.0
@@ -366,7 +637,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tj = json.load(f)
-            if tj.get("frame") == [W, H] and stages == tj.get("stages", 0xF) and n == tj.get("frames", n):
+            if tj.get("frame") == [W, H] and stages == tj.get("stages", 0xF):
                 traffic = tj["bytes_per_frame"] * n
                 tsrc = "profiles/traffic.json (committed rocprofv3 PMC run %s: FETCH_SIZE x2 + WRITE_SIZE of the kernel, gfx950 correction)" % tj.get("run", "")
         except (OSError, ValueError, KeyError):
@@ -377,9 +648,9 @@ def main():
                            "algorithmic_bytes_per_frame": kernel_bytes, "launch_ms": stages_ms["map_pass"],
                            "note": "launch duration from hipEvents on the launch's stream inside the timed region: with pipeline_depth > 1 "
                                    "the launches of several batches overlap each other and the other batches' line-segment searches, so a "
-                                   "launch takes longer than the kernel needs (at depth 4: 0.7-0.9 ms against 0.44-0.49 alone) while the "
-                                   "pipeline as a whole moves more bytes per second (pipeline_algorithmic_GBps); roofline_isolated is the same "
-                                   "kernel in a pass that runs alone, with the box's own device-copy rate beside it"}
+                                   "launch takes longer than the kernel needs while the pipeline as a whole moves more bytes per second "
+                                   "(pipeline_algorithmic_GBps); roofline_isolated is the same kernel in a pass that runs alone, with the "
+                                   "box's own device-copy rate beside it"}
         if iso_ms is not None and iso_ms["map_pass"] > 0:
             a2 = n * kernel_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9
             out["roofline_isolated"] = {"kernel": kname, "achieved": a2, "frac": a2 / HBM_PEAK_GBS, "unit": "GB/s",
@@ -387,7 +658,7 @@ def main():
             # calibration on THIS box (they differ by 10 %): a plain device-to-device copy moving the same number of bytes
             # (half read, half written); outside every timed region
             try:
-                half = int(n * kernel_bytes // 2)
+                half = int(min(n, 256) * kernel_bytes // 2)
                 ca = torch.empty(half, dtype=torch.uint8, device="cuda"); cb = torch.empty_like(ca)
                 for _ in range(3):
                     cb.copy_(ca)
@@ -413,19 +684,16 @@ def main():
                       "time_share": stages_ms["lsd"] / max(sum(stages_ms.values()), 1e-9)}
 
     if args.ingest_frames > 0 and world == 1 and args.config == 2 and not custom:
-        out["ingest"] = ingest_leg(smh, vision, pipe, frames_host.numpy(), anchors, stages, args.ingest_frames, W, H, n)
+        out["ingest"] = ingest_leg(smh, torch, vision, pipe, frames_host, anchors, stages, args.ingest_frames, W, H, n)
 
     if args.cpu_sample > 0 and world == 1:
         from oracle import oracle as orc   # CPU baseline leg only (checker, never the product path)
-        k = min(args.cpu_sample, n) if n > 1 else min(args.cpu_sample, 16)
+        k = min(args.cpu_sample, n, len(frames_host)) if n > 1 else min(args.cpu_sample, 16)
         if n == 1:                                         # config 1: more frames of the same kind for a stable figure
             sub, sinfo = synth.make_batch(W, H, k, first_idx=first, n_lines=args.lines)
         else:
-            sub, sinfo = frames_host.numpy()[:k], infos[:k]
-        quota = cpu_quota_cores()
-        cores = min(os.cpu_count() or 1, k)              # threads actually used: one frame per thread at a time
-        if quota:
-            cores = max(1, min(cores, int(quota + 0.5)))  # more threads than the container's CPU quota only time-slice
+            sub, sinfo = frames_host[:k], infos[:k]
+        cores = cpu_threads(k)
         a = np.zeros((k, 3, 3), np.uint32)
         for i in range(k):
             for j, s_ in enumerate(sinfo[i]["anchors"][:3]):
@@ -435,13 +703,18 @@ def main():
         t0 = time.perf_counter()
         res = orc.process_batch(sub, cores, **kw)
         cdt = time.perf_counter() - t0
-        same = n == 1 or all(res[i].n_lines == recs[i]["n_lines"] and res[i].rounds == recs[i]["rounds"] for i in range(k))
+        same = n == 1 or all(records_equal_oracle(np, recs[i], res[i]) for i in range(k))
         split = cpu_stage_split(orc, sub[:8], sinfo[:8])
         out["cpu_baseline"] = {"value": k / cdt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
                                "cpu_quota_cores": cpu_quota_cores(),
                                "single_thread_stage_ms": split, "single_thread_frames_per_s": 1e3 / max(sum(split.values()), 1e-9),
+                               "gpu_records_equal_cpu": bool(same),
                                "sample": "%d frames of rank 0's workload, same stages, C oracle (gcc -O2, -ffp-contract=off), frames parallel across "
-                                         "%d threads; line/round counts match GPU: %s; stage split: median of 8 frames on one thread after an untimed pass" % (k, cores, same)}
+                                         "%d threads; lines (bit-exact), round and mask-pixel counts and m/px of these frames match the GPU records: %s; "
+                                         "stage split: median of 8 frames on one thread after an untimed pass" % (k, cores, same)}
+        if not same:
+            print(json.dumps(out))
+            raise SystemExit("bench.py: GPU records differ from the CPU oracle on the sampled frames")
     print(json.dumps(out))
     pipe.close()
     if world > 1:

@@ -63,8 +63,9 @@ SMHV_API int smhv_thread_ctx(smhv_ctx *ctx);
  * cosf / sinf (vision-cpu/src/lib.rs:398-399), so the reference itself is not bit-stable across platforms.  The library
  * ships the glibc 2.35 values (csrc/ray_table.inc): line end points are bit-exact against a Linux/glibc build of
  * vision-cpu.  A host on another libm (Windows UCRT, musl, ...) passes its own f32::cos / f32::sin values here once
- * after smhv_init to get the same guarantee against its own build.  dx, dy: 3600 floats each; applies to every context
- * on this device; synchronises the device. */
+ * after smhv_init to get the same guarantee against its own build.  dx, dy: 3600 floats each.  The table is per DEVICE: the
+ * call synchronises the device and rebuilds the derived offset tables of every open context on it; no other thread may be
+ * launching line searches on that device while it runs. */
 SMHV_API int smhv_set_ray_table(smhv_ctx *ctx, const float *dx, const float *dy);
 /* thread-local message of the last failing call on this thread ("" if none) */
 SMHV_API const char *smhv_last_error(void);
@@ -157,8 +158,20 @@ typedef struct {
 	float angle[SMHV_MAX_LINES];
 	uint32_t minimap[4];            /* find_minimap: {left, right, top, bottom} in map-ROI coordinates  */
 	uint32_t has_minimap;           /* 1 iff SMHV_STAGE_MINIMAP ran and the map is open                 */
-	uint32_t reserved;
+	uint32_t status;                /* SMHV_FRAME_OK, or why this frame has no valid marker lines (SMHV_FRAME_*) */
 } smhv_frame_result;
+
+/* smhv_frame_result.status.  The reference logs and drops a frame on any Err of a trait method
+ * (src/vision/mod.rs:272-276); a frame whose status is not SMHV_FRAME_OK is to be dropped the same way.
+ *   SMHV_FRAME_LSD_STUCK: the line search's watchdog gave the frame up (its waves made no progress for the spin budget --
+ *   never observed outside the test that lowers the budget).  The record then has n_lines = 0 and rounds = 0xFFFFFFFF; every
+ *   other stage output of the frame (ui_map, mask, ocr, scales, m/px) is valid.  smhv_batch_read_results,
+ *   smhv_pipeline_wait(_all) and smhv_node_gather return SMHV_E_STATE when a frame of the run they cover has a non-zero
+ *   status (the message names the first such frame and carries the watchdog's state dump); the records are still copied
+ *   out, so the caller can drop exactly the frames whose status is set.  The condition is reported once, by the first
+ *   of those calls that sees it. */
+#define SMHV_FRAME_OK 0u
+#define SMHV_FRAME_LSD_STUCK 1u
 
 /* per-frame OCR anchors for SMHV_STAGE_SCALES: OCR (Tesseract) is outside this library */
 typedef struct {
@@ -222,6 +235,10 @@ SMHV_API int smhv_debug_lsd_classic(int on);
  * to 1440p, 541 at 4K; a marker scene has 40-260); a frame with more is searched on the mask in global memory (slow).  The
  * tests lower the cap to run frames through that path. */
 SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
+/* diagnostic (process-wide): idle polls (about 0.25 us each) a wave of k_lsd_tile may spend without progress before the
+ * watchdog gives its frame up (SMHV_FRAME_LSD_STUCK).  0 restores the default (4,000,000: about a second).  The tests lower
+ * it to 1 to force the error path. */
+SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
 /* ---- pipeline: several batches in flight, scheduled by the library ----------------------------------------------
  * `depth` output buffer sets (smhv_batch objects) of max_frames frames, each with its own stream.  The streams are
  * created by the library, in a fixed order, and consecutive submissions are started half a period apart, so the

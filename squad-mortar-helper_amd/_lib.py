@@ -21,6 +21,7 @@ VIEW_NONE, VIEW_OCR_INPUT, VIEW_FIND_SCALES_INPUT, VIEW_LSD_PREPROCESS, VIEW_LSD
 IMAGE_UI_MAP = 100
 
 E_INVALID, E_GEOMETRY, E_HIP, E_NO_DEVICE, E_STATE = -1, -2, -3, -4, -5
+FRAME_OK, FRAME_LSD_STUCK = 0, 1          # smhv_frame_result.status
 
 
 class Line(C.Structure):
@@ -34,7 +35,7 @@ class FrameResult(C.Structure):
         ("mpx", C.c_double), ("has_mpx", C.c_uint32), ("n_mask_px", C.c_uint32),
         ("red_pixels", C.c_uint32), ("rounds", C.c_uint32), ("ray_steps", C.c_uint64),
         ("length_px", C.c_double * MAX_LINES), ("meters", C.c_double * MAX_LINES), ("angle", C.c_float * MAX_LINES),
-        ("minimap", C.c_uint32 * 4), ("has_minimap", C.c_uint32), ("reserved", C.c_uint32),
+        ("minimap", C.c_uint32 * 4), ("has_minimap", C.c_uint32), ("status", C.c_uint32),
     ]
 
 
@@ -108,6 +109,7 @@ SIGNATURES = {
     "smhv_node_gather": (C.c_int, [C.c_void_p, C.POINTER(FrameResult), C.POINTER(C.c_uint32)]),
     "smhv_debug_lsd_classic": (C.c_int, [C.c_int]),
     "smhv_debug_lsd_tile_cap": (C.c_int, [C.c_uint32]),
+    "smhv_debug_lsd_spin_limit": (C.c_int, [C.c_uint32]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "smhv_ingest_destroy": (None, [C.c_void_p]),

@@ -34,7 +34,9 @@ def results_to_dicts(recs):
             rounds=int(r.rounds), ray_steps=int(r.ray_steps),
             length_px=np.array(r.length_px[:n], np.float64), meters=np.array(r.meters[:n], np.float64),
             angle=np.array(r.angle[:n], np.float32),
-            minimap=(tuple(r.minimap) if r.has_minimap else None)))
+            minimap=(tuple(r.minimap) if r.has_minimap else None),
+            status=int(r.status), error=(None if r.status == L.FRAME_OK else "line search gave the frame up (SMHV_FRAME_LSD_STUCK)" if r.status == L.FRAME_LSD_STUCK
+                                         else "status %d" % r.status)))
     return out
 
 
@@ -107,10 +109,15 @@ class FrameBatch:
         L.check(self._lib.smhv_batch_device_ptrs(self._b, *[C.byref(x) for x in p]))
         return dict(zip(("results", "ui", "mask", "ocr", "scales", "bits"), [x.value for x in p]))
 
-    def read_results(self, first=0, n=None):
+    def read_results(self, first=0, n=None, check=True):
+        """Synchronising host copy of the records.  A frame the library gave up (status != 0 in its record) makes the call
+        raise VisionError(E_STATE) -- the reference drops a frame on any Err (src/vision/mod.rs:272-276); check=False returns
+        the records regardless, for a caller that drops exactly those frames."""
         n = self.max_frames - first if n is None else n
         recs = (L.FrameResult * n)()
-        L.check(self._lib.smhv_batch_read_results(self._b, first, n, recs))
+        rc = self._lib.smhv_batch_read_results(self._b, first, n, recs)
+        if rc != 0 and not (rc == L.E_STATE and not check):
+            L.check(rc)
         return recs
 
     def read_image(self, which, frame):

@@ -75,7 +75,18 @@ struct LsdCoopBufs {
 	uint32_t epoch;
 };
 
+// Error mailbox of a batch: pinned host memory mapped into the device, written by the device only when a frame fails
+// (SMHV_FRAME_*), read by the host after it has synchronised with the run (smhv_batch_read_results, smhv_pipeline_wait,
+// smhv_node_gather).  Sticky until reported.
+struct BatchError {
+	uint32_t count;          // frames whose status is not SMHV_FRAME_OK since the last report
+	uint32_t frame, status;  // the first of them
+	uint32_t info[8];        // SMHV_FRAME_LSD_STUCK: head, tail, disp_e, disp_end, n_lines, rounds, spec, state of the head slot
+	uint32_t pad[5];
+};
+
 struct Buffers {
+	BatchError *err;         // device address of the batch's mailbox (null: none)
 	const uint8_t *frames;   // n * frame_bytes
 	uint8_t *ui, *mask, *ocr, *scales;
 	uint32_t *bits;
@@ -139,6 +150,8 @@ size_t lsd_lds_bytes();
 void lsd_set_classic(bool on);
 // diagnostic: cap the tile store of k_lsd_tile (0 = what fits), to exercise the path of frames with more tiles than that
 void lsd_set_tile_cap(uint32_t cap);
+// diagnostic: watchdog budget of k_lsd_tile in idle polls (0 = default)
+void lsd_set_spin_limit(uint32_t polls);
 // overwrite the 3600 ray directions of the current device's code object (synchronous)
 hipError_t set_ray_table(const float *dx, const float *dy);
 // CRC-32 of n_dwords 32-bit words at d_msg, xor-ed into *d_acc (zero it first) WITHOUT the init / final-xor terms:

@@ -870,7 +870,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		if (tid == 0) {
 			res->lines[0].x0 = spx; res->lines[0].y0 = spy; res->lines[0].x1 = sh.cand_end[0][0]; res->lines[0].y1 = sh.cand_end[0][1];
 			res->length_px[0] = (double)__uint_as_float((uint32_t)(sh.cand_best[0] >> 32));
-			res->n_lines = 1; res->rounds = 1; res->ray_steps = sh.cand_steps[0];
+			res->n_lines = 1; res->rounds = 1; res->ray_steps = sh.cand_steps[0]; res->status = SMHV_FRAME_OK;
 		}
 		return;
 	}
@@ -1065,7 +1065,7 @@ __device__ void lsd_frame(const Geom &g, const Buffers &b, uint32_t f, float max
 		res->lines[tid].x0 = sh.lines[tid][0]; res->lines[tid].y0 = sh.lines[tid][1];
 		res->lines[tid].x1 = sh.lines[tid][2]; res->lines[tid].y1 = sh.lines[tid][3];
 	}
-	if (tid == 0) { res->n_lines = n_lines; res->rounds = rounds; res->ray_steps = steps; }
+	if (tid == 0) { res->n_lines = n_lines; res->rounds = rounds; res->ray_steps = steps; res->status = SMHV_FRAME_OK; }
 	PROF_STORE(res);
 }
 
@@ -1201,7 +1201,7 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 			// touched only by the kernel that owns the frame -- lsd_frame always stores n_lines / rounds / ray_steps at its end --
 			// and frames nobody searches (map closed, empty mask) are zeroed by the ROWS kernel alone.
 			if (!aux.open || aux.n_mask_px == 0) {
-				if (MODE == LSD_MODE_ROWS && threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; }
+				if (MODE == LSD_MODE_ROWS && threadIdx.x == 0) { b.results[f].n_lines = 0; b.results[f].rounds = 0; b.results[f].ray_steps = 0; b.results[f].status = SMHV_FRAME_OK; }
 				mine = false;
 			}
 		}
@@ -1288,6 +1288,8 @@ static std::atomic<bool> &lsd_classic_flag() {
 void lsd_set_classic(bool on) { lsd_classic_flag().store(on, std::memory_order_relaxed); }
 static std::atomic<uint32_t> g_tile_cap_override{0};
 void lsd_set_tile_cap(uint32_t cap) { g_tile_cap_override.store(cap, std::memory_order_relaxed); }
+static std::atomic<uint32_t> g_spin_limit{W_SPIN_LIMIT_DEFAULT};
+void lsd_set_spin_limit(uint32_t polls) { g_spin_limit.store(polls ? polls : W_SPIN_LIMIT_DEFAULT, std::memory_order_relaxed); }
 
 bool lsd_rows_only(const Geom &g) { return (g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP; }
 
@@ -1319,7 +1321,7 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		const uint32_t cap_o = g_tile_cap_override.load(std::memory_order_relaxed);
 		const uint32_t cap = cap_o ? std::min(cap_o, tile_cap_for(g)) : tile_cap_for(g);
 		const unsigned t_lds = (tile_mask_words(g.rw, g.rh, cap) + 2u * LSD_LIST_CAP) * 4u;
-		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap);
+		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed));
 		return hipGetLastError();
 	}
 	if (coop) {

@@ -223,7 +223,7 @@ __device__ __forceinline__ void finalize_body(const Geom &g, const Buffers &b, u
 		res->red_pixels = aux.red;
 		if (!(open && markers)) { res->rounds = 0; res->ray_steps = 0; }
 		if (!(stages & SMHV_STAGE_MINIMAP)) { res->has_minimap = 0; res->minimap[0] = 0; res->minimap[1] = 0; res->minimap[2] = 0; res->minimap[3] = 0; }
-		res->reserved = 0;
+		if (!(open && markers)) res->status = SMHV_FRAME_OK;          // otherwise the line search's verdict stands
 	}
 }
 

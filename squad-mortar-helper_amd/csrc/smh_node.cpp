@@ -151,35 +151,62 @@ extern "C" SMHV_API int smhv_node_ctx(smhv_node *nd, uint32_t i, smhv_ctx **ctx,
 extern "C" SMHV_API int smhv_node_run(smhv_node *nd, const void *const *d_frames, const uint32_t *n, uint32_t stages, int grayscale, uint32_t max_gap,
                                       const smhv_anchors *const *anchors) {
 	if (!nd || !d_frames || !n) return smhv_internal_fail(SMHV_E_INVALID, "node_run: null argument");
-	for (size_t i = 0; i < nd->devices.size(); ++i) {
+	const size_t nd_n = nd->devices.size();
+	for (size_t i = 0; i < nd_n; ++i) {                            // nothing is submitted unless every shard is acceptable
 		if (n[i] > nd->max_frames) return smhv_internal_fail(SMHV_E_INVALID, "node_run: %u frames on device %zu, capacity %u", n[i], i, nd->max_frames);
-		nd->n_last[i] = n[i];
-		if (n[i] == 0) continue;
-		int rc = smhv_pipeline_submit(nd->pipe[i], d_frames[i], n[i], stages, grayscale, max_gap, anchors ? anchors[i] : nullptr, nullptr, &nd->slot_last[i]);
-		if (rc) return rc;
+		if (n[i] && !d_frames[i]) return smhv_internal_fail(SMHV_E_INVALID, "node_run: null frame pointer for device %zu", i);
 	}
+	std::vector<uint32_t> slot(nd->slot_last);
+	for (size_t i = 0; i < nd_n; ++i) {
+		if (n[i] == 0) continue;
+		int rc = smhv_pipeline_submit(nd->pipe[i], d_frames[i], n[i], stages, grayscale, max_gap, anchors ? anchors[i] : nullptr, nullptr, &slot[i]);
+		if (rc) return rc;                                         // the run is void: smhv_node_gather keeps returning the previous complete run
+	}
+	// committed only now: a gather never mixes the counts of a failed run with the slots of the one before
+	for (size_t i = 0; i < nd_n; ++i) { nd->n_last[i] = n[i]; nd->slot_last[i] = slot[i]; }
 	return SMHV_OK;
 }
+
+extern "C" int smhv_internal_batch_check(smhv_batch *b, const char *what);     // smh_runtime.cpp: frames that failed (SMHV_FRAME_*)
 
 extern "C" SMHV_API int smhv_node_gather(smhv_node *nd, smhv_frame_result *out, uint32_t *n_total) {
 	if (!nd || !out) return smhv_internal_fail(SMHV_E_INVALID, "node_gather: null argument");
 	const size_t nd_n = nd->devices.size();
-	const size_t per = sizeof(smhv_frame_result) * (size_t)nd->max_frames;
-	// one ncclGather over all devices (group: a single thread issues every rank's call), each on its device's gather stream,
-	// ordered after that device's most recent pass
-	NCCLCHK(nd, nd->rccl.GroupStart());
+	// ncclGather moves the same count from every rank: the largest shard of the run (the records behind a shorter shard's
+	// own are stale padding and are dropped below), not the capacity
+	uint32_t n_max = 0;
+	for (size_t i = 0; i < nd_n; ++i) n_max = nd->n_last[i] > n_max ? nd->n_last[i] : n_max;
+	if (n_total) *n_total = 0;
+	if (n_max == 0) return SMHV_OK;
+	const size_t per = sizeof(smhv_frame_result) * (size_t)n_max;
+	// everything that can fail without RCCL comes first: each device's gather stream is ordered after that device's most
+	// recent pass, and the send pointers are looked up
+	std::vector<void *> src(nd_n, nullptr);
+	std::vector<smhv_batch *> batch(nd_n, nullptr);
 	for (size_t i = 0; i < nd_n; ++i) {
 		HIPCHK(hipSetDevice(nd->devices[i]));
-		smhv_batch *b = nullptr; void *st = nullptr; void *d_results = nullptr;
-		int rc = smhv_pipeline_slot(nd->pipe[i], nd->slot_last[i], &b, &st);
+		void *st = nullptr;
+		int rc = smhv_pipeline_slot(nd->pipe[i], nd->slot_last[i], &batch[i], &st);
 		if (rc) return rc;
-		rc = smhv_batch_device_ptrs(b, &d_results, nullptr, nullptr, nullptr, nullptr, nullptr);
+		rc = smhv_batch_device_ptrs(batch[i], &src[i], nullptr, nullptr, nullptr, nullptr, nullptr);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(nd->gdone[i], (hipStream_t)st));
 		HIPCHK(hipStreamWaitEvent(nd->gstream[i], nd->gdone[i], 0));
-		NCCLCHK(nd, nd->rccl.Gather(d_results, i == 0 ? (void *)nd->d_gather : nullptr, per, ncclUint8, 0, nd->comm[i], nd->gstream[i]));
 	}
-	NCCLCHK(nd, nd->rccl.GroupEnd());
+	// one ncclGather over all devices (group: a single thread issues every rank's call).  The group is closed on every
+	// path: an open group would swallow every later RCCL call of this thread (including those of a host framework that
+	// shares the library).
+	ncclResult_t first = ncclSuccess;
+	hipError_t hfirst = hipSuccess;
+	NCCLCHK(nd, nd->rccl.GroupStart());
+	for (size_t i = 0; i < nd_n && first == ncclSuccess && hfirst == hipSuccess; ++i) {
+		hfirst = hipSetDevice(nd->devices[i]);
+		if (hfirst == hipSuccess) first = nd->rccl.Gather(src[i], i == 0 ? (void *)nd->d_gather : nullptr, per, ncclUint8, 0, nd->comm[i], nd->gstream[i]);
+	}
+	const ncclResult_t end = nd->rccl.GroupEnd();
+	if (hfirst != hipSuccess) return smhv_internal_fail(SMHV_E_HIP, "node_gather: hipSetDevice failed: %s", hipGetErrorString(hfirst));
+	if (first != ncclSuccess) return smhv_internal_fail(SMHV_E_HIP, "node_gather: ncclGather failed: %s", nd->rccl.GetErrorString(first));
+	if (end != ncclSuccess) return smhv_internal_fail(SMHV_E_HIP, "node_gather: ncclGroupEnd failed: %s", nd->rccl.GetErrorString(end));
 	for (size_t i = 0; i < nd_n; ++i) {                             // each slot's next pass waits for the gather that reads its records
 		int rc = smhv_pipeline_hold(nd->pipe[i], nd->slot_last[i], nd->gstream[i]);
 		if (rc) return rc;
@@ -189,9 +216,16 @@ extern "C" SMHV_API int smhv_node_gather(smhv_node *nd, smhv_frame_result *out, 
 	HIPCHK(hipStreamSynchronize(nd->gstream[0]));
 	uint32_t k = 0;
 	for (size_t i = 0; i < nd_n; ++i) {                             // compact: device i contributed n_last[i] records
-		memcpy(out + k, nd->h_gather + i * (size_t)nd->max_frames, sizeof(smhv_frame_result) * nd->n_last[i]);
+		memcpy(out + k, nd->h_gather + i * (size_t)n_max, sizeof(smhv_frame_result) * nd->n_last[i]);
 		k += nd->n_last[i];
 	}
 	if (n_total) *n_total = k;
+	// frames that failed on any device (their records carry the status; the root's copy above is complete either way).  The
+	// gather on the root's stream finished after every peer's send, i.e. after every device's pass.
+	for (size_t i = 0; i < nd_n; ++i) {
+		if (nd->n_last[i] == 0) continue;
+		const int r = smhv_internal_batch_check(batch[i], "node_gather");
+		if (r) return r;                                           // (a later device's failures are reported by the next call)
+	}
 	return SMHV_OK;
 }

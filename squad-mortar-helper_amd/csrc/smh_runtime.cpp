@@ -142,6 +142,7 @@ struct smhv_batch {
 	FrameAux *d_aux = nullptr;
 	smhv_frame_result *d_results = nullptr;   // max_frames (+3 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
+	BatchError *h_err = nullptr, *d_err = nullptr;   // error mailbox: pinned host memory and its device address (smh_kernels.h)
 	// k_lsd cooperation (smh_kernels.h): [LsdCtl][LsdCoop x n] zeroed per launch, request rings, result caches
 	uint8_t *d_lsd_ctl = nullptr;
 	uint32_t *d_lsd_req = nullptr;
@@ -206,6 +207,10 @@ struct smhv_ctx {
 	std::atomic<int> refs{1};
 	std::atomic<bool> closed{false};
 };
+
+// Open contexts (smhv_set_ray_table rebuilds the offset tables of every context on the device whose ray directions change)
+static std::mutex g_ctx_mu;
+static std::vector<smhv_ctx *> g_ctx_open;
 
 static void ctx_release(smhv_ctx *c) {
 	if (c && c->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete c;
@@ -278,6 +283,7 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
+	bf.err = b->d_err;
 	bf.cull_tab = nullptr;
 	bf.ray_off = b->ctx->d_ray_off;
 	bf.frames = frames;
@@ -330,12 +336,17 @@ extern "C" SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out) {
 		return fail(SMHV_E_HIP, "context setup failed: %s", hipGetErrorString(he));
 	}
 	logf(c, 3, "smh_vision_hip ready on device %d (%s, %d CUs)", device, prop.gcnArchName, prop.multiProcessorCount);
+	{ std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctx_open.push_back(c); }
 	*out = c;
 	return SMHV_OK;
 }
 
 extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
 	if (!c || c->closed.exchange(true, std::memory_order_acq_rel)) return;
+	{
+		std::lock_guard<std::mutex> lk(g_ctx_mu);
+		for (size_t i = 0; i < g_ctx_open.size(); ++i) if (g_ctx_open[i] == c) { g_ctx_open.erase(g_ctx_open.begin() + (long)i); break; }
+	}
 	(void)hipSetDevice(c->device);
 	(void)hipDeviceSynchronize();
 	if (c->fb) { smhv_batch_destroy(c->fb); c->fb = nullptr; }
@@ -376,6 +387,11 @@ extern "C" SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap) {
 	return SMHV_OK;
 }
 
+extern "C" SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls) {
+	lsd_set_spin_limit(polls);
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_set_ray_table(smhv_ctx *c, const float *dx, const float *dy) {
 	if (!c || !dx || !dy) return fail(SMHV_E_INVALID, "bad arguments");
 	CTX_OPEN(c);
@@ -385,10 +401,14 @@ extern "C" SMHV_API int smhv_set_ray_table(smhv_ctx *c, const float *dx, const f
 		if (!(std::fabs((double)dx[i] - std::cos(a)) < 1e-5 && std::fabs((double)dy[i] - std::sin(a)) < 1e-5))
 			return fail(SMHV_E_INVALID, "ray table entry %d is not (cos, sin) of %.1f degrees", i, i / 10.0);
 	}
+	// The directions are a device global of the code object, the accumulated offsets derived from them a buffer of each
+	// context: both change together, for every open context on this device, or a line search would mix two tables.
+	std::lock_guard<std::mutex> lk(g_ctx_mu);                 // (smhv_init / smhv_shutdown of other contexts wait)
 	HIPCHK(hipSetDevice(c->device));
 	HIPCHK(hipDeviceSynchronize());                           // no k_lsd launch may be reading the table
 	HIPCHK(set_ray_table(dx, dy));
-	HIPCHK(launch_build_ray_offsets(c->d_ray_off, c->s_main));   // note: other contexts on this device keep their (now stale) tables: call it on each
+	for (smhv_ctx *o : g_ctx_open)
+		if (o->device == c->device && o->d_ray_off) HIPCHK(launch_build_ray_offsets(o->d_ray_off, c->s_main));
 	HIPCHK(hipStreamSynchronize(c->s_main));
 	return SMHV_OK;
 }
@@ -440,7 +460,10 @@ static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_f
 	ALLOC0(b->d_lsd_cache, sizeof(LsdCacheEntry) * SMH_LSD_CACHE_SLOTS * n);
 #undef ALLOC0
 	{
-		hipError_t e = hipEventCreateWithFlags(&b->ev_map_done, hipEventDisableTiming);
+		// the error mailbox lives in host memory: the device writes it only when a frame fails, the host reads it for free
+		hipError_t e = hipHostMalloc((void **)&b->h_err, sizeof(BatchError), hipHostMallocMapped | hipHostMallocCoherent);
+		if (e == hipSuccess) { memset(b->h_err, 0, sizeof(BatchError)); e = hipHostGetDevicePointer((void **)&b->d_err, b->h_err, 0); }
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_map_done, hipEventDisableTiming);
 		// Only for frame sizes that need them: a process has few hardware queues, and every extra stream makes it more
 		// likely that two independent branches share one (measured: 10 % off the pipelined 1080p throughput).
 		if (max_frames > 1 && !lsd_rows_only(b->g)) {
@@ -464,6 +487,7 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	                b->d_lsd_ctl, b->d_lsd_req, b->d_lsd_cache};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
+	if (b->h_err) (void)hipHostFree(b->h_err);
 	for (auto &a : b->anchor_stage) {
 		if (a.h) (void)hipHostFree(a.h);
 		if (a.done) (void)hipEventDestroy(a.done);
@@ -485,6 +509,23 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	ctx_release(b->ctx);
 	delete b;
 }
+
+// Frames that failed since the last report (smh_vision_hip.h, SMHV_FRAME_*).  The caller has synchronised with the run.
+static int batch_check_errors(smhv_batch *b, const char *what) {
+	BatchError *e = b->h_err;
+	if (!e) return SMHV_OK;
+	const uint32_t count = __atomic_load_n(&e->count, __ATOMIC_ACQUIRE);
+	if (count == 0) return SMHV_OK;
+	const BatchError snap = *e;
+	memset(e, 0, sizeof *e);                                  // reported once
+	logf(b->ctx, 1, "%s: %u frame(s) failed, first: frame %u status %u", what, count, snap.frame, snap.status);
+	if (snap.status == SMHV_FRAME_LSD_STUCK)
+		return fail(SMHV_E_STATE, "%s: %u frame(s) without marker lines (status != 0 in their records); first: frame %u, line search gave up "
+		            "(SMHV_FRAME_LSD_STUCK: head %u tail %u list %u/%u lines %u rounds %u spec %u head-state %u)", what, count, snap.frame,
+		            snap.info[0], snap.info[1], snap.info[2], snap.info[3], snap.info[4], snap.info[5], snap.info[6], snap.info[7]);
+	return fail(SMHV_E_STATE, "%s: %u frame(s) failed; first: frame %u, status %u", what, count, snap.frame, snap.status);
+}
+extern "C" int smhv_internal_batch_check(smhv_batch *b, const char *what) { return b ? batch_check_errors(b, what) : SMHV_OK; }   // smh_node.cpp
 
 extern "C" SMHV_API int smhv_batch_layout_get(smhv_batch *b, smhv_batch_layout *o) {
 	if (!b || !o) return fail(SMHV_E_INVALID, "bad arguments");
@@ -652,7 +693,7 @@ extern "C" SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, u
 	HIPCHK(hipSetDevice(b->ctx->device));
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(out, b->d_results + first, sizeof(smhv_frame_result) * n, hipMemcpyDeviceToHost));
-	return SMHV_OK;
+	return batch_check_errors(b, "batch_read_results");       // (the records are in `out` either way)
 }
 
 // Tight host copy (rows x width bytes) of a pitched device image.  hipMemcpy2D turns into one small transfer per row
@@ -843,14 +884,21 @@ extern "C" SMHV_API int smhv_pipeline_wait(smhv_pipeline *p, uint32_t slot) {
 	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_wait: bad arguments");
 	HIPCHK(hipSetDevice(p->ctx->device));
 	HIPCHK(hipEventSynchronize(p->done[slot]));
-	return SMHV_OK;
+	return batch_check_errors(p->batch[slot], "pipeline_wait");
 }
 
 extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
 	if (!p) return fail(SMHV_E_INVALID, "null pipeline");
 	HIPCHK(hipSetDevice(p->ctx->device));
 	for (uint32_t i = 0; i < p->depth; ++i) HIPCHK(hipEventSynchronize(p->done[i]));
-	return SMHV_OK;
+	int rc = SMHV_OK;
+	for (uint32_t i = 0; i < p->depth; ++i) {                 // every slot is checked (and cleared); the first failure is the one returned
+		std::string keep = t_last_error;
+		const int r = batch_check_errors(p->batch[i], "pipeline_wait_all");
+		if (r && !rc) rc = r;
+		else if (r) t_last_error = keep;
+	}
+	return rc;
 }
 
 extern "C" SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream) {

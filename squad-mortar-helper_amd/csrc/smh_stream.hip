@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 		if (r + 12 > re) break;
 	}
 	// the clamped loads of the sets nobody consumed are still in flight: their registers must not be reused before they land
-	asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(S1[0]), "+v"(S1[1]), "+v"(S1[2]), "+v"(S1[3]),
+	asm volatile("s_waitcnt vmcnt(0) ; smh-drain" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(S1[0]), "+v"(S1[1]), "+v"(S1[2]), "+v"(S1[3]),
 	             "+v"(S2[0]), "+v"(S2[1]), "+v"(S2[2]), "+v"(S2[3]) : : "memory");
 
 	// ---- lane / wave neighbours of the column masks: marker dilation (P) and the 7-row-dilated white masks (V) ----

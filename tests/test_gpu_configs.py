@@ -427,23 +427,154 @@ def test_pipeline_object_gives_the_records_of_plain_runs(vision):
     del idle
 
 
+def _oracle_batch(frames, infos, stages=0xF):
+    k = len(frames)
+    a9 = np.zeros((k, 3, 3), np.uint32)
+    for i in range(k):
+        for j, sc in enumerate(infos[i]["anchors"][:3]):
+            a9[i, j] = sc
+    return o.process_batch(frames, min(os.cpu_count() or 1, k), stages=stages, anchors=a9, n_anchors=len(infos[0]["anchors"]),
+                           scales_start_y=infos[0]["scales_start_y"])
+
+
+@pytest.mark.parametrize("W,H,N", [(1920, 1080, 256), (2560, 1440, 128)])
+def test_headline_configuration_pipelined_depth4(vision, W, H, N):
+    """The EXACT configuration bench.py's `value` is measured on (BASELINE configs[2] / configs[3]): N resident frames,
+    smhv_pipeline with four batches in flight (k_lsd_tile, 512-thread workgroups, two per CU), twelve submissions back to
+    back.  Every slot's N records must equal, byte for byte, a plain smhv_batch_run of the same frames (k_lsd_tile with
+    1024-thread workgroups, nothing beside it), the depth-1 pipeline (k_lsd with helper workgroups at 1080p) must give them
+    too, and eight frames spread over the batch are checked against the oracle field by field."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    frames, infos = synth.make_batch(W, H, N, first_idx=0)            # the bench's own frames (rank 0)
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
+    want_raw = fb.read_results(0, N)
+    want = bytes(want_raw)
+    recs = smh.results_to_dicts(want_raw)
+    fb.close()
+    pipe = smh.Pipeline(vision, W, H, N, 4)
+    for j in range(12):
+        assert pipe.submit(d.data_ptr(), N, anchors=anchors) == j % 4
+    pipe.wait()
+    for s_ in range(4):
+        assert bytes(pipe.slots[s_].read_results(0, N)) == want, "slot %d of the depth-4 pipeline differs from the plain run" % s_
+    pipe.close()
+    pipe1 = smh.Pipeline(vision, W, H, N, 1)
+    for _ in range(2):
+        pipe1.submit(d.data_ptr(), N, anchors=anchors)
+    pipe1.wait()
+    assert bytes(pipe1.slots[0].read_results(0, N)) == want, "the depth-1 pipeline differs from the plain run"
+    pipe1.close()
+    pick = [0, 1, N // 5, N // 3, N // 2, N // 2 + 7, N - 2, N - 1]
+    ref = _oracle_batch(np.ascontiguousarray(frames[pick]), [infos[i] for i in pick])
+    for r, i in zip(ref, pick):
+        g = recs[i]
+        assert g["map_open"] == 1 and g["status"] == 0
+        assert np.array_equal(g["lines"], _lines(r)) and g["rounds"] == r.rounds and g["n_mask_px"] == r.n_mask_px, i
+        assert g["mpx"] == (r.mpx if r.has_mpx else None), i
+        for k in range(r.n_lines):                                      # derived f64 / f32 outputs: the north star's 1e-4
+            x0, y0, x1, y1 = [float(v) for v in _lines(r)[k]]
+            assert abs(g["length_px"][k] - np.hypot(x0 - x1, y0 - y1)) <= TOL and abs(g["angle"][k] - np.arctan2(np.float32(y0 - y1), np.float32(x0 - x1))) <= TOL
+
+
+def test_line_search_watchdog_becomes_an_error(vision):
+    """A frame the line search gives up (its waves made no progress for the spin budget) must not pass as "no marker
+    lines": the record carries status = SMHV_FRAME_LSD_STUCK (n_lines 0, rounds 0xFFFFFFFF), and read_results /
+    pipeline_wait return SMHV_E_STATE naming the frame -- once; the reference logs and drops such a frame
+    (src/vision/mod.rs:272-276).  Forced here by a spin budget of one poll; with the default budget the same batch is clean."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    lib = smh._lib.load()
+    W, H, N = 1920, 1080, 32
+    frames, infos = synth.make_batch(W, H, N, first_idx=300, n_lines=3)
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    st = torch.cuda.current_stream().cuda_stream
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=st)
+    clean = fb.read_results(0, N)
+    clean_b = bytes(clean)
+    assert all(r.status == 0 for r in clean)
+    lib.smhv_debug_lsd_spin_limit(1)
+    try:
+        fb.run(d.data_ptr(), N, anchors=anchors, stream=st)
+        with pytest.raises(smh.VisionError) as ei:
+            fb.read_results(0, N)
+        assert ei.value.code == smh._lib.E_STATE and "SMHV_FRAME_LSD_STUCK" in str(ei.value) and "frame" in str(ei.value)
+        recs = fb.read_results(0, N, check=False)                       # reported once; the records are there either way
+        stuck = [i for i in range(N) if recs[i].status == smh._lib.FRAME_LSD_STUCK]
+        assert stuck, "a spin budget of one poll did not trip the watchdog on any of %d frames" % N
+        dd = smh.results_to_dicts(recs)
+        for i in range(N):
+            if i in stuck:
+                assert recs[i].n_lines == 0 and recs[i].rounds == 0xFFFFFFFF and dd[i]["error"]
+                # everything but the line search is valid for such a frame
+                assert recs[i].map_open == 1 and recs[i].n_mask_px == clean[i].n_mask_px and recs[i].mpx == clean[i].mpx
+            else:
+                assert dd[i]["error"] is None and bytes(recs[i]) == bytes(clean[i])
+        # the pipeline reports it from wait()
+        pipe = smh.Pipeline(vision, W, H, N, 3)
+        slot = pipe.submit(d.data_ptr(), N, anchors=anchors)
+        with pytest.raises(smh.VisionError) as ei:
+            pipe.wait(slot)
+        assert ei.value.code == smh._lib.E_STATE
+        pipe.wait(slot)                                                 # reported once
+        lib.smhv_debug_lsd_spin_limit(0)
+        slot = pipe.submit(d.data_ptr(), N, anchors=anchors)
+        pipe.wait(slot)
+        assert bytes(pipe.slots[slot].read_results(0, N)) == clean_b
+        pipe.close()
+    finally:
+        lib.smhv_debug_lsd_spin_limit(0)
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=st)
+    assert bytes(fb.read_results(0, N)) == clean_b
+    fb.close()
+
+
 def test_bench_two_ranks_on_one_gpu_over_gloo(vision):
-    """bench.py's N > 1 path (block shard, per-pass gather of the records on the slot's stream, MAX-over-ranks timing) with
-    two ranks sharing this GPU over gloo: the JSON line must report both ranks' frames."""
+    """bench.py's N > 1 path started the way the driver starts it -- `python bench.py --gpus 2`, no launcher in front: it
+    launches its own two ranks (block shard, per-pass gather of the records on the slot's stream, MAX-over-ranks timing of
+    every sub-region), here sharing this box's one GPU over gloo.  The JSON line must report both ranks' frames, and the
+    gathered records of rank 0's block must be its own."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29741",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-gpu", "16", "--rounds-per-step", "2",
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--frames-per-gpu", "16", "--rounds-per-step", "2",
            "--dist-backend", "gloo", "--force-device", "0", "--cpu-sample", "0", "--ingest-frames", "0"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0 and out["value_depth1"] > 0
-    assert out["config"]["frames_per_step"] == 64 and out["scaling"] == "weak"
+    assert out["config"]["frames_per_step"] == 64 and out["scaling"] == "weak" and out["config"]["baseline_config"] == 4
+    assert out["slots_identical"] and out["gather_matches_rank0_records"] and out["value_min"] <= out["value"] <= out["value_max"]
+
+
+def test_bench_node_leg_and_config0(vision):
+    """bench.py --node (one process, smhv_node_run + smhv_node_gather per pass; a world of one on this box) and
+    bench.py --config 0 (the reference's sample screenshot through the C oracle beside the GPU trait path)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--node", "--gpus", "1", "--config", "4", "--frames-per-gpu", "24", "--steps", "5",
+                        "--warmup", "1", "--rounds-per-step", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["all_map_open"] and "smhv_node" in out["config"]["schedule"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["cases"][0]["size"] == [2560, 1440] and out["cases"][0]["gpu_lines_equal_cpu"] and out["cases"][1]["gpu_lines_equal_cpu"]
+    assert set(out["cases"][0]["cpu_single_thread_stage_ms"]) == {"crop_to_map", "threshold_dilate", "lsd", "ocr_preprocess", "find_scales_preprocess"}
 
 
 def test_node_entry_points_on_one_gpu(vision):

@@ -79,6 +79,10 @@ def test_record_layout_matches_header(built):
     assert _lib.FrameResult.lines.offset == 8 and _lib.FrameResult.mpx.offset == 520
     assert _lib.FrameResult.ray_steps.offset == 544 and _lib.FrameResult.length_px.offset == 552
     assert C.sizeof(_lib.Anchors) == 44 and C.sizeof(_lib.Line) == 16
+    # the per-frame status word (SMHV_FRAME_*) is the record's last field; the header's values are the binding's
+    assert _lib.FrameResult.status.offset == 1212 and (_lib.FRAME_OK, _lib.FRAME_LSD_STUCK) == (0, 1)
+    hdr = open(os.path.join(ROOT, "include", "smh_vision_hip.h")).read()
+    assert "#define SMHV_FRAME_OK 0u" in hdr and "#define SMHV_FRAME_LSD_STUCK 1u" in hdr and "uint32_t status;" in hdr
 
 
 def test_shard_range_partitions_exactly(built):
@@ -146,6 +150,25 @@ def test_gather_of_result_records_gloo_world2(built, tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "GATHER_OK" in p.stdout
+
+
+def test_bench_launches_its_own_ranks(built):
+    """`python bench.py --gpus 2` with no launcher in front (how the driver starts it) must start its two ranks itself -- as a
+    child process, before anything touches the GPU -- and relay rank 0's JSON line and exit code.  --rendezvous-only stops
+    after the ranks have met over gloo (no GPU here); the GPU suite runs the same launch with the real workload.  With
+    --gpus > 1 the default workload is BASELINE configs[4]: 1024 frames per GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rank_sum"] == 3.0 and out["baseline_config"] == 4 and out["global_batch"] == 2048
+    # a rank that fails makes the launcher's exit code non-zero (an unknown flag here)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    # under a launcher whose world does not match --gpus: refuse
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rendezvous-only"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2
 
 
 def test_parse_ocr_labels_follows_the_reference_filter(built):

@@ -12,8 +12,23 @@ import os, re, subprocess, sys, tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "..", "squad-mortar-helper_amd", "csrc", "smh_stream.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-         "-fno-fast-math", "-fno-slp-vectorize"]
+MAKEFILE = os.path.join(HERE, "..", "squad-mortar-helper_amd", "csrc", "Makefile")
+
+
+def build_flags():
+    """The compiler flags of the library build: from the environment when the Makefile runs this script as its post-link
+    step (SMH_HIPCC_FLAGS), else read out of the Makefile (`make -pn` expands the variables) -- never a hand copy."""
+    env = os.environ.get("SMH_HIPCC_FLAGS")
+    if env:
+        return env.split()
+    out = subprocess.run(["make", "-pn", "-f", os.path.realpath(MAKEFILE), "-C", os.path.dirname(os.path.realpath(MAKEFILE)), "print-nothing"],
+                         capture_output=True, text=True).stdout
+    arch = re.search(r"^ARCH \??:?= (.*)$", out, re.M).group(1).strip()
+    flags = re.search(r"^FLAGS :?= (.*)$", out, re.M).group(1).replace("$(ARCH)", arch)
+    return flags.split()
+
+
+HIPCC = os.environ.get("SMH_HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def regs_in(text):
@@ -61,12 +76,19 @@ def check_kernel(name, lines):
     # start of the next trip: up to the wait that releases the set (the in-loop loads of set 2 sit in that range and must not alias)
     scan(hdr, waits[0], in0[2], "set 0 (refill, start of the next trip)")
     scan(hdr, waits[1], in1[2], "set 1 (refill, start of the next trip)")
+    # the exits: a `break` leaves with up to two sets (clamped loads nobody consumes) still in flight; everything between
+    # the end of the loop body and the `s_waitcnt vmcnt(0)` that drains them must leave all three sets alone
+    drains = [i for i in range(len(code)) if "smh-drain" in lines[i]]
+    if len(drains) != 1 or drains[0] <= back:
+        errors.append("%s: expected exactly one drain wait behind the loop, found %s (loop ends at line %d)" % (name, [d + 1 for d in drains], back + 1))
+    else:
+        scan(back + 1, drains[0], pro0[2] | pro1[2] | in2[2], "a set still in flight at a loop exit")
     return errors
 
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-x", "hip", os.path.realpath(SRC), "-c", "--save-temps", "-o", "out.o"], cwd=tmp, check=True,
+        subprocess.run([HIPCC] + build_flags() + ["-x", "hip", os.path.realpath(SRC), "-c", "--save-temps", "-o", "out.o"], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         asm = [f for f in os.listdir(tmp) if f.endswith(".s") and "gfx950" in f]
         text = open(os.path.join(tmp, asm[0])).read().split("\n")

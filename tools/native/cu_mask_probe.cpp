@@ -1,4 +1,5 @@
-// Probe: which CUs does a stream created with hipExtStreamCreateWithCUMask use on this device?  (tools/cu_mask_probe.sh)
+// Probe: which CUs does a stream created with hipExtStreamCreateWithCUMask use on this device?
+// build (on the GPU box): hipcc --offload-arch=gfx950 -O2 tools/native/cu_mask_probe.cpp -o tools/native/cu_mask_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
