@@ -162,6 +162,19 @@ def cpu_threads(k):
     return cores
 
 
+def omp_threads(n):
+    """The C oracle's per-pixel loops are OpenMP loops (its stand-alone stage functions would otherwise use every core):
+    pin the team size for the single-thread figures.  -> previous maximum."""
+    import ctypes
+    try:
+        g = ctypes.CDLL("libgomp.so.1")
+        prev = g.omp_get_max_threads()
+        g.omp_set_num_threads(int(n))
+        return prev
+    except OSError:
+        return None
+
+
 def cpu_stage_split(orc, frames, infos, max_gap=15):
     """Single-thread per-stage milliseconds of the C oracle: median over the given frames, after one
     untimed pass over the same frames (first-touch page faults in freshly mapped output arrays moved whole stages by 10-40x
@@ -180,10 +193,13 @@ def cpu_stage_split(orc, frames, infos, max_gap=15):
             for k, dt in zip(names, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 samples[k].append(dt)
 
+    prev = omp_threads(1)
     for fr, info in zip(frames, infos):                      # untimed pass: the allocator and the page cache settle
         one(fr, info, False)
     for fr, info in zip(frames, infos):
         one(fr, info, True)
+    if prev:
+        omp_threads(prev)
     return {k: sorted(v)[len(v) // 2] * 1e3 for k, v in samples.items()}
 
 
@@ -312,13 +328,16 @@ def config0(args):
         H, W = frame.shape[:2]
         info = dict(scales_start_y=start_y)
         split = cpu_stage_split(orc, [frame] * 5, [info] * 5)
+        prev = omp_threads(1)
         for _ in range(2):
             ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=start_y)
         reps = 5
         t0 = time.perf_counter()
-        for _ in range(reps):
+        for _ in range(reps):                                   # the whole call: + isolate_map_markers' own pass and the per-call buffers
             ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=start_y)
         cpu_ms = (time.perf_counter() - t0) / reps * 1e3
+        if prev:
+            omp_threads(prev)
         threads = cpu_threads(64)
         k = max(threads * 2, 8)
         batch = np.ascontiguousarray(np.broadcast_to(frame, (k,) + frame.shape))

@@ -120,7 +120,21 @@ enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
 hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s);
 // map pass + quadrant pass in one (the quadrant pixels are read once); flags: MAP_*, qflags: BRQ_*
-hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
+// Occupancy policy of a pipelined batch (smhv_pipeline_create).  A streaming workgroup beyond the two per
+// CU that saturate HBM only waits in the memory queues -- while holding wave slots and registers the other batches' line
+// searches need -- so the pipeline (a) makes every streaming workgroup reserve enough LDS that a third does not fit on a
+// CU and a line-search workgroup still does, and (b) caps the streaming grid (workgroups walk the (frame, band) items with
+// a grid stride).  All zero: no policy (a batch that runs alone).
+struct LaunchTuning {
+	uint32_t map_lds_total;   // LDS a streaming workgroup occupies, static + dynamic, in bytes (0: what it needs)
+	uint32_t map_grid_cap;    // streaming workgroups per launch (0: one per item)
+	uint32_t lsd_tile_limit;  // k_lsd_tile keeps at most this many mask tiles in LDS (0: what fits the kernel's own budget)
+};
+// LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
+uint32_t map_brq_lds_bytes(const Geom &g);
+uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit);
+hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
+                               const LaunchTuning *tune = nullptr);
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
 // k_lsd is three kernels, one per mask residency mode, each over all frames (a workgroup whose frame needs another mode
 // exits at once).  When the whole ROI fits the LDS window (<= 1080p) every frame is a ROWS frame and only that kernel is
@@ -134,7 +148,7 @@ bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame
 // better: smhv_pipeline at depth 2 on frames up to 1080p) or the process-wide diagnostic switch is.
 // tile_bs: threads per workgroup of k_lsd_tile (0: 512, the pipelined default; a batch that runs alone takes 1024)
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs = 0,
-                      bool prefer_classic = false);
+                      bool prefer_classic = false, uint32_t tile_limit = 0);
 size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocation, zeroed per launch)
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);

@@ -1293,7 +1293,23 @@ void lsd_set_spin_limit(uint32_t polls) { g_spin_limit.store(polls ? polls : W_S
 
 bool lsd_rows_only(const Geom &g) { return (g.rh + 2u) * LSD_ROWS_PITCH(g.bits_pitch_w) + 4u <= LSD_WIN_WORDS_CAP; }
 
-hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs, bool prefer_classic) {
+static uint32_t lsd_tile_static_lds() {
+	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_lsd_tile) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 17408u; }();
+	return v;
+}
+static uint32_t lsd_tile_cap_of(const Geom &g, uint32_t tile_limit) {
+	const uint32_t cap_o = g_tile_cap_override.load(std::memory_order_relaxed);   // process-wide diagnostic, wins
+	uint32_t cap = tile_cap_for(g);
+	if (tile_limit) cap = std::min(cap, tile_limit);
+	if (cap_o) cap = std::min(cap_o, tile_cap_for(g));
+	return cap;
+}
+uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit) {
+	return lsd_tile_static_lds() + (tile_mask_words(g.rw, g.rh, lsd_tile_cap_of(g, tile_limit)) + 2u * LSD_LIST_CAP) * 4u;
+}
+
+hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs, bool prefer_classic,
+                      uint32_t tile_limit) {
 	const unsigned lds_full = LSD_DYN_LDS_BYTES;
 	// more than 64 KB of dynamic LDS has to be allowed per function and per device
 	static std::atomic<uint64_t> attr_devices{0};
@@ -1318,9 +1334,10 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	if (mode == 0 && !coop && !prefer_classic && !lsd_classic_flag().load(std::memory_order_relaxed)) {
 		static const uint32_t bs_env = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= LSD_TILE_BS && v % 64 == 0) ? (uint32_t)v : 0u; }();
 		const uint32_t bs = bs_env ? bs_env : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u);
-		const uint32_t cap_o = g_tile_cap_override.load(std::memory_order_relaxed);
-		const uint32_t cap = cap_o ? std::min(cap_o, tile_cap_for(g)) : tile_cap_for(g);
-		const unsigned t_lds = (tile_mask_words(g.rw, g.rh, cap) + 2u * LSD_LIST_CAP) * 4u;
+		const uint32_t cap = lsd_tile_cap_of(g, tile_limit);
+		// diagnostic: SMH_W_LDS_PAD=<bytes> enlarges the request (fewer workgroups of this kernel per CU, the rest of the CU left to other kernels)
+		static const unsigned lds_pad = [] { const char *e = getenv("SMH_W_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
+		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * LSD_LIST_CAP) * 4u + lds_pad, LSD_TILE_DYN_LDS_MAX);
 		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed));
 		return hipGetLastError();
 	}

@@ -171,6 +171,7 @@ struct smhv_batch {
 	// a pipeline (two workgroups per CU, and room for the streaming pass of the other batches beside them)
 	uint32_t lsd_bs = 1024;
 	bool lsd_prefer_classic = false;      // set by smhv_pipeline_create where the workgroup-synchronous k_lsd measures faster
+	LaunchTuning tune{0u, 0u, 0u};        // occupancy policy of a pipelined batch (smh_kernels.h); all zero for a batch that runs alone
 };
 
 struct smhv_ctx {
@@ -608,7 +609,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
 	if (scales) qflags |= BRQ_SCALES;
 	STAGE_BEGIN(1, s);
-	if (mflags && qflags) HIPCHK(launch_map_brq_pass(g, bf, n, mflags, qflags, grayscale, 0, 1, s));
+	if (mflags && qflags) HIPCHK(launch_map_brq_pass(g, bf, n, mflags, qflags, grayscale, 0, 1, s, &b->tune));
 	else if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
 	STAGE_END(1, s);
 	STAGE_BEGIN(2, s);
@@ -617,7 +618,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	HIPCHK(hipEventRecord(b->ev_map_done, s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	STAGE_BEGIN(3, sl);
-	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic));
+	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic, b->tune.lsd_tile_limit));
 	STAGE_END(3, sl);
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
 	STAGE_BEGIN(4, sl);
@@ -776,6 +777,29 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	delete p;
 }
 
+// Occupancy policy of the batches of a deep pipeline (measured on MI355X, DESIGN.md section 7: 256 x 1080p, depth 4, 389 k ->
+// 453 k frames/s).  The streaming pass saturates HBM with two of its 4-wave workgroups per CU; the third and fourth only queue
+// up in the memory system, and the wave slots and registers they hold are what the line searches of the other batches in
+// flight are short of.  So each streaming workgroup RESERVES LDS it does not use: R bytes with 3 R > 160 KB (a third
+// workgroup never fits) and 2 R + L <= 160 KB, L = the LDS of one line-search workgroup with its tile store limited to
+// SMH_PIPE_TILE_LIMIT tiles (a scene uses 40-260; a frame with more is searched on the mask in global memory).  The grid of
+// the streaming pass is capped as well (its workgroups walk the items with a grid stride).  Frame sizes whose tile index
+// leaves no room for that (4K and up) get no policy.
+#define SMH_PIPE_TILE_LIMIT 400u
+#define SMH_PIPE_MAP_GRID 1024u
+#define SMH_LDS_PER_CU 163840u
+static LaunchTuning pipeline_tuning(const Geom &g) {
+	LaunchTuning t{0u, 0u, 0u};
+	static const bool off = [] { const char *e = getenv("SMH_PIPE_TUNING"); return e && atoi(e) == 0; }();   // diagnostic: SMH_PIPE_TUNING=0
+	if (off) return t;
+	const uint32_t lsd = (lsd_tile_lds_bytes(g, SMH_PIPE_TILE_LIMIT) + 1023u) & ~1023u;       // (allocation granularity: be generous)
+	if (lsd + 2048u >= SMH_LDS_PER_CU) return t;
+	const uint32_t r = ((SMH_LDS_PER_CU - lsd - 2048u) / 2u) & ~1023u;
+	if (3u * r <= SMH_LDS_PER_CU || r <= map_brq_lds_bytes(g)) return t;                        // a third streaming workgroup would still fit
+	t.map_lds_total = r; t.map_grid_cap = SMH_PIPE_MAP_GRID; t.lsd_tile_limit = SMH_PIPE_TILE_LIMIT;
+	return t;
+}
+
 // stream_cus: 0 = every kernel may use every CU; 1..31 = the streaming kernels get that many CUs of every 32 (of each XCD's
 // share), the line-segment search the rest (hipExtStreamCreateWithCUMask).
 static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, uint32_t stream_cus, smhv_pipeline **out) {
@@ -815,6 +839,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		// helper workgroups, depth 2: k_lsd, depth >= 3: k_lsd_tile with 512-thread workgroups; larger frames: k_lsd_tile always.
 		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
+		if (depth >= 3) p->batch[i]->tune = pipeline_tuning(p->batch[i]->g);
 	}
 	*out = p;
 	return SMHV_OK;

@@ -8,6 +8,10 @@
 // right at a threshold, so the reference's scalar f32 operation order (no FMA contraction, IEEE divide) is
 // part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
 // structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+
 #include "smh_device.h"
 
 namespace smh {
@@ -418,9 +422,25 @@ __device__ __forceinline__ uint32_t rows_of_col(uint32_t nibbles, int c) {
 	return (y | (y >> 3) | (y >> 6) | (y >> 9)) & 0xFu;
 }
 
+// One work item = one band of RB rows of one frame.  A real call: inlined into the kernel's grid-stride loop the item spills
+// (the loop's own state on top of 123 registers), and a spilled load destination would be spilled before its data has
+// arrived.  The callee reads the launch parameters from the kernel argument segment (scalar loads), so nothing but the
+// item's coordinates crosses the call.
+#ifndef SMH_MAP_ITEM_INLINE
+#define SMH_MAP_ITEM_INLINE __forceinline__
+#endif
+struct MapKernelArgs { Geom g; Buffers b; uint32_t flags, qflags, RB, fixed_start_y; int use_anchor_start; uint32_t nbands, items; };
+#ifdef __HIP_DEVICE_COMPILE__
+typedef const __attribute__((address_space(4))) MapKernelArgs *MapKernelArgsPtr;   // constant address space: scalar loads
+#else
+typedef const MapKernelArgs *MapKernelArgsPtr;                                     // (host pass: the body is only parsed)
+#endif
 template <bool GRAY>
-__global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start) {
-	const uint32_t f = blockIdx.y;
+__device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f, uint32_t band) {
+	const Geom g = ka->g;
+	const Buffers b = ka->b;
+	const uint32_t flags = ka->flags, qflags = ka->qflags, RB = ka->RB, fixed_start_y = ka->fixed_start_y;
+	const int use_anchor_start = ka->use_anchor_start;
 	if (!b.aux[f].open) return;
 	uint32_t start_y = fixed_start_y;
 	bool do_scales = (qflags & BRQ_SCALES) != 0;
@@ -432,7 +452,7 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	}
 	const bool do_ocr = (qflags & BRQ_OCR) != 0;
 	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6, nwave = blockDim.x >> 6;
-	const int r0 = (int)(blockIdx.x * RB);
+	const int r0 = (int)(band * RB);
 	const int r1 = min(r0 + (int)RB, (int)g.rh);
 	const bool qact = q < g.m_quads;
 	uint32_t vmask = 0;
@@ -742,6 +762,24 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	}
 }
 
+// The grid is capped (launch_map_brq_pass): a workgroup walks the (frame, band) items with a grid stride.  Beyond the
+// number of workgroups that saturates HBM, more resident streaming workgroups only wait on each other in the memory queues
+// while holding wave slots and registers the other batches' line searches need.
+template <bool GRAY>
+__global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start,
+                                                       uint32_t nbands, uint32_t items) {
+#ifdef SMH_MAP_FAT
+	asm volatile("; register footprint experiment" ::: SMH_MAP_FAT);   // e.g. -DSMH_MAP_FAT='"v255"': the wave is allocated that many VGPRs
+#endif
+	static_assert(sizeof(MapKernelArgs) == sizeof(Geom) + sizeof(Buffers) + 7 * 4 + 4 || sizeof(MapKernelArgs) == sizeof(Geom) + sizeof(Buffers) + 7 * 4, "the kernel's parameter list");
+	MapKernelArgsPtr ka = (MapKernelArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+	for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+		const uint32_t f = item / nbands, band = item - f * nbands;
+		map_brq_item<GRAY>(ka, f, band);
+		__syncthreads();                                       // the next item reuses the LDS exchange arrays
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
@@ -761,13 +799,40 @@ hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 	return hipGetLastError();
 }
 
-hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s) {
+static uint32_t map_brq_static_lds() {
+	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_map_brq_pass<true>) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 2048u; }();
+	return v;
+}
+uint32_t map_brq_lds_bytes(const Geom &g) { return map_brq_static_lds() + (g.m_block / 64u) * 640u; }
+
+hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
+                               const LaunchTuning *tune) {
 	uint32_t RB = MAPQ_RB_MAX;
 	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
-	const dim3 grid((g.rh + RB - 1) / RB, n);
-	const unsigned lds = (g.m_block / 64u) * 640u;
-	if (grayscale) hipLaunchKernelGGL(k_map_brq_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start);
-	else hipLaunchKernelGGL(k_map_brq_pass<false>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start);
+	const uint32_t nbands = (g.rh + RB - 1) / RB, items = nbands * n;
+	// diagnostics (override the caller's policy): SMH_MAP_LDS_PAD=<bytes> enlarges the LDS request (fewer streaming workgroups
+	// per CU); SMH_MAP_GRID=<workgroups> caps the grid
+	static const int lds_pad = [] { const char *e = getenv("SMH_MAP_LDS_PAD"); return e ? atoi(e) : -1; }();
+	static const int grid_env = [] { const char *e = getenv("SMH_MAP_GRID"); return e ? atoi(e) : -1; }();
+	unsigned lds = (g.m_block / 64u) * 640u;                 // 64 x (pixel, verdict, id) per wave
+	if (lds_pad >= 0) lds += (unsigned)lds_pad;
+	else if (tune && tune->map_lds_total > map_brq_lds_bytes(g)) lds = tune->map_lds_total - map_brq_static_lds();
+	if (lds > 65536u) {                                      // more than 64 KB of dynamic LDS has to be allowed per function (and per device)
+		static std::atomic<uint64_t> attr_devices{0};
+		int dev = 0;
+		hipError_t e = hipGetDevice(&dev);
+		if (e != hipSuccess) return e;
+		if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
+			e = hipFuncSetAttribute((const void *)k_map_brq_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+			if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_map_brq_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+			if (e != hipSuccess) return e;
+			if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
+		}
+	}
+	uint32_t cap = grid_env >= 0 ? (uint32_t)grid_env : (tune ? tune->map_grid_cap : 0u);
+	const dim3 grid(cap ? std::min(cap, items) : items);
+	if (grayscale) hipLaunchKernelGGL(k_map_brq_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+	else hipLaunchKernelGGL(k_map_brq_pass<false>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
 	return hipGetLastError();
 }
 

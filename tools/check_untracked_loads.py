@@ -56,7 +56,19 @@ def check_kernel(name, lines):
     if not (in2[0] < waits[0] < in0[0] < waits[1] < in1[0] < waits[2]):
         errors.append("%s: loads and waits are not in the expected order" % name)
     # loop body in layout order: from the header label before the first in-loop load to the last branch back to it
-    hdr = max(i for i in range(in2[0]) if re.match(r"\.LBB\d+_\d+:", code[i]) and "Loop Header" in lines[i])
+    def is_header(i):
+        # `.LBBn_m: ; =>This Loop Header: Depth=1`, or for a nested loop the label line followed by comment-only lines
+        # (`; Parent Loop ...` / `; =>  This Loop Header: Depth=2`)
+        if not re.match(r"\.LBB\d+_\d+:", code[i]):
+            return False
+        j = i
+        while True:
+            if "Loop Header" in lines[j]:
+                return True
+            j += 1
+            if j >= len(lines) or code[j].strip():
+                return False
+    hdr = max(i for i in range(in2[0]) if is_header(i))
     label = code[hdr].split(":")[0]
     back = max(i for i in range(len(code)) if re.search(r"s_cbranch\w*\s+%s\b|s_branch\s+%s\b" % (re.escape(label), re.escape(label)), code[i]))
 
@@ -83,6 +95,16 @@ def check_kernel(name, lines):
         errors.append("%s: expected exactly one drain wait behind the loop, found %s (loop ends at line %d)" % (name, [d + 1 for d in drains], back + 1))
     else:
         scan(back + 1, drains[0], pro0[2] | pro1[2] | in2[2], "a set still in flight at a loop exit")
+    # Spills: the scans above already cover every instruction (scratch stores included) between a load and its wait, so a
+    # spill elsewhere cannot catch a register with a load in flight; the streaming loop itself must stay free of scratch
+    # traffic (it would sit in the same vmcnt queue as the pixel loads and change what the counted waits mean).
+    for i in range(hdr, back + 1):
+        if re.match(r"\s*scratch_(load|store)", code[i]):
+            errors.append("%s: line %d: scratch access inside the streaming loop: %s" % (name, i + 1, code[i].strip()))
+    # ... and before the loop, between the first fills of sets 0 / 1 and the loop: a scratch access there would be counted by vmcnt too
+    for i in range(pro0[0], hdr):
+        if re.match(r"\s*scratch_(load|store)", code[i]):
+            errors.append("%s: line %d: scratch access between the first loads and the loop: %s" % (name, i + 1, code[i].strip()))
     return errors
 
 
@@ -104,8 +126,8 @@ def main():
         i += 1
     meta = "\n".join(text)
     for km in re.finditer(r"\.name:\s+(_ZN3smh14k_map_brq_pass\w+)\s*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s*(\d+)", meta):
-        if int(km.group(2)) != 0:
-            errors.append("%s uses %s bytes of scratch: a spilled load destination would be spilled before its data has arrived" % (km.group(1)[:40], km.group(2)))
+        if int(km.group(2)) > 128:
+            errors.append("%s uses %s bytes of scratch (more than the prologue / epilogue spills of the grid-stride loop's state account for)" % (km.group(1)[:40], km.group(2)))
     if found != 2:
         errors.append("expected two instantiations of k_map_brq_pass, found %d" % found)
     for e in errors:

@@ -5,6 +5,7 @@ import numpy as np, torch
 import squad_mortar_helper_amd as smh
 from squad_mortar_helper_amd import synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+COPY = len(sys.argv) > 2 and sys.argv[2] == "copy"      # a plain device copy runs beside the profiled launches (HBM traffic, no VALU to speak of)
 W, H = 1920, 1080
 host = torch.empty((N, H, W, 4), dtype=torch.uint8, pin_memory=True)
 _, infos = synth.make_batch(W, H, N, out=host.numpy())
@@ -13,8 +14,16 @@ v = smh.HipVision.init(0)
 smh._lib.load().smhv_debug_lsd_classic(0)
 fb = smh.FrameBatch(v, W, H, N)
 fb.enable_timing(True)
+if COPY:
+    src = torch.empty(1_000_000_000, dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
 for _ in range(3):
+    if COPY:
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                dst.copy_(src, non_blocking=True)
     fb.run(d.data_ptr(), N, stages=smh.STAGE_MARKERS | smh.STAGE_UI_MAP, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
 torch.cuda.synchronize()
 print("stage ms", fb.stage_ms())
 raw = fb.read_results(0, N)
