@@ -235,6 +235,12 @@ SMHV_API int smhv_debug_lsd_classic(int on);
  * to 1440p, 541 at 4K; a marker scene has 40-260); a frame with more is searched on the mask in global memory (slow).  The
  * tests lower the cap to run frames through that path. */
 SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
+/* diagnostic (process-wide): find_lines has a third kernel, k_lsd_seq -- ONE wave per frame runs the reference's sequential scan
+ * as it stands (no speculation, no atomics): least wave-time per frame, longest time to a frame's result; what smhv_pipeline
+ * uses for its batches at depth >= 3, where throughput is wave slots x time.  threads = 64 forces it for every batched
+ * find_lines launch, 128..1024 (multiples of 64) force k_lsd_tile with that workgroup size, 0 restores the library's choice.
+ * The tests run every scene through all three kernels. */
+SMHV_API int smhv_debug_lsd_threads(uint32_t threads);
 /* diagnostic (process-wide): idle polls (about 0.25 us each) a wave of k_lsd_tile may spend without progress before the
  * watchdog gives its frame up (SMHV_FRAME_LSD_STUCK).  0 restores the default (4,000,000: about a second).  The tests lower
  * it to 1 to force the error path. */

@@ -133,6 +133,7 @@ struct LaunchTuning {
 // LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
 uint32_t map_brq_lds_bytes(const Geom &g);
 uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit);
+uint32_t lsd_seq_lds_bytes(const Geom &g, uint32_t tile_limit);      // k_lsd_seq (one wave per frame: tile_bs = 64)
 hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
                                const LaunchTuning *tune = nullptr);
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
@@ -146,7 +147,8 @@ bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame
 // b.co (if present) is zeroed on `s` before the launch; extra_helpers: additional workgroups that only help (small batches).
 // find_lines runs on k_lsd_tile unless the buffers carry the helper scheme (b.co), prefer_classic is set (the schedule knows
 // better: smhv_pipeline at depth 2 on frames up to 1080p) or the process-wide diagnostic switch is.
-// tile_bs: threads per workgroup of k_lsd_tile (0: 512, the pipelined default; a batch that runs alone takes 1024)
+// tile_bs: threads per workgroup of k_lsd_tile (0: 512; a batch that runs alone takes 1024); 64 selects k_lsd_seq, the
+// one-wave-per-frame sequential scan (deep pipelines: least wave-time per frame, longest time to a frame's result)
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs = 0,
                       bool prefer_classic = false, uint32_t tile_limit = 0);
 size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocation, zeroed per launch)
@@ -164,6 +166,8 @@ size_t lsd_lds_bytes();
 void lsd_set_classic(bool on);
 // diagnostic: cap the tile store of k_lsd_tile (0 = what fits), to exercise the path of frames with more tiles than that
 void lsd_set_tile_cap(uint32_t cap);
+// diagnostic: threads per workgroup of every find_lines launch that is not k_lsd (0 = the caller's choice; 64 = k_lsd_seq)
+void lsd_set_threads(uint32_t threads);
 // diagnostic: watchdog budget of k_lsd_tile in idle polls (0 = default)
 void lsd_set_spin_limit(uint32_t polls);
 // overwrite the 3600 ray directions of the current device's code object (synchronous)

@@ -101,7 +101,12 @@ struct Win {
 	const LdsWord *t_tiles;
 	uint32_t t_pitch;
 	bool tiled;
+	// LSD_MODE_WIN2 only (k_lsd_tile): the candidate's own window of the mask -- whole words, LSD_W2_PITCH words per row,
+	// zero outside the image -- addressed directly: w2 is the byte address of (word 0, row 0) of the IMAGE, so the word of
+	// pixel (x, y) sits at w2 + y * 4 LSD_W2_PITCH + 4 (x >> 5) for every (x, y) inside the window.
+	const LdsByte *w2;
 };
+#define LSD_W2_PITCH 6u
 
 // Mask residency modes of k_lsd, chosen per frame from the bounding box of the set bits:
 //   ROWS   whole rows [y_min-1, y_max+1] in LDS, realigned so that bit x == pixel x.  The sample needs
@@ -115,7 +120,10 @@ struct Win {
 //          mask is a few thin lines, 1-4 % of its tiles hold a set bit, so a frame of ANY size takes 20-50 KB of LDS
 //          instead of 110 KB (1080p) or not fitting at all (1440p, 4K), and two frames share a CU.  One more dependent
 //          LDS read per sample.
-enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2, LSD_MODE_TILE = 3 };
+//   WIN2   (k_lsd_tile only) the first 64 steps of every ray of a candidate stay within 67 px of its pixel: the candidate's
+//          neighbourhood is copied once (from the tile store) into a small window with a fixed pitch, and those steps --
+//          most of all samples -- read it with one LDS access and no index look-up.
+enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2, LSD_MODE_TILE = 3, LSD_MODE_WIN2 = 4 };
 
 // One sample.  Coordinates below/left of the window wrap to huge unsigned values and clamp to the far
 // (zero) border just like coordinates beyond it, so each axis costs one v_min_u32.  24-bit multiply:
@@ -143,6 +151,17 @@ __device__ __forceinline__ uint32_t tile_raw(const Win &m, float x, float y) {
 	const int xi = (int)x;
 	return tile_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u);
 }
+// LSD_MODE_WIN2 sample straight from the float position (bit 0 = the pixel).  No clamp: the caller guarantees the position
+// lies inside the window (rows and columns outside the image are zero there); (int) of a position in (-1, 0) is 0 -- an
+// out-of-image sample either way, masked by the caller like every sample behind the image's edge.
+__device__ __forceinline__ uint32_t win2_raw(const Win &m, float x, float y) {
+	const int yi = (int)y, xi = (int)x;
+	const uint32_t word = *(const LdsWord *)(m.w2 + __mul24(yi, (int)(4u * LSD_W2_PITCH)) + ((xi >> 3) & ~3));
+	return word >> ((uint32_t)xi & 31u);
+}
+__device__ __forceinline__ uint32_t win2_word(const Win &m, int wq, int yi) { return *(const LdsWord *)(m.w2 + __mul24(yi, (int)(4u * LSD_W2_PITCH)) + (wq << 2)); }
+__device__ __forceinline__ uint32_t win2_bit(const Win &m, int xi, int yi) { return (win2_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u)) & 1u; }
+
 // (not on the hot path: the cache test is a run-time one here)
 __device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) {
 	if (m.tiled) return (tile_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u)) & 1u;      // callers pass in-image coordinates
@@ -230,6 +249,7 @@ __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float
 			x = xo + xs; y = yo + ys;                   // x = x_offset + x_start
 			// shifts in bit 0 of its first operand
 			if (MODE == LSD_MODE_ROWS) Wm = __builtin_amdgcn_alignbit(win_raw_rows(m, x, y), Wm, 1);
+			else if (MODE == LSD_MODE_WIN2) Wm = __builtin_amdgcn_alignbit(win2_raw(m, x, y), Wm, 1);
 			else if (MODE == LSD_MODE_TILE) Wm = __builtin_amdgcn_alignbit(tile_raw(m, x, y), Wm, 1);
 			else Wm = __builtin_amdgcn_alignbit(win_raw<MODE == LSD_MODE_GLOBAL>(m, (int)x, (int)y), Wm, 1);
 			xo += dx; yo += dy;                         // x_offset += dx
@@ -685,7 +705,7 @@ __device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uin
 	m.w = g.rw; m.h = g.rh; m.wf = (float)g.rw; m.hf = (float)g.rh;
 	m.rows0 = nullptr; m.ylo_f = 0.0f; m.yhi_f = 0.0f;
 	m.c_p = (const LdsWord *)smem; m.c_y0 = 0u; m.c_rows = 0u; m.c_pitch4 = 0u;
-	m.t_idx = nullptr; m.t_tiles = nullptr; m.t_pitch = 0u; m.tiled = false;
+	m.t_idx = nullptr; m.t_tiles = nullptr; m.t_pitch = 0u; m.tiled = false; m.w2 = nullptr;
 	v.c_pitch = g.bits_pitch_w | 1u; v.c_cap_rows = min(g.rh, LSD_WIN_WORDS_CAP / v.c_pitch);
 	if (MODE == LSD_MODE_ROWS) {
 		const uint32_t wy0 = aux.y_min, wrows = aux.y_max - aux.y_min + 1u;
@@ -1231,6 +1251,7 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 }
 
 #include "smh_lsd_wave.inc"
+#include "smh_lsd_seq.inc"
 
 // ------------------------------------------------------------------------------------------------
 // Sector culling for find_lines (k_lsd).  lsd.rs:94 keeps a candidate only if its longest ray has
@@ -1288,6 +1309,8 @@ static std::atomic<bool> &lsd_classic_flag() {
 void lsd_set_classic(bool on) { lsd_classic_flag().store(on, std::memory_order_relaxed); }
 static std::atomic<uint32_t> g_tile_cap_override{0};
 void lsd_set_tile_cap(uint32_t cap) { g_tile_cap_override.store(cap, std::memory_order_relaxed); }
+static std::atomic<uint32_t> g_bs_override{0};
+void lsd_set_threads(uint32_t threads) { g_bs_override.store(threads, std::memory_order_relaxed); }
 static std::atomic<uint32_t> g_spin_limit{W_SPIN_LIMIT_DEFAULT};
 void lsd_set_spin_limit(uint32_t polls) { g_spin_limit.store(polls ? polls : W_SPIN_LIMIT_DEFAULT, std::memory_order_relaxed); }
 
@@ -1304,8 +1327,15 @@ static uint32_t lsd_tile_cap_of(const Geom &g, uint32_t tile_limit) {
 	if (cap_o) cap = std::min(cap_o, tile_cap_for(g));
 	return cap;
 }
+static uint32_t lsd_seq_static_lds() {
+	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_lsd_seq) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 17408u; }();
+	return v;
+}
+uint32_t lsd_seq_lds_bytes(const Geom &g, uint32_t tile_limit) {
+	return lsd_seq_static_lds() + (tile_mask_words(g.rw, g.rh, lsd_tile_cap_of(g, tile_limit)) + 2u * tile_list_cap_for(g) + W_WIN_STRIDE) * 4u;
+}
 uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit) {
-	return lsd_tile_static_lds() + (tile_mask_words(g.rw, g.rh, lsd_tile_cap_of(g, tile_limit)) + 2u * LSD_LIST_CAP) * 4u;
+	return lsd_tile_static_lds() + (tile_mask_words(g.rw, g.rh, lsd_tile_cap_of(g, tile_limit)) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u;
 }
 
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs, bool prefer_classic,
@@ -1322,6 +1352,7 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		                     (const void *)k_lsd<LSD_MODE_ROWS, true>, (const void *)k_lsd<LSD_MODE_XWIN, true>, (const void *)k_lsd<LSD_MODE_GLOBAL, true>};
 		for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSD_TILE_DYN_LDS_MAX);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSD_TILE_DYN_LDS_MAX);
 		if (e != hipSuccess) return e;
 		if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 	}
@@ -1333,12 +1364,18 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	// on request: smhv_debug_lsd_classic / SMH_LSD_KERNEL=classic).
 	if (mode == 0 && !coop && !prefer_classic && !lsd_classic_flag().load(std::memory_order_relaxed)) {
 		static const uint32_t bs_env = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= LSD_TILE_BS && v % 64 == 0) ? (uint32_t)v : 0u; }();
-		const uint32_t bs = bs_env ? bs_env : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u);
+		const uint32_t bs_o = g_bs_override.load(std::memory_order_relaxed);
+		const uint32_t bs = bs_o ? bs_o : (bs_env ? bs_env : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u));
 		const uint32_t cap = lsd_tile_cap_of(g, tile_limit);
+		if (bs == LSD_SEQ_BS) {                                  // one wave per frame (smh_lsd_seq.inc): what a deep pipeline asks for
+			const unsigned q_lds = (tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_WIN_STRIDE) * 4u;
+			hipLaunchKernelGGL(k_lsd_seq, dim3(n), dim3(LSD_SEQ_BS), q_lds, s, g, b, max_gap, cap, tile_list_cap_for(g));
+			return hipGetLastError();
+		}
 		// diagnostic: SMH_W_LDS_PAD=<bytes> enlarges the request (fewer workgroups of this kernel per CU, the rest of the CU left to other kernels)
 		static const unsigned lds_pad = [] { const char *e = getenv("SMH_W_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
-		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * LSD_LIST_CAP) * 4u + lds_pad, LSD_TILE_DYN_LDS_MAX);
-		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed));
+		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u + lds_pad, LSD_TILE_DYN_LDS_MAX);
+		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed), tile_list_cap_for(g));
 		return hipGetLastError();
 	}
 	if (coop) {

@@ -388,6 +388,12 @@ extern "C" SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap) {
 	return SMHV_OK;
 }
 
+extern "C" SMHV_API int smhv_debug_lsd_threads(uint32_t threads) {
+	if (threads != 0 && (threads < 64 || threads > 1024 || threads % 64)) return fail(SMHV_E_INVALID, "lsd_threads: 0 or a multiple of 64 up to 1024");
+	lsd_set_threads(threads);
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls) {
 	lsd_set_spin_limit(polls);
 	return SMHV_OK;
@@ -617,8 +623,9 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	STAGE_END(2, s);
 	HIPCHK(hipEventRecord(b->ev_map_done, s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
+	static const bool skip_lsd = [] { const char *e = getenv("SMH_SKIP_LSD"); return e && atoi(e) != 0; }();   // diagnostic: time the streaming pass with every output, no search
 	STAGE_BEGIN(3, sl);
-	if (stages & SMHV_STAGE_MARKERS) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic, b->tune.lsd_tile_limit));
+	if ((stages & SMHV_STAGE_MARKERS) && !skip_lsd) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic, b->tune.lsd_tile_limit));
 	STAGE_END(3, sl);
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
 	STAGE_BEGIN(4, sl);
@@ -780,12 +787,13 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 // Occupancy policy of the batches of a deep pipeline (measured on MI355X, DESIGN.md section 7: 256 x 1080p, depth 4, 389 k ->
 // 453 k frames/s).  The streaming pass saturates HBM with two of its 4-wave workgroups per CU; the third and fourth only queue
 // up in the memory system, and the wave slots and registers they hold are what the line searches of the other batches in
-// flight are short of.  So each streaming workgroup RESERVES LDS it does not use: R bytes with 3 R > 160 KB (a third
-// workgroup never fits) and 2 R + L <= 160 KB, L = the LDS of one line-search workgroup with its tile store limited to
+// flight are short of.  So each streaming workgroup RESERVES LDS it does not use: R bytes with 4 R > 160 KB (a fourth
+// workgroup never fits: three measured like two, four are the uncapped kernel) and 2 R + L <= 160 KB, L = the LDS of one
+// line-search workgroup with its tile store limited to
 // SMH_PIPE_TILE_LIMIT tiles (a scene uses 40-260; a frame with more is searched on the mask in global memory).  The grid of
 // the streaming pass is capped as well (its workgroups walk the items with a grid stride).  Frame sizes whose tile index
 // leaves no room for that (4K and up) get no policy.
-#define SMH_PIPE_TILE_LIMIT 400u
+#define SMH_PIPE_TILE_LIMIT 200u
 #define SMH_PIPE_MAP_GRID 1024u
 #define SMH_LDS_PER_CU 163840u
 static LaunchTuning pipeline_tuning(const Geom &g) {
@@ -794,8 +802,9 @@ static LaunchTuning pipeline_tuning(const Geom &g) {
 	if (off) return t;
 	const uint32_t lsd = (lsd_tile_lds_bytes(g, SMH_PIPE_TILE_LIMIT) + 1023u) & ~1023u;       // (allocation granularity: be generous)
 	if (lsd + 2048u >= SMH_LDS_PER_CU) return t;
-	const uint32_t r = ((SMH_LDS_PER_CU - lsd - 2048u) / 2u) & ~1023u;
-	if (3u * r <= SMH_LDS_PER_CU || r <= map_brq_lds_bytes(g)) return t;                        // a third streaming workgroup would still fit
+	const uint32_t r = ((SMH_LDS_PER_CU - lsd - 2048u) / 2u) & ~1023u;                           // two streaming workgroups beside one line search
+	// (a line search too large for "3 R > 160 KB" still gets a cap of three: measured a little below the cap of two)
+	if (4u * r <= SMH_LDS_PER_CU || r <= map_brq_lds_bytes(g)) return t;                        // a fourth streaming workgroup would still fit: no cap at all
 	t.map_lds_total = r; t.map_grid_cap = SMH_PIPE_MAP_GRID; t.lsd_tile_limit = SMH_PIPE_TILE_LIMIT;
 	return t;
 }
@@ -837,7 +846,9 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (rc) { smhv_pipeline_destroy(p); return rc; }
 		// Measured on MI355X: frames whose mask window fits the LDS (<= 1080p) -- depth 1: k_lsd with
 		// helper workgroups, depth 2: k_lsd, depth >= 3: k_lsd_tile with 512-thread workgroups; larger frames: k_lsd_tile always.
-		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
+		static const int seq_env = [] { const char *e = getenv("SMH_LSD_SEQ"); return e ? atoi(e) : -1; }();   // diagnostic: 0 = never, 1 = at every depth
+		const bool seq = seq_env >= 0 ? seq_env != 0 : depth >= 3;
+		p->batch[i]->lsd_bs = seq ? 64u : (depth >= 2 ? 512u : 1024u);
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
 		if (depth >= 3) p->batch[i]->tune = pipeline_tuning(p->batch[i]->g);
 	}

@@ -222,10 +222,11 @@ def test_fuzz_lsd_slice(vision, seed, size, max_gap):
 
 
 def test_both_line_segment_kernels_agree_with_the_oracle(vision):
-    """find_lines has two kernels (smhv_debug_lsd_classic): the task-based k_lsd_tile (the default: sparse tile store of the
-    mask, reorder buffer, waves claim 64-ray units) and the workgroup-synchronous k_lsd.  Random scenes and synthetic frames
-    through both, culled and exact; the tile kernel also with its tile store capped so low that some (cap 48) or all (cap 4)
-    frames overflow it and are searched on the mask in global memory."""
+    """find_lines has three kernels: the task-based k_lsd_tile (sparse tile store of the mask, reorder buffer, waves claim
+    64-ray units), the workgroup-synchronous k_lsd (smhv_debug_lsd_classic) and k_lsd_seq, one wave per frame running the
+    reference's sequential scan (smhv_debug_lsd_threads(64); what deep pipelines use).  Random scenes and synthetic frames
+    through all of them, culled and exact; the tile-store kernels also with the store capped so low that some (cap 48) or
+    all (cap 4) frames overflow it and are searched on the mask in global memory."""
     import torch
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import synth
@@ -239,22 +240,25 @@ def test_both_line_segment_kernels_agree_with_the_oracle(vision):
             ref = o.process_batch(frames, min(os.cpu_count() or 1, n), stages=0x1, max_gap=max_gap)
             fb = smh.FrameBatch(vision, W, H, n)
             d = torch.from_numpy(frames).cuda()
-            for classic, cap in ((0, 0), (1, 0), (0, 48), (0, 4)):
+            # (classic, tile cap, threads): threads = 64 is k_lsd_seq, the one-wave-per-frame sequential scan of deep pipelines
+            for classic, cap, threads in ((0, 0, 0), (1, 0, 0), (0, 48, 0), (0, 4, 0), (0, 0, 64), (0, 48, 64), (0, 4, 64), (0, 0, 256)):
                 lib.smhv_debug_lsd_classic(classic)
                 lib.smhv_debug_lsd_tile_cap(cap)
+                lib.smhv_debug_lsd_threads(threads)
                 for exact in (0, smh.STAGE_EXACT_STATS):
                     for rep in range(2):
                         fb.run(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=max_gap, stream=torch.cuda.current_stream().cuda_stream)
                         got = smh.results_to_dicts(fb.read_results(0, n))
                         for i in range(n):
-                            assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (seed, i, classic, cap, bool(exact))
-                            assert got[i]["rounds"] == ref[i].rounds, (seed, i, classic, cap, bool(exact))
+                            assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (seed, i, classic, cap, threads, bool(exact))
+                            assert got[i]["rounds"] == ref[i].rounds, (seed, i, classic, cap, threads, bool(exact))
                             if exact:
-                                assert got[i]["ray_steps"] == ref[i].steps, (seed, i, classic, cap)
+                                assert got[i]["ray_steps"] == ref[i].steps, (seed, i, classic, cap, threads)
             fb.close()
     finally:
         lib.smhv_debug_lsd_classic(0)
         lib.smhv_debug_lsd_tile_cap(0)
+        lib.smhv_debug_lsd_threads(0)
 
 
 def test_sample_screenshots_through_the_batch_path(vision):
