@@ -846,8 +846,10 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (rc) { smhv_pipeline_destroy(p); return rc; }
 		// Measured on MI355X: frames whose mask window fits the LDS (<= 1080p) -- depth 1: k_lsd with
 		// helper workgroups, depth 2: k_lsd, depth >= 3: k_lsd_tile with 512-thread workgroups; larger frames: k_lsd_tile always.
-		static const int seq_env = [] { const char *e = getenv("SMH_LSD_SEQ"); return e ? atoi(e) : -1; }();   // diagnostic: 0 = never, 1 = at every depth
-		const bool seq = seq_env >= 0 ? seq_env != 0 : depth >= 3;
+		// k_lsd_seq (one wave per frame) takes a third of k_lsd_tile's wave-time per frame but four times as long to deliver the
+		// batch's slowest frame (4.1 ms against 1.0 for 256 x 1080p), and a slot cannot be resubmitted before that: measured
+		// 200 k frames/s against 455 k at depth 4 and 8.  Opt-in (SMH_LSD_SEQ=1) until a launch no longer waits for its slowest frame.
+		static const bool seq = [] { const char *e = getenv("SMH_LSD_SEQ"); return e && atoi(e) != 0; }();
 		p->batch[i]->lsd_bs = seq ? 64u : (depth >= 2 ? 512u : 1024u);
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
 		if (depth >= 3) p->batch[i]->tune = pipeline_tuning(p->batch[i]->g);
