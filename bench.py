@@ -593,11 +593,16 @@ def main():
             ms_d1 = frames_per_step / value_d1 * 1e3
             assert bytes(pipe1.slots[0].read_results(0, n)) == slot_bytes[0], "the depth-1 pipeline's records differ from the depth-%d pipeline's" % depth
         if not args.no_stage_timing:
-            pipe1.slots[0].enable_timing(True)
+            # one pass that runs ALONE and whole (a plain smhv_batch_run: the depth-1 pipeline cuts its submissions into
+            # chunks, whose launches overlap) for the per-stage durations in isolation
+            fb_iso = smh.FrameBatch(vision, W, H, n)
+            fb_iso.enable_timing(True)
             for _ in range(3):
-                one_pass(pipe1)
+                fb_iso.run(fptr, n, stages=stages, grayscale=True, max_gap=15, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()
-            iso_ms = pipe1.slots[0].stage_ms()
+            iso_ms = fb_iso.stage_ms()
+            assert bytes(fb_iso.read_results(0, n)) == slot_bytes[0], "a plain smhv_batch_run's records differ from the pipeline's"
+            fb_iso.close()
         pipe1.close()
 
     # ---- result sanity + workload statistics (outside the timed region) ----

@@ -762,10 +762,13 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	}
 }
 
-// The grid is capped (launch_map_brq_pass): a workgroup walks the (frame, band) items with a grid stride.  Beyond the
-// number of workgroups that saturates HBM, more resident streaming workgroups only wait on each other in the memory queues
-// while holding wave slots and registers the other batches' line searches need.
-template <bool GRAY>
+// LOOP: the grid is capped (launch_map_brq_pass) and a workgroup walks the (frame, band) items with a grid stride.  Beyond
+// the number of workgroups that saturates HBM, more resident streaming workgroups only wait on each other in the memory
+// queues while holding wave slots and registers the other batches' line searches need.  The loop's
+// state costs the kernel 76 bytes of scratch per lane (spilled in the prologue / epilogue of an item, never in the streaming
+// loop: tools/check_untracked_loads.py); a launch with one workgroup per item (a batch that runs alone) takes the variant
+// without the loop and without the spills.
+template <bool GRAY, bool LOOP>
 __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start,
                                                        uint32_t nbands, uint32_t items) {
 #ifdef SMH_MAP_FAT
@@ -773,10 +776,14 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 #endif
 	static_assert(sizeof(MapKernelArgs) == sizeof(Geom) + sizeof(Buffers) + 7 * 4 + 4 || sizeof(MapKernelArgs) == sizeof(Geom) + sizeof(Buffers) + 7 * 4, "the kernel's parameter list");
 	MapKernelArgsPtr ka = (MapKernelArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-	for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-		const uint32_t f = item / nbands, band = item - f * nbands;
-		map_brq_item<GRAY>(ka, f, band);
-		__syncthreads();                                       // the next item reuses the LDS exchange arrays
+	if (LOOP) {
+		for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+			const uint32_t f = item / nbands, band = item - f * nbands;
+			map_brq_item<GRAY>(ka, f, band);
+			__syncthreads();                                   // the next item reuses the LDS exchange arrays
+		}
+	} else {
+		map_brq_item<GRAY>(ka, blockIdx.y, blockIdx.x);       // grid = (bands, frames)
 	}
 }
 
@@ -800,7 +807,7 @@ hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 }
 
 static uint32_t map_brq_static_lds() {
-	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_map_brq_pass<true>) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 2048u; }();
+	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_map_brq_pass<true, true>) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 2048u; }();
 	return v;
 }
 uint32_t map_brq_lds_bytes(const Geom &g) { return map_brq_static_lds() + (g.m_block / 64u) * 640u; }
@@ -823,16 +830,20 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess) return e;
 		if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
-			e = hipFuncSetAttribute((const void *)k_map_brq_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-			if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_map_brq_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+			const void *fns[] = {(const void *)k_map_brq_pass<true, true>, (const void *)k_map_brq_pass<false, true>, (const void *)k_map_brq_pass<true, false>, (const void *)k_map_brq_pass<false, false>};
+			for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 			if (e != hipSuccess) return e;
 			if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 		}
 	}
-	uint32_t cap = grid_env >= 0 ? (uint32_t)grid_env : (tune ? tune->map_grid_cap : 0u);
-	const dim3 grid(cap ? std::min(cap, items) : items);
-	if (grayscale) hipLaunchKernelGGL(k_map_brq_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
-	else hipLaunchKernelGGL(k_map_brq_pass<false>, grid, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+	const uint32_t cap = grid_env >= 0 ? (uint32_t)grid_env : (tune ? tune->map_grid_cap : 0u);
+	if (cap && cap < items) {
+		if (grayscale) hipLaunchKernelGGL((k_map_brq_pass<true, true>), dim3(cap), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+		else hipLaunchKernelGGL((k_map_brq_pass<false, true>), dim3(cap), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+	} else {
+		if (grayscale) hipLaunchKernelGGL((k_map_brq_pass<true, false>), dim3(nbands, n), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+		else hipLaunchKernelGGL((k_map_brq_pass<false, false>), dim3(nbands, n), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+	}
 	return hipGetLastError();
 }
 

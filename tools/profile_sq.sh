@@ -19,7 +19,7 @@ for sub in ("sq1", "sq2"):
     for f in glob.glob(os.path.join("gpurun_out", "prof_%s_%s" % (tag, sub), "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f, newline="")):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-lines = ["%s: bench.py --pipeline-depth 1, 256 x 1080p; rocprofv3 --pmc (two passes), mean per dispatch" % tag]
+lines = ["%s: bench.py --pipeline-depth %s, 256 x 1080p; rocprofv3 --pmc (two passes), mean per dispatch" % (tag, os.environ.get("PDEPTH", "1"))]
 for k in sorted(acc):
     if "smh::" not in k:
         continue
