@@ -111,6 +111,18 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def emit(obj):
+    """The JSON line, LAST on stdout: RCCL prints its version banner through C stdio, whose buffer (when stdout is a pipe)
+    would otherwise be flushed after Python's at exit and end up behind the line."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+    sys.stdout.write(json.dumps(obj) + "\n")
+    sys.stdout.flush()
+
+
 def algorithmic_bytes(roi_w, roi_h, btn_w, btn_h, stages):
     """each input ROI pixel read once as BGRA, each API-visible output written once.
     -> (bytes of the streaming kernel per frame, bytes of the whole step per frame)"""
@@ -370,9 +382,9 @@ def config0(args):
            "cases": out_cases,
            "cpu_baseline": {"value": first["cpu_all_core_frames_per_s"], "unit": "frames/s", "cores": first["cpu_threads"], "kind": "port", "cpu": cpu_model(),
                             "cpu_quota_cores": cpu_quota_cores(), "sample": "copies of the sample frame spread over the host threads"}}
-    print(json.dumps(out))
     if vision is not None:
         vision.shutdown()
+    emit(out)
 
 
 def node_main(args, cfg, n, W, H, stages, rounds, custom):
@@ -431,8 +443,8 @@ def node_main(args, cfg, n, W, H, stages, rounds, custom):
                       "schedule": "smhv_node (one pass in flight per device, records gathered after every pass)"},
            "per_gpu_frames_per_s": value / G, "all_map_open": bool(all(r["map_open"] for r in per)),
            "lsd": {"rounds_per_frame": float(np.mean([r["rounds"] for r in per])), "lines_per_frame": float(np.mean([r["n_lines"] for r in per]))}}
-    print(json.dumps(out))
     node.close()
+    emit(out)
 
 
 def main():
@@ -621,6 +633,16 @@ def main():
         gather_ok = bytes(got)[:n * sz] == slot_bytes[0]
         assert gather_ok, "rank 0's own block of the gather differs from its records"
 
+    if world > 1:
+        # every rank empties its C stdio buffer (RCCL's banner) NOW, so that nothing of the other ranks can land behind
+        # rank 0's JSON line when they exit
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
+        sys.stdout.flush()
+        dist.barrier()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -737,12 +759,12 @@ def main():
                                          "%d threads; lines (bit-exact), round and mask-pixel counts and m/px of these frames match the GPU records: %s; "
                                          "stage split: median of 8 frames on one thread after an untimed pass" % (k, cores, same)}
         if not same:
-            print(json.dumps(out))
+            emit(out)
             raise SystemExit("bench.py: GPU records differ from the CPU oracle on the sampled frames")
-    print(json.dumps(out))
     pipe.close()
     if world > 1:
         dist.destroy_process_group()
+    emit(out)
 
 
 if __name__ == "__main__":
