@@ -485,6 +485,69 @@ def test_headline_configuration_pipelined_depth4(vision, W, H, N):
             assert abs(g["length_px"][k] - np.hypot(x0 - x1, y0 - y1)) <= TOL and abs(g["angle"][k] - np.arctan2(np.float32(y0 - y1), np.float32(x0 - x1))) <= TOL
 
 
+def test_pipeline_occupancy_policy_does_not_change_any_output(vision):
+    """A pipeline of depth >= 3 sets the occupancy of its own kernels (LDS reservation and capped, grid-stride grid of the
+    streaming pass; tile limit of the line search: DESIGN.md section 7).  None of that may change an output byte: records AND
+    images (ui_map, mask, ocr, scales) of a depth-4 pipeline equal a plain smhv_batch_run's -- on synthetic frames, and on
+    frames with MORE marker tiles than the policy's tile limit (dense scenes: those are searched on the mask in global
+    memory).  k_lsd_seq (one wave per frame) through a pipeline gives the same records too."""
+    import subprocess
+    import sys
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    from fuzz_scenes import scene
+    W, H, N = 1920, 1080, 40
+    frames, infos = synth.make_batch(W, H, N, first_idx=2100, n_lines=3)
+    rng = np.random.default_rng(77)
+    for i in range(0, N, 5):                                           # dense random scenes: hundreds of mask tiles
+        frames[i] = scene(rng, W, H, 9000 + i, 15)
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, N)
+    fb.run(d.data_ptr(), N, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
+    want = bytes(fb.read_results(0, N))
+    which = (smh._lib.IMAGE_UI_MAP, smh._lib.VIEW_LSD_INPUT, smh._lib.VIEW_OCR_INPUT, smh._lib.VIEW_FIND_SCALES_INPUT)
+    pick = (0, 5, 17, N - 1)
+    imgs = {(w, f): fb.read_image(w, f).copy() for w in which for f in pick}
+    fb.close()
+    pipe = smh.Pipeline(vision, W, H, N, 4)
+    for j in range(6):
+        slot = pipe.submit(d.data_ptr(), N, anchors=anchors)
+    pipe.wait()
+    for s_ in range(4):
+        assert bytes(pipe.slots[s_].read_results(0, N)) == want, s_
+    for (w, f), img in imgs.items():
+        assert np.array_equal(pipe.slots[slot].read_image(w, f), img), (w, f)
+    pipe.close()
+    lib = smh._lib.load()
+    lib.smhv_debug_lsd_threads(64)
+    try:
+        pipe = smh.Pipeline(vision, W, H, N, 3)
+        for j in range(4):
+            pipe.submit(d.data_ptr(), N, anchors=anchors)
+        pipe.wait()
+        for s_ in range(3):
+            assert bytes(pipe.slots[s_].read_results(0, N)) == want, ("k_lsd_seq", s_)
+        pipe.close()
+    finally:
+        lib.smhv_debug_lsd_threads(0)
+    # the policy switched off (its own process: the switch is read once) gives the same records
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, torch, squad_mortar_helper_amd as smh\n"
+            "from squad_mortar_helper_amd import synth\n"
+            "fr, inf = synth.make_batch(1920, 1080, 12, first_idx=2100, n_lines=3)\n"
+            "a = smh.make_anchors([(i['scales_start_y'], i['anchors']) for i in inf]); d = torch.from_numpy(fr).cuda(); v = smh.HipVision.init(0)\n"
+            "p = smh.Pipeline(v, 1920, 1080, 12, 4); [p.submit(d.data_ptr(), 12, anchors=a) for _ in range(5)]; p.wait()\n"
+            "import hashlib; print('SHA', hashlib.sha256(bytes(p.slots[0].read_results(0, 12))).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import hashlib
+    shas = []
+    for tuning in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMH_PIPE_TUNING=tuning), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        shas.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][-1])
+    assert shas[0] == shas[1]
+
+
 def test_line_search_watchdog_becomes_an_error(vision):
     """A frame the line search gives up (its waves made no progress for the spin budget) must not pass as "no marker
     lines": the record carries status = SMHV_FRAME_LSD_STUCK (n_lines 0, rounds 0xFFFFFFFF), and read_results /
