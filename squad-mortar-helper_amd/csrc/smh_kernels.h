@@ -129,6 +129,7 @@ struct LaunchTuning {
 	uint32_t map_lds_total;   // LDS a streaming workgroup occupies, static + dynamic, in bytes (0: what it needs)
 	uint32_t map_grid_cap;    // streaming workgroups per launch (0: one per item)
 	uint32_t lsd_tile_limit;  // k_lsd_tile keeps at most this many mask tiles in LDS (0: what fits the kernel's own budget)
+	uint32_t map_lean_sub;    // > 0: the lean form of the streaming pass with this many bands side by side per workgroup
 };
 // LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
 uint32_t map_brq_lds_bytes(const Geom &g);

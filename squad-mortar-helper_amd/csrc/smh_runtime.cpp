@@ -171,7 +171,7 @@ struct smhv_batch {
 	// a pipeline (two workgroups per CU, and room for the streaming pass of the other batches beside them)
 	uint32_t lsd_bs = 1024;
 	bool lsd_prefer_classic = false;      // set by smhv_pipeline_create where the workgroup-synchronous k_lsd measures faster
-	LaunchTuning tune{0u, 0u, 0u};        // occupancy policy of a pipelined batch (smh_kernels.h); all zero for a batch that runs alone
+	LaunchTuning tune{0u, 0u, 0u, 0u};        // occupancy policy of a pipelined batch (smh_kernels.h); all zero for a batch that runs alone
 };
 
 struct smhv_ctx {
@@ -795,11 +795,29 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 // leaves no room for that (4K and up) get no policy.
 #define SMH_PIPE_TILE_LIMIT 200u
 #define SMH_PIPE_MAP_GRID 1024u
+#ifndef SMH_PIPE_LEAN_DEFAULT
+#define SMH_PIPE_LEAN_DEFAULT 0
+#endif
+#define SMH_PIPE_LEAN_TILE_LIMIT 400u
+#define SMH_PIPE_LEAN_GRID 512u
 #define SMH_LDS_PER_CU 163840u
 static LaunchTuning pipeline_tuning(const Geom &g) {
-	LaunchTuning t{0u, 0u, 0u};
+	LaunchTuning t{0u, 0u, 0u, 0u};
 	static const bool off = [] { const char *e = getenv("SMH_PIPE_TUNING"); return e && atoi(e) == 0; }();   // diagnostic: SMH_PIPE_TUNING=0
 	if (off) return t;
+	// The lean form of the streaming pass (smh_stream.hip, k_map_brq_lean): ONE workgroup of twelve 80-register waves per CU --
+	// three bands side by side at 1080p, two at 1440p -- reserving more than half of the LDS, so that a second one never fits
+	// and a line-search workgroup always does.
+	static const int lean_env = [] { const char *e = getenv("SMH_PIPE_LEAN"); return e ? atoi(e) : -1; }();   // diagnostic: 0 / 1
+	const uint32_t wpb = g.m_block / 64u, nsub = wpb ? 12u / wpb : 0u;
+	if ((lean_env < 0 ? SMH_PIPE_LEAN_DEFAULT : lean_env) && nsub >= 2u && nsub * g.m_block <= 1024u && !(g.m_block % 64u)) {
+		const uint32_t r = 84u * 1024u, need = map_brq_lds_bytes(g) + nsub * wpb * 640u + nsub * g.m_block * 64u;
+		const uint32_t lsd_l = (lsd_tile_lds_bytes(g, SMH_PIPE_LEAN_TILE_LIMIT) + 1023u) & ~1023u;
+		if (need <= r && r + lsd_l + 2048u <= SMH_LDS_PER_CU) {
+			t.map_lds_total = r; t.map_grid_cap = SMH_PIPE_LEAN_GRID; t.lsd_tile_limit = SMH_PIPE_LEAN_TILE_LIMIT; t.map_lean_sub = nsub;
+			return t;
+		}
+	}
 	const uint32_t lsd = (lsd_tile_lds_bytes(g, SMH_PIPE_TILE_LIMIT) + 1023u) & ~1023u;       // (allocation granularity: be generous)
 	if (lsd + 2048u >= SMH_LDS_PER_CU) return t;
 	const uint32_t r = ((SMH_LDS_PER_CU - lsd - 2048u) / 2u) & ~1023u;                           // two streaming workgroups beside one line search

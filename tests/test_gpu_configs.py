@@ -539,13 +539,14 @@ def test_pipeline_occupancy_policy_does_not_change_any_output(vision):
             "a = smh.make_anchors([(i['scales_start_y'], i['anchors']) for i in inf]); d = torch.from_numpy(fr).cuda(); v = smh.HipVision.init(0)\n"
             "p = smh.Pipeline(v, 1920, 1080, 12, 4); [p.submit(d.data_ptr(), 12, anchors=a) for _ in range(5)]; p.wait()\n"
             "import hashlib; print('SHA', hashlib.sha256(bytes(p.slots[0].read_results(0, 12))).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import hashlib
+    # ... and so does the opt-in lean form of the streaming pass (SMH_PIPE_LEAN=1: twelve 80-register waves per workgroup,
+    # three bands walking their own items, per-band LDS barriers, the quadrant masks in LDS)
     shas = []
-    for tuning in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMH_PIPE_TUNING=tuning), capture_output=True, text=True, timeout=600)
+    for env in (dict(SMH_PIPE_TUNING="1"), dict(SMH_PIPE_TUNING="0"), dict(SMH_PIPE_LEAN="1")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
         shas.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][-1])
-    assert shas[0] == shas[1]
+    assert shas[0] == shas[1] == shas[2]
 
 
 def test_line_search_watchdog_becomes_an_error(vision):
