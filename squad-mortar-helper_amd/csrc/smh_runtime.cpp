@@ -172,6 +172,9 @@ struct smhv_batch {
 	uint32_t lsd_bs = 1024;
 	bool lsd_prefer_classic = false;      // set by smhv_pipeline_create where the workgroup-synchronous k_lsd measures faster
 	LaunchTuning tune{0u, 0u, 0u, 0u};        // occupancy policy of a pipelined batch (smh_kernels.h); all zero for a batch that runs alone
+	// probe of a pipeline that adapts its policy to the workload: start of the streaming pass, its end, end of the line search
+	hipEvent_t ev_probe[3] = {nullptr, nullptr, nullptr};
+	bool probe = false, probe_valid = false;
 };
 
 struct smhv_ctx {
@@ -508,6 +511,7 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
 	if (b->ev_join) (void)hipEventDestroy(b->ev_join);
 	if (b->ev_map_done) (void)hipEventDestroy(b->ev_map_done);
+	for (auto e : b->ev_probe) if (e) (void)hipEventDestroy(e);
 	if (b->lsd_fork.s1) (void)hipStreamDestroy(b->lsd_fork.s1);
 	if (b->lsd_fork.s2) (void)hipStreamDestroy(b->lsd_fork.s2);
 	if (b->lsd_fork.fork) (void)hipEventDestroy(b->lsd_fork.fork);
@@ -614,6 +618,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (stages & SMHV_STAGE_UI_MAP) mflags |= MAP_UI;
 	if (stages & SMHV_STAGE_OCR) qflags |= BRQ_OCR;
 	if (scales) qflags |= BRQ_SCALES;
+	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[0], s));
 	STAGE_BEGIN(1, s);
 	if (mflags && qflags) HIPCHK(launch_map_brq_pass(g, bf, n, mflags, qflags, grayscale, 0, 1, s, &b->tune));
 	else if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
@@ -622,11 +627,14 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (qflags && !mflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
 	STAGE_END(2, s);
 	HIPCHK(hipEventRecord(b->ev_map_done, s));
+	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[1], s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	static const bool skip_lsd = [] { const char *e = getenv("SMH_SKIP_LSD"); return e && atoi(e) != 0; }();   // diagnostic: time the streaming pass with every output, no search
 	STAGE_BEGIN(3, sl);
-	if ((stages & SMHV_STAGE_MARKERS) && !skip_lsd) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic, b->tune.lsd_tile_limit));
+	if ((stages & SMHV_STAGE_MARKERS) && !skip_lsd) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic,
+	                                                      (mflags && qflags) ? b->tune.lsd_tile_limit : 0u));   // (the limit makes room for the fused pass's reservation: no fused pass, no limit)
 	STAGE_END(3, sl);
+	if (b->probe) { HIPCHK(hipEventRecord(b->ev_probe[2], sl)); b->probe_valid = (stages & SMHV_STAGE_MARKERS) && mflags && qflags; }
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
 	STAGE_BEGIN(4, sl);
 	if (scales) HIPCHK(launch_scales_finalize(g, bf, n, stages, b->d_bars, sl));
@@ -765,6 +773,14 @@ struct smhv_pipeline {
 	std::vector<char> held;
 	std::vector<hipStream_t> last_sl;   // stream on which the slot's most recent record kernel ran
 	hipEvent_t ev_after = nullptr;
+	// The occupancy policy suits a pipeline whose streaming pass and line search take comparable time (the synthetic
+	// workload: 0.9 and 1.1 ms per launch).  Real screenshots in small batches are search-bound (a 128-frame launch waits
+	// 4-5 ms for its slowest frame while its streaming pass takes 0.5): one search workgroup per CU is a cut for them.  So the
+	// pipeline measures both (three events per submission, read when the slot comes round again) and switches the policy off
+	// while the search takes more than SMH_ADAPT_OFF x the streaming pass, back on below SMH_ADAPT_ON x.
+	LaunchTuning tuning{0u, 0u, 0u, 0u};
+	bool adapt = false, tune_on = true;
+	float ratio_ema = 0.0f;
 	uint64_t submitted = 0;             // submissions so far
 	uint64_t round_start = 0;           // index of the first submission after the pipeline last ran empty
 };
@@ -790,10 +806,10 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 // flight are short of.  So each streaming workgroup RESERVES LDS it does not use: R bytes with 4 R > 160 KB (a fourth
 // workgroup never fits: three measured like two, four are the uncapped kernel) and 2 R + L <= 160 KB, L = the LDS of one
 // line-search workgroup with its tile store limited to
-// SMH_PIPE_TILE_LIMIT tiles (a scene uses 40-260; a frame with more is searched on the mask in global memory).  The grid of
+// SMH_PIPE_TILE_LIMIT tiles (200 up to 1080p, 320 above; a frame with more is searched on the mask in global memory).  The grid of
 // the streaming pass is capped as well (its workgroups walk the items with a grid stride).  Frame sizes whose tile index
 // leaves no room for that (4K and up) get no policy.
-#define SMH_PIPE_TILE_LIMIT 200u
+#define SMH_PIPE_TILE_LIMIT(g) ((g).rh > 900u ? 320u : 200u)   // a 1080p scene has 36-126 mask tiles, the 1440p screenshots up to 261
 #define SMH_PIPE_MAP_GRID 1024u
 #ifndef SMH_PIPE_LEAN_DEFAULT
 #define SMH_PIPE_LEAN_DEFAULT 0
@@ -801,6 +817,8 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 #define SMH_PIPE_LEAN_TILE_LIMIT 400u
 #define SMH_PIPE_LEAN_GRID 512u
 #define SMH_LDS_PER_CU 163840u
+#define SMH_ADAPT_OFF 3.5f              // line search / streaming pass, launch durations: above -> no occupancy policy
+#define SMH_ADAPT_ON 1.6f               // ... below -> policy on again
 static LaunchTuning pipeline_tuning(const Geom &g) {
 	LaunchTuning t{0u, 0u, 0u, 0u};
 	static const bool off = [] { const char *e = getenv("SMH_PIPE_TUNING"); return e && atoi(e) == 0; }();   // diagnostic: SMH_PIPE_TUNING=0
@@ -818,12 +836,12 @@ static LaunchTuning pipeline_tuning(const Geom &g) {
 			return t;
 		}
 	}
-	const uint32_t lsd = (lsd_tile_lds_bytes(g, SMH_PIPE_TILE_LIMIT) + 1023u) & ~1023u;       // (allocation granularity: be generous)
+	const uint32_t lsd = (lsd_tile_lds_bytes(g, SMH_PIPE_TILE_LIMIT(g)) + 1023u) & ~1023u;    // (allocation granularity: be generous)
 	if (lsd + 2048u >= SMH_LDS_PER_CU) return t;
 	const uint32_t r = ((SMH_LDS_PER_CU - lsd - 2048u) / 2u) & ~1023u;                           // two streaming workgroups beside one line search
 	// (a line search too large for "3 R > 160 KB" still gets a cap of three: measured a little below the cap of two)
 	if (4u * r <= SMH_LDS_PER_CU || r <= map_brq_lds_bytes(g)) return t;                        // a fourth streaming workgroup would still fit: no cap at all
-	t.map_lds_total = r; t.map_grid_cap = SMH_PIPE_MAP_GRID; t.lsd_tile_limit = SMH_PIPE_TILE_LIMIT;
+	t.map_lds_total = r; t.map_grid_cap = SMH_PIPE_MAP_GRID; t.lsd_tile_limit = SMH_PIPE_TILE_LIMIT(g);
 	return t;
 }
 
@@ -870,7 +888,18 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		static const bool seq = [] { const char *e = getenv("SMH_LSD_SEQ"); return e && atoi(e) != 0; }();
 		p->batch[i]->lsd_bs = seq ? 64u : (depth >= 2 ? 512u : 1024u);
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
-		if (depth >= 3) p->batch[i]->tune = pipeline_tuning(p->batch[i]->g);
+		if (depth >= 3) {
+			p->tuning = pipeline_tuning(p->batch[i]->g);
+			p->batch[i]->tune = p->tuning;
+			static const bool adapt_off = [] { const char *e = getenv("SMH_PIPE_ADAPT"); return e && atoi(e) == 0; }();   // diagnostic
+			if (p->tuning.map_lds_total && !adapt_off && !stream_cus) {
+				p->adapt = true;
+				hipError_t e2 = hipSuccess;
+				for (int k = 0; k < 3 && e2 == hipSuccess; ++k) e2 = hipEventCreate(&p->batch[i]->ev_probe[k]);
+				if (e2 != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline probe events: %s", hipGetErrorString(e2)); }
+				p->batch[i]->probe = true;
+			}
+		}
 	}
 	*out = p;
 	return SMHV_OK;
@@ -896,6 +925,21 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 	// the slot's previous submission (depth submissions ago) owns its output buffers until it has finished: this is the
 	// only place the call can wait, and only when more than `depth` submissions would be in flight
 	HIPCHK(hipEventSynchronize(p->done[slot]));
+	if (p->adapt) {
+		smhv_batch *bb = p->batch[slot];
+		if (bb->probe_valid) {                                // the slot's previous submission has finished: its three events are there
+			float map_ms = 0.0f, lsd_ms = 0.0f;
+			if (hipEventElapsedTime(&map_ms, bb->ev_probe[0], bb->ev_probe[1]) == hipSuccess &&
+			    hipEventElapsedTime(&lsd_ms, bb->ev_probe[1], bb->ev_probe[2]) == hipSuccess && map_ms > 0.0f) {
+				const float ratio = lsd_ms / map_ms;
+				p->ratio_ema = p->ratio_ema == 0.0f ? ratio : 0.75f * p->ratio_ema + 0.25f * ratio;
+				if (p->tune_on && p->ratio_ema > SMH_ADAPT_OFF) p->tune_on = false;
+				else if (!p->tune_on && p->ratio_ema < SMH_ADAPT_ON) p->tune_on = true;
+			}
+			bb->probe_valid = false;
+		}
+		bb->tune = p->tune_on ? p->tuning : LaunchTuning{0u, 0u, 0u, 0u};
+	}
 	hipStream_t st, sl;
 	if (p->stream_cus) {
 		st = p->s_stream; sl = p->s_lsd[p->submitted & 1u];

@@ -16,6 +16,9 @@ import squad_mortar_helper_amd as smh
 from oracle import oracle as orc   # checker + CPU timing only
 
 
+STAGES = int(os.environ.get("SMH_BENCH_STAGES", "0x3"), 0)   # (0x43: with helper workgroups, k_lsd)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     frames, stems = [], []
@@ -31,17 +34,17 @@ def main():
     d = torch.from_numpy(batch).cuda()
     torch.cuda.synchronize()
     for i in range(2 * depth):
-        pipe.submit(d.data_ptr(), n, stages=0x3, max_gap=15)
+        pipe.submit(d.data_ptr(), n, stages=STAGES, max_gap=15)
     pipe.wait()
     steps = 40
     t0 = time.perf_counter()
     for i in range(steps):
-        slot = pipe.submit(d.data_ptr(), n, stages=0x3, max_gap=15)
+        slot = pipe.submit(d.data_ptr(), n, stages=STAGES, max_gap=15)
     pipe.wait()
     dt = time.perf_counter() - t0
     got = smh.results_to_dicts(pipe.slots[slot].read_results(0, n))
     t1 = time.perf_counter()
-    ref = orc.process_batch(np.stack(frames), min(os.cpu_count() or 1, k), stages=0x3, max_gap=15)
+    ref = orc.process_batch(np.stack(frames), min(os.cpu_count() or 1, k), stages=STAGES, max_gap=15)
     cdt = time.perf_counter() - t1
     ok = True
     for i in range(n):
