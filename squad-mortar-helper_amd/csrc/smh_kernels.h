@@ -85,8 +85,33 @@ struct BatchError {
 	uint32_t pad[5];
 };
 
+// ---- helper workgroups of k_lsd_tile ("farm", round 3) ------------------------------------------------------------------
+// A launch may carry extra workgroups beyond its frames.  Helper h attaches to the frame with the h-th largest marker mask
+// (both sides derive that from FrameAux; no planning kernel), builds the same tile store and casts whole CANDIDATES the
+// owner posts to it: the owner's reorder buffer holds local and remote candidates alike and retires them in order, so lines,
+// rounds and sample counts are the sequential scan's whichever workgroup cast a candidate (casting is a pure function of
+// (mask, pixel)).  Every word below is ONE 8-byte agent-scope atomic (a granule is never torn, needs no fence); the three
+// payload words of a result are stored, drained (s_waitcnt vmcnt(0)), then the tagged word.
+#define SMH_FARM_RING 4u
+struct FarmEntry {                  // 64 bytes
+	unsigned long long post;        // owner -> helper: epoch16 << 48 | (k + 1)24 << 24 | py12 << 12 | px12   (k = posts so far)
+	unsigned long long best;        // helper -> owner: max over rays of (len^2 bits << 32 | ray index)
+	unsigned long long end;         //   ey bits << 32 | ex bits
+	unsigned long long start;       //   pty bits << 32 | ptx bits
+	unsigned long long done;        //   tag32 << 32 | steps, tag = epoch16 << 16 | (k + 1)16: written last
+	unsigned long long pad[3];
+};
+struct FarmFrame {                  // one per helper workgroup of the launch
+	unsigned long long attached;    // helper -> owner: epoch when the helper has built its tile store and listens
+	unsigned long long owner_done;  // owner -> helper: epoch when the frame is finished
+	unsigned long long pad[6];
+	FarmEntry ring[SMH_FARM_RING];
+};
+
 struct Buffers {
 	BatchError *err;         // device address of the batch's mailbox (null: none)
+	FarmFrame *farm;         // helper exchange of k_lsd_tile, n_farm entries (null / 0: no helpers in this launch)
+	uint32_t n_farm, farm_pad;
 	const uint8_t *frames;   // n * frame_bytes
 	uint8_t *ui, *mask, *ocr, *scales;
 	uint32_t *bits;
@@ -151,7 +176,7 @@ bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame
 // tile_bs: threads per workgroup of k_lsd_tile (0: 512; a batch that runs alone takes 1024); 64 selects k_lsd_seq, the
 // one-wave-per-frame sequential scan (deep pipelines: least wave-time per frame, longest time to a frame's result)
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs = 0,
-                      bool prefer_classic = false, uint32_t tile_limit = 0);
+                      bool prefer_classic = false, uint32_t tile_limit = 0, uint32_t n_helpers = 0);
 size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocation, zeroed per launch)
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);

@@ -1339,7 +1339,7 @@ uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit) {
 }
 
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs, bool prefer_classic,
-                      uint32_t tile_limit) {
+                      uint32_t tile_limit, uint32_t n_helpers) {
 	const unsigned lds_full = LSD_DYN_LDS_BYTES;
 	// more than 64 KB of dynamic LDS has to be allowed per function and per device
 	static std::atomic<uint64_t> attr_devices{0};
@@ -1375,7 +1375,9 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		// diagnostic: SMH_W_LDS_PAD=<bytes> enlarges the request (fewer workgroups of this kernel per CU, the rest of the CU left to other kernels)
 		static const unsigned lds_pad = [] { const char *e = getenv("SMH_W_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
 		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u + lds_pad, LSD_TILE_DYN_LDS_MAX);
-		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed), tile_list_cap_for(g));
+		Buffers bh = b;                                          // helper workgroups beyond the frames (smh_kernels.h, FarmFrame)
+		bh.n_farm = bh.farm ? n_helpers : 0u;
+		hipLaunchKernelGGL(k_lsd_tile, dim3(n + bh.n_farm), dim3(bs), t_lds, s, g, bh, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed), tile_list_cap_for(g), n);
 		return hipGetLastError();
 	}
 	if (coop) {

@@ -143,6 +143,7 @@ struct smhv_batch {
 	smhv_frame_result *d_results = nullptr;   // max_frames (+3 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
 	BatchError *h_err = nullptr, *d_err = nullptr;   // error mailbox: pinned host memory and its device address (smh_kernels.h)
+	FarmFrame *d_farm = nullptr;                     // helper exchange of k_lsd_tile (max_frames / 2 entries)
 	// k_lsd cooperation (smh_kernels.h): [LsdCtl][LsdCoop x n] zeroed per launch, request rings, result caches
 	uint8_t *d_lsd_ctl = nullptr;
 	uint32_t *d_lsd_req = nullptr;
@@ -169,6 +170,7 @@ struct smhv_batch {
 	LsdFork lsd_fork{};
 	// threads per workgroup of the line search (k_lsd_tile): 1024 for a batch that has the chip to itself, 512 for the batches of
 	// a pipeline (two workgroups per CU, and room for the streaming pass of the other batches beside them)
+	uint32_t lsd_farm_pct = 0;            // helper workgroups of k_lsd_tile, in percent of the frames of a run
 	uint32_t lsd_bs = 1024;
 	bool lsd_prefer_classic = false;      // set by smhv_pipeline_create where the workgroup-synchronous k_lsd measures faster
 	LaunchTuning tune{0u, 0u, 0u, 0u};        // occupancy policy of a pipelined batch (smh_kernels.h); all zero for a batch that runs alone
@@ -288,6 +290,7 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
 	bf.err = b->d_err;
+	bf.farm = b->d_farm; bf.n_farm = 0u; bf.farm_pad = 0u;
 	bf.cull_tab = nullptr;
 	bf.ray_off = b->ctx->d_ray_off;
 	bf.frames = frames;
@@ -467,6 +470,7 @@ static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_f
 	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
 	ALLOC0(b->d_lsd_ctl, lsd_coop_ctl_bytes(max_frames));
 	ALLOC0(b->d_lsd_req, sizeof(uint32_t) * SMH_LSD_REQ_CAP * n);
+	ALLOC0(b->d_farm, sizeof(FarmFrame) * ((n + 1) / 2));
 	ALLOC0(b->d_lsd_cache, sizeof(LsdCacheEntry) * SMH_LSD_CACHE_SLOTS * n);
 #undef ALLOC0
 	{
@@ -493,7 +497,7 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	if (!b) return;
 	if (b->ctx) (void)hipSetDevice(b->ctx->device);
 	(void)hipDeviceSynchronize();
-	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars,
+	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars, b->d_farm,
 	                b->d_lsd_ctl, b->d_lsd_req, b->d_lsd_cache};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -567,6 +571,15 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 	return SMHV_OK;
 }
 
+// Helper workgroups of the line search for a run over n frames (smh_kernels.h, FarmFrame): SMH_LSD_FARM=<percent of n> (diagnostic;
+// default: the batch's own setting, 0 = none)
+static uint32_t lsd_helpers_for(const smhv_batch *b, uint32_t n) {
+	static const int pct = [] { const char *e = getenv("SMH_LSD_FARM"); return e ? atoi(e) : -1; }();
+	const uint32_t p = pct >= 0 ? (uint32_t)pct : b->lsd_farm_pct;
+	const uint32_t h = (uint32_t)((uint64_t)n * p / 100u);
+	return h < (b->max_frames + 1u) / 2u ? h : (b->max_frames + 1u) / 2u;
+}
+
 // s: the streaming kernels (button test, the fused map / quadrant pass); sl: the line-segment search and the record kernel.
 // sl == s for a plain smhv_batch_run; a pipeline with partitioned CUs passes two streams (sl waits for the streaming pass).
 static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
@@ -632,7 +645,8 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	static const bool skip_lsd = [] { const char *e = getenv("SMH_SKIP_LSD"); return e && atoi(e) != 0; }();   // diagnostic: time the streaming pass with every output, no search
 	STAGE_BEGIN(3, sl);
 	if ((stages & SMHV_STAGE_MARKERS) && !skip_lsd) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic,
-	                                                      (mflags && qflags) ? b->tune.lsd_tile_limit : 0u));   // (the limit makes room for the fused pass's reservation: no fused pass, no limit)
+	                                                      (mflags && qflags) ? b->tune.lsd_tile_limit : 0u,   // (the limit makes room for the fused pass's reservation: no fused pass, no limit)
+	                                                      lsd_helpers_for(b, n)));
 	STAGE_END(3, sl);
 	if (b->probe) { HIPCHK(hipEventRecord(b->ev_probe[2], sl)); b->probe_valid = (stages & SMHV_STAGE_MARKERS) && mflags && qflags; }
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));

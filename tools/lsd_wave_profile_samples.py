@@ -27,6 +27,7 @@ U = np.array([[raw[i].angle[16 + k] for k in range(4)] for i in range(N)], dtype
 NWV = int(os.environ.get('SMH_W_BS', '1024')) // 64
 for i in np.argsort(-P[:, 7]):
     if raw[i].rounds == 0: continue
+    print("farm on %d remote %3d | " % (raw[i].length_px[26], raw[i].length_px[27]), end="")
     print("%-24s rounds %3d lines %2d units %4d cands %3d skipped %3d | frame %.3g cycles (%.2f ms at 2.4 GHz) | %s | first batches %.0f%% long %.0f%% merge %.0f%%" % (
         stems[i][:24], raw[i].rounds, raw[i].n_lines, D[i, 0], D[i, 1], D[i, 2], P[i, 7] / NWV, P[i, 7] / NWV / 2.4e6,
         " ".join("%s %.0f%%" % (names[k], 100 * P[i, k] / P[i, 7]) for k in range(7)), 100 * U[i, 0] / P[i, 7], 100 * U[i, 1] / P[i, 7], 100 * U[i, 3] / P[i, 7]))
