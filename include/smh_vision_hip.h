@@ -81,6 +81,10 @@ SMHV_API int smhv_button_bounds(uint32_t frame_w, uint32_t frame_h, uint32_t xyw
  * memory.  The bytes are copied; the caller keeps ownership (the Rust shim keeps the Arc<VisionFrame>
  * for get_cpu_frame itself).  (Re)allocates device buffers when the dimensions change. */
 SMHV_API int smhv_load_frame(smhv_ctx *ctx, const uint8_t *bgra, uint32_t w, uint32_t h);
+/* The sub-view case of load_frame (vision-gpu/src/lib.rs:175-179): the frame is the w x h rectangle at (x, y) of a
+ * tightly packed parent_w x parent_h BGRA8 image (VisionFrame = OwnedSubImage, util/src/image.rs:238-262). */
+SMHV_API int smhv_load_frame_view(smhv_ctx *ctx, const uint8_t *parent_bgra, uint32_t parent_w, uint32_t parent_h,
+                                  uint32_t x, uint32_t y, uint32_t w, uint32_t h);
 /* Same, but the frame already lives in device memory (zero-copy path for device-side producers). */
 SMHV_API int smhv_load_frame_device(smhv_ctx *ctx, const void *d_bgra, uint32_t w, uint32_t h);
 
@@ -318,6 +322,17 @@ SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra);
 SMHV_API int smhv_ingest_commit(smhv_ingest *q);
 /* acquire + memcpy + commit for frames that live in ordinary host memory */
 SMHV_API int smhv_ingest_push(smhv_ingest *q, const uint8_t *bgra);
+/* Frames that come out of an image decoder instead of the screen capture (src/ui/debug.rs:169:
+ * `image::load_from_memory(..).into_bgra8()`): the staging buffer holds frame_w * frame_h pixels in the decoder's layout,
+ * they are uploaded as they are and converted to BGRA8 on the device exactly as image 0.23's into_bgra8 does for 8-bit
+ * images (RGB: alpha = 255; L / LA: b = g = r = l), BEFORE the CRC, so the duplicate rule sees the reference's bytes. */
+#define SMHV_PIXELS_BGRA8   0u
+#define SMHV_PIXELS_RGBA8   1u
+#define SMHV_PIXELS_RGB8    2u
+#define SMHV_PIXELS_LUMA8   3u
+#define SMHV_PIXELS_LUMA_A8 4u
+SMHV_API int smhv_ingest_commit_pixels(smhv_ingest *q, uint32_t layout);
+SMHV_API int smhv_ingest_push_pixels(smhv_ingest *q, const uint8_t *pixels, uint32_t layout);
 /* wait for everything committed (or until the slab is full); *d_frames = slab of *n <= capacity accepted frames, valid
  * until smhv_ingest_reset; *last_crc (optional) = CRC-32 of the last accepted frame.  Frames committed after the slab
  * filled up are not lost: they stay queued in their staging slots (at most `slots` of them -- smhv_ingest_acquire

@@ -252,6 +252,31 @@ def capture_dedupe(crcs, last=0):
     return keep.astype(bool), int(lst[0])
 
 
+def into_bgra8(pixels, layout):
+    """`DynamicImage::into_bgra8` for the 8-bit variants a decoder returns (src/ui/debug.rs:169; image 0.23.14, Cargo.lock:1487,
+    third-party and not vendored: color.rs `FromColor` -- Rgb -> Bgra copies the channels and sets alpha to 255, Rgba -> Bgra
+    keeps alpha, Luma(A) -> Bgra replicates the luma into b, g, r).  pixels: uint8[h, w, c] ("l": [h, w]); -> uint8[h, w, 4]."""
+    a = np.asarray(pixels, np.uint8)
+    h, w = a.shape[:2]
+    a = a.reshape(h, w, -1)
+    out = np.empty((h, w, 4), np.uint8)
+    if layout == "bgra":
+        out[...] = a
+    elif layout == "rgba":
+        out[..., 0], out[..., 1], out[..., 2], out[..., 3] = a[..., 2], a[..., 1], a[..., 0], a[..., 3]
+    elif layout == "rgb":
+        out[..., 0], out[..., 1], out[..., 2], out[..., 3] = a[..., 2], a[..., 1], a[..., 0], 255
+    elif layout == "l":
+        out[..., :3] = a[..., :1]
+        out[..., 3] = 255
+    elif layout == "la":
+        out[..., :3] = a[..., :1]
+        out[..., 3] = a[..., 1]
+    else:
+        raise ValueError(layout)
+    return out
+
+
 def marker_new(line, ratio):
     ln = np.ascontiguousarray(line, np.float32)
     a, b = C.c_double(), C.c_double()

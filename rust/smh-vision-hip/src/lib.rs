@@ -21,6 +21,7 @@ extern "C" {
     fn smhv_thread_ctx(ctx: *mut c_void) -> c_int;
     fn smhv_last_error() -> *const c_char;
     fn smhv_load_frame(ctx: *mut c_void, bgra: *const u8, w: u32, h: u32) -> c_int;
+    fn smhv_load_frame_view(ctx: *mut c_void, parent_bgra: *const u8, parent_w: u32, parent_h: u32, x: u32, y: u32, w: u32, h: u32) -> c_int;
     fn smhv_crop_to_map(ctx: *mut c_void, grayscale: c_int, map_open: *mut c_int, roi: *mut u32, ui_rgba: *mut u8) -> c_int;
     fn smhv_map_bounds(w: u32, h: u32, xywh: *mut u32) -> c_int;
     fn smhv_ocr_preprocess(ctx: *mut c_void, out: *mut *const u8, len: *mut usize) -> c_int;
@@ -65,7 +66,14 @@ impl Vision for HipInstance {
     fn get_cpu_frame(&self) -> Arc<VisionFrame> { self.cpu_frame.clone() }
 
     fn load_frame(&mut self, image: VisionFrame) -> Result<(), AnyError> {
-        check(unsafe { smhv_load_frame(self.ctx, image.as_ptr(), image.width(), image.height()) })?;
+        // the same two cases as vision-gpu/src/lib.rs:175-179: a view of a larger image is uploaded with a pitched copy
+        let (x, y, w, h) = image.bounds();
+        let (pw, ph) = image.inner().dimensions();
+        if image.inner().bounds() != image.bounds() {
+            check(unsafe { smhv_load_frame_view(self.ctx, image.inner().as_ptr(), pw, ph, x, y, w, h) })?;
+        } else {
+            check(unsafe { smhv_load_frame(self.ctx, image.inner().as_ptr(), w, h) })?;
+        }
         self.cpu_frame = Arc::new(image);
         Ok(())
     }

@@ -67,6 +67,7 @@ SIGNATURES = {
     "smhv_map_bounds": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "smhv_button_bounds": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "smhv_load_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "smhv_load_frame_view": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_uint32] * 6),
     "smhv_load_frame_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "smhv_crop_to_map": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.c_void_p]),
     "smhv_red_pixels": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
@@ -117,6 +118,8 @@ SIGNATURES = {
     "smhv_ingest_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smhv_ingest_commit": (C.c_int, [C.c_void_p]),
     "smhv_ingest_push": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "smhv_ingest_commit_pixels": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "smhv_ingest_push_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "smhv_ingest_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "smhv_ingest_reset": (C.c_int, [C.c_void_p]),
     "smhv_ingest_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -203,6 +203,8 @@ hipError_t set_ray_table(const float *dx, const float *dy);
 // wgs workgroups of SMH_CRC_BS threads, rounds * wgs * SMH_CRC_BS * 4 >= n_dwords; x_skip = x^(128 (G - 1)),
 // d_x_local[t] = x^(128 (SMH_CRC_BS - 1 - t)), d_x_wg[g] = x^(128 SMH_CRC_BS (wgs - 1 - g)), G = wgs * SMH_CRC_BS.
 #define SMH_CRC_BS 1024
+// decoder layouts -> BGRA8 (n_px pixels; layout = SMHV_PIXELS_*)
+hipError_t launch_to_bgra(const void *d_src, void *d_bgra, uint64_t n_px, uint32_t layout, hipStream_t s);
 hipError_t launch_crc32(const void *d_msg, uint64_t n_dwords, uint32_t wgs, uint32_t rounds, uint32_t x_skip, const uint32_t *d_x_local,
                         const uint32_t *d_x_wg, uint32_t *d_acc, hipStream_t s);
 uint32_t crc32_xpow(uint64_t n);                 // x^n mod P (reflected representation, x^0 = 0x80000000)

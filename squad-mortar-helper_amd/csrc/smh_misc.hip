@@ -398,4 +398,58 @@ hipError_t launch_crc32(const void *d_msg, uint64_t n_dwords, uint32_t wgs, uint
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_to_bgra: a decoder's 8-bit pixels -> BGRA8 (image 0.23 `DynamicImage::into_bgra8`, src/ui/debug.rs:169).  Streaming: one
+// thread converts four pixels (4 / 8 / 12 / 16 source bytes as dword loads, one 16-byte store); bytes in, bytes out, no
+// arithmetic but byte permutes.  BPP = source bytes per pixel: 1 L, 2 LA, 3 RGB, 4 RGBA.
+// ------------------------------------------------------------------------------------------------
+template <int BPP>
+__global__ void __launch_bounds__(256) k_to_bgra(const uint32_t *__restrict__ src, uint4 *__restrict__ dst, uint64_t n_groups, uint64_t n_px) {
+	for (uint64_t gidx = (uint64_t)blockIdx.x * 256u + threadIdx.x; gidx < n_groups; gidx += (uint64_t)gridDim.x * 256u) {
+		uint32_t w[4] = {0u, 0u, 0u, 0u}, px[4];
+		const uint64_t n_src_dwords = (n_px * BPP + 3u) / 4u;
+#pragma unroll
+		for (int k = 0; k < BPP; ++k) { const uint64_t i = gidx * BPP + k; if (i < n_src_dwords) w[k] = src[i]; }
+		if (BPP == 4) {                                          // r g b a -> b g r a
+#pragma unroll
+			for (int k = 0; k < 4; ++k) px[k] = __builtin_amdgcn_perm(w[k], w[k], 0x03000102u);
+		} else if (BPP == 3) {                                     // 12 bytes r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+			const uint32_t ff = 0xFFFFFFFFu;
+			px[0] = __builtin_amdgcn_perm(ff, w[0], 0x04000102u);                                  // b0 g0 r0 ff
+			px[1] = __builtin_amdgcn_perm(ff, __builtin_amdgcn_perm(w[1], w[0], 0x00050403u), 0x04000102u);   // r1 g1 b1 . -> b1 g1 r1 ff
+			px[2] = __builtin_amdgcn_perm(ff, __builtin_amdgcn_perm(w[2], w[1], 0x00040302u), 0x04000102u);   // r2 g2 b2 .
+			px[3] = __builtin_amdgcn_perm(ff, w[2], 0x04010203u);                                  // b3 g3 r3 ff
+		} else if (BPP == 2) {                                     // l0 a0 l1 a1 | l2 a2 l3 a3
+			px[0] = __builtin_amdgcn_perm(w[0], w[0], 0x01000000u);
+			px[1] = __builtin_amdgcn_perm(w[0], w[0], 0x03020202u);
+			px[2] = __builtin_amdgcn_perm(w[1], w[1], 0x01000000u);
+			px[3] = __builtin_amdgcn_perm(w[1], w[1], 0x03020202u);
+		} else {                                                   // l0 l1 l2 l3
+			const uint32_t ff = 0xFFFFFFFFu;
+			px[0] = __builtin_amdgcn_perm(ff, w[0], 0x04000000u);
+			px[1] = __builtin_amdgcn_perm(ff, w[0], 0x04010101u);
+			px[2] = __builtin_amdgcn_perm(ff, w[0], 0x04020202u);
+			px[3] = __builtin_amdgcn_perm(ff, w[0], 0x04030303u);
+		}
+		const uint64_t p0 = gidx * 4u;
+		if (p0 + 4u <= n_px) dst[gidx] = make_uint4(px[0], px[1], px[2], px[3]);
+		else for (int k = 0; k < 4; ++k) if (p0 + k < n_px) ((uint32_t *)dst)[p0 + k] = px[k];
+	}
+}
+
+hipError_t launch_to_bgra(const void *d_src, void *d_bgra, uint64_t n_px, uint32_t layout, hipStream_t s) {
+	const uint64_t groups = (n_px + 3u) / 4u;
+	const uint32_t wgs = (uint32_t)std::min<uint64_t>((groups + 255u) / 256u, 2048u);
+	const uint32_t *src = (const uint32_t *)d_src;
+	uint4 *dst = (uint4 *)d_bgra;
+	switch (layout) {
+	case 1u: hipLaunchKernelGGL(k_to_bgra<4>, dim3(wgs), dim3(256), 0, s, src, dst, groups, n_px); break;
+	case 2u: hipLaunchKernelGGL(k_to_bgra<3>, dim3(wgs), dim3(256), 0, s, src, dst, groups, n_px); break;
+	case 3u: hipLaunchKernelGGL(k_to_bgra<1>, dim3(wgs), dim3(256), 0, s, src, dst, groups, n_px); break;
+	case 4u: hipLaunchKernelGGL(k_to_bgra<2>, dim3(wgs), dim3(256), 0, s, src, dst, groups, n_px); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
 }  // namespace smh

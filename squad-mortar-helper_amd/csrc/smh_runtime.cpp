@@ -1087,6 +1087,38 @@ extern "C" SMHV_API int smhv_load_frame(smhv_ctx *c, const uint8_t *bgra, uint32
 	return SMHV_OK;
 }
 
+// The sub-view case of load_frame (vision-gpu/src/lib.rs:175-179: `frame.inner().bounds() != frame.bounds()`): a VisionFrame
+// is a rectangle of a parent image (util/src/image.rs:238-262); the reference repacks it on the host and uploads the copy.
+// Here the rows the pipeline reads go straight from the parent into the tight device frame with one pitched copy.
+extern "C" SMHV_API int smhv_load_frame_view(smhv_ctx *c, const uint8_t *parent_bgra, uint32_t parent_w, uint32_t parent_h,
+                                              uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
+	if (!c || !parent_bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
+	if ((uint64_t)x + w > parent_w || (uint64_t)y + h > parent_h)
+		return fail(SMHV_E_INVALID, "load_frame_view: the view %ux%u+%u+%u does not lie inside its %ux%u parent", w, h, x, y, parent_w, parent_h);
+	if (x == 0 && w == parent_w) return smhv_load_frame(c, parent_bgra + (size_t)y * parent_w * 4, w, h);   // full rows: already tight
+	CTX_OPEN(c);
+	HIPCHK(hipSetDevice(c->device));
+	int rc = ensure_frame_buffers(c, w, h);
+	if (rc) return rc;
+	const size_t bytes = (size_t)w * h * 4;
+	if (c->d_frame_cap < bytes) {
+		HIPCHK(hipDeviceSynchronize());
+		if (c->d_frame) (void)hipFree(c->d_frame);
+		c->d_frame = nullptr; c->d_frame_cap = 0;
+		HIPCHK(hipMalloc((void **)&c->d_frame, bytes));
+		c->d_frame_cap = bytes;
+	}
+	const Geom &g = c->fb->g;
+	const uint32_t y0 = g.ry < g.by ? g.ry : g.by;
+	const uint32_t y1 = (g.ry + g.rh > g.by + g.bh) ? g.ry + g.rh : g.by + g.bh;
+	const uint8_t *src = parent_bgra + ((size_t)(y + y0) * parent_w + x) * 4;
+	HIPCHK(hipMemcpy2DAsync(c->d_frame + (size_t)y0 * w * 4, (size_t)w * 4, src, (size_t)parent_w * 4, (size_t)w * 4, y1 - y0, hipMemcpyHostToDevice, c->s_main));
+	HIPCHK(hipStreamSynchronize(c->s_main));
+	c->frame_ptr = c->d_frame;
+	reset_frame_state(c);
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_load_frame_device(smhv_ctx *c, const void *d_bgra, uint32_t w, uint32_t h) {
 	if (!c || !d_bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
 	CTX_OPEN(c);
@@ -1370,7 +1402,7 @@ struct smhv_ingest {
 	uint32_t W = 0, H = 0, slots = 0, capacity = 0;
 	size_t frame_bytes = 0;
 	hipStream_t s = nullptr;
-	std::vector<uint8_t *> h_stage, d_stage;
+	std::vector<uint8_t *> h_stage, d_stage, d_raw;           // d_raw: a slot's upload in a decoder's layout (allocated on first use)
 	std::vector<hipEvent_t> done;
 	uint32_t *d_acc = nullptr, *h_acc = nullptr;            // one CRC accumulator per slot (device / pinned host)
 	uint32_t *d_x_local = nullptr, *d_x_wg = nullptr;
@@ -1436,6 +1468,7 @@ extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
 	if (q->s) (void)hipStreamSynchronize(q->s);
 	for (auto p : q->h_stage) if (p) (void)hipHostFree(p);
 	for (auto p : q->d_stage) if (p) (void)hipFree(p);
+	for (auto p : q->d_raw) if (p) (void)hipFree(p);
 	for (auto ev : q->done) if (ev) (void)hipEventDestroy(ev);
 	if (q->d_acc) (void)hipFree(q->d_acc);
 	if (q->h_acc) (void)hipHostFree(q->h_acc);
@@ -1449,7 +1482,7 @@ extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
 
 static int ingest_setup(smhv_ingest *q) {
 	HIPCHK(hipStreamCreateWithFlags(&q->s, hipStreamNonBlocking));
-	q->h_stage.assign(q->slots, nullptr); q->d_stage.assign(q->slots, nullptr); q->done.assign(q->slots, nullptr);
+	q->h_stage.assign(q->slots, nullptr); q->d_stage.assign(q->slots, nullptr); q->d_raw.assign(q->slots, nullptr); q->done.assign(q->slots, nullptr);
 	for (uint32_t i = 0; i < q->slots; ++i) {
 		HIPCHK(hipHostMalloc((void **)&q->h_stage[i], q->frame_bytes, hipHostMallocDefault));
 		HIPCHK(hipMalloc((void **)&q->d_stage[i], q->frame_bytes));
@@ -1520,11 +1553,33 @@ extern "C" SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra)
 	return SMHV_OK;
 }
 
-extern "C" SMHV_API int smhv_ingest_commit(smhv_ingest *q) {
+static uint32_t pixel_layout_bytes(uint32_t layout) {
+	switch (layout) {
+	case SMHV_PIXELS_BGRA8: case SMHV_PIXELS_RGBA8: return 4u;
+	case SMHV_PIXELS_RGB8: return 3u;
+	case SMHV_PIXELS_LUMA_A8: return 2u;
+	case SMHV_PIXELS_LUMA8: return 1u;
+	default: return 0u;
+	}
+}
+
+// The decode half of the hand-off (src/ui/debug.rs:169: `image::load_from_memory(..).into_bgra8()`): the host's codec leaves
+// RGB8 / RGBA8 / L8 / LA8 pixels in the staging buffer, they are uploaded as they are (3 bytes per pixel for a JPEG or an
+// opaque PNG / WebP instead of 4) and become BGRA on the device, in front of the CRC: the duplicate rule sees the same
+// bytes the reference's capture thread would hash.
+extern "C" SMHV_API int smhv_ingest_commit_pixels(smhv_ingest *q, uint32_t layout) {
 	if (!q || !q->acquired) return fail(SMHV_E_INVALID, "ingest_commit: nothing acquired");
+	const uint32_t bpp = pixel_layout_bytes(layout);
+	if (!bpp) return fail(SMHV_E_INVALID, "ingest_commit_pixels: unknown pixel layout %u", layout);
 	HIPCHK(hipSetDevice(q->ctx->device));
 	const uint32_t slot = (uint32_t)(q->head % q->slots);
-	HIPCHK(hipMemcpyAsync(q->d_stage[slot], q->h_stage[slot], q->frame_bytes, hipMemcpyHostToDevice, q->s));
+	if (layout == SMHV_PIXELS_BGRA8) {
+		HIPCHK(hipMemcpyAsync(q->d_stage[slot], q->h_stage[slot], q->frame_bytes, hipMemcpyHostToDevice, q->s));
+	} else {
+		if (!q->d_raw[slot]) HIPCHK(hipMalloc((void **)&q->d_raw[slot], q->frame_bytes));
+		HIPCHK(hipMemcpyAsync(q->d_raw[slot], q->h_stage[slot], q->frame_bytes / 4 * bpp, hipMemcpyHostToDevice, q->s));
+		HIPCHK(launch_to_bgra(q->d_raw[slot], q->d_stage[slot], (uint64_t)q->W * q->H, layout, q->s));
+	}
 	HIPCHK(hipMemsetAsync(q->d_acc + slot, 0, sizeof(uint32_t), q->s));
 	HIPCHK(launch_crc32(q->d_stage[slot], q->frame_bytes / 4, q->wgs, q->rounds, q->x_skip, q->d_x_local, q->d_x_wg, q->d_acc + slot, q->s));
 	HIPCHK(hipMemcpyAsync(q->h_acc + slot, q->d_acc + slot, sizeof(uint32_t), hipMemcpyDeviceToHost, q->s));
@@ -1534,14 +1589,20 @@ extern "C" SMHV_API int smhv_ingest_commit(smhv_ingest *q) {
 	return SMHV_OK;
 }
 
-extern "C" SMHV_API int smhv_ingest_push(smhv_ingest *q, const uint8_t *bgra) {
-	if (!q || !bgra) return fail(SMHV_E_INVALID, "ingest_push: null argument");
+extern "C" SMHV_API int smhv_ingest_commit(smhv_ingest *q) { return smhv_ingest_commit_pixels(q, SMHV_PIXELS_BGRA8); }
+
+extern "C" SMHV_API int smhv_ingest_push_pixels(smhv_ingest *q, const uint8_t *pixels, uint32_t layout) {
+	if (!q || !pixels) return fail(SMHV_E_INVALID, "ingest_push: null argument");
+	const uint32_t bpp = pixel_layout_bytes(layout);
+	if (!bpp) return fail(SMHV_E_INVALID, "ingest_push_pixels: unknown pixel layout %u", layout);
 	uint8_t *dst = nullptr;
 	int rc = smhv_ingest_acquire(q, &dst);
 	if (rc) return rc;
-	memcpy(dst, bgra, q->frame_bytes);
-	return smhv_ingest_commit(q);
+	memcpy(dst, pixels, q->frame_bytes / 4 * bpp);
+	return smhv_ingest_commit_pixels(q, layout);
 }
+
+extern "C" SMHV_API int smhv_ingest_push(smhv_ingest *q, const uint8_t *bgra) { return smhv_ingest_push_pixels(q, bgra, SMHV_PIXELS_BGRA8); }
 
 extern "C" SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames, uint32_t *n, uint32_t *last_crc) {
 	if (!q || !d_frames || !n) return fail(SMHV_E_INVALID, "ingest_batch: null argument");

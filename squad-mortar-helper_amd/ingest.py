@@ -19,6 +19,10 @@ def crc32_device(vision, device_ptr, nbytes):
     return int(out.value)
 
 
+# pixel layouts a host-side image decoder leaves behind (include/smh_vision_hip.h SMHV_PIXELS_*): name -> (code, bytes per pixel)
+PIXEL_LAYOUTS = {"bgra": (0, 4), "rgba": (1, 4), "rgb": (2, 3), "l": (3, 1), "la": (4, 2)}
+
+
 class IngestQueue:
     """`slots` pinned staging buffers + one device slab of `capacity` frames of w x h BGRA."""
 
@@ -57,6 +61,19 @@ class IngestQueue:
         if a.shape != (self.h, self.w, 4):
             raise ValueError("frame must be (%d, %d, 4) BGRA" % (self.h, self.w))
         check(self._lib.smhv_ingest_push(self._q, a.ctypes.data_as(C.c_void_p)))
+
+    def push_pixels(self, pixels, layout):
+        """A decoded image (src/ui/debug.rs:169, `image::load_from_memory(..).into_bgra8()`): uint8[h, w, c] (or [h, w] for
+        "l") in the decoder's layout -- "rgba", "rgb", "l", "la" or "bgra"; it becomes BGRA on the device, before the CRC."""
+        code, bpp = PIXEL_LAYOUTS[layout]
+        a = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if a.size != self.h * self.w * bpp or a.shape[:2] != (self.h, self.w):
+            raise ValueError("pixels must be (%d, %d, %d) for layout %r" % (self.h, self.w, bpp, layout))
+        check(self._lib.smhv_ingest_push_pixels(self._q, a.ctypes.data_as(C.c_void_p), code))
+
+    def commit_pixels(self, layout):
+        """commit() for a staging buffer whose first h * w * bytes-per-pixel bytes hold pixels in a decoder's layout."""
+        check(self._lib.smhv_ingest_commit_pixels(self._q, PIXEL_LAYOUTS[layout][0]))
 
     def batch(self):
         """Wait for everything committed: (device pointer of the slab, accepted frames in it, CRC of the last one)."""

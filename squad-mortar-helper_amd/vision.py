@@ -82,6 +82,17 @@ class HipVision:
         self._frame = image
         self._size = (w, h)
 
+    def load_frame_view(self, parent, x, y, w, h):
+        """The sub-view case of load_frame (vision-gpu/src/lib.rs:175-179): the frame is parent[y:y+h, x:x+w] of a
+        uint8[H, W, 4] BGRA image; nothing is repacked on the host."""
+        parent = np.ascontiguousarray(parent, np.uint8)
+        if parent.ndim != 3 or parent.shape[2] != 4:
+            raise ValueError("VisionFrame must be uint8[H, W, 4] BGRA")
+        ph, pw, _ = parent.shape
+        L.check(self._lib.smhv_load_frame_view(self._ctx, parent.ctypes.data, pw, ph, int(x), int(y), int(w), int(h)))
+        self._frame = parent[y:y + h, x:x + w]
+        self._size = (int(w), int(h))
+
     def load_frame_device(self, data_ptr, w, h):
         """Frame already in HBM (e.g. a slab frame of IngestQueue.batch()); get_cpu_frame() is then None."""
         L.check(self._lib.smhv_load_frame_device(self._ctx, C.c_void_p(data_ptr), w, h))

@@ -781,3 +781,72 @@ def test_c_example_runs_the_trait_sequence_without_python(vision, tmp_path):
            for ln in out.stdout.splitlines() if ln.startswith("  (")]
     assert len(got) == ref["n_lines"] == 7
     assert np.allclose(np.array(got), ref["lines"], atol=0.051)            # printed with one decimal
+
+
+def test_decoded_images_enter_the_queue_as_the_reference_would_hash_them(vision):
+    """The decode half of row f4 (src/ui/debug.rs:169): RGB / RGBA / L / LA pixels from a host decoder become the BGRA bytes of
+    `into_bgra8` on the device, in front of the CRC and the duplicate rule (src/capture.rs:44-47)."""
+    import zlib
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H = 1282, 1023                                         # 1311486 pixels: not a multiple of the kernel's 4-pixel groups
+    A, _ = synth.make_frame(W, H, 5, n_lines=2)
+    rng = np.random.default_rng(11)
+    A[..., 3] = rng.integers(0, 256, (H, W), dtype=np.uint8)   # a decoder's alpha is not always 255
+    rgba = np.ascontiguousarray(A[..., [2, 1, 0, 3]])
+    rgb = np.ascontiguousarray(A[..., [2, 1, 0]])
+    lum = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    la = np.stack([lum, A[..., 3]], axis=-1)
+    seq = [("rgba", rgba), ("bgra", A), ("rgb", rgb), ("rgb", rgb), ("l", lum), ("la", la), ("bgra", o.into_bgra8(la, "la"))]
+    want = [o.into_bgra8(px, lay) for lay, px in seq]
+    assert np.array_equal(want[0], A)
+    keep, last = o.capture_dedupe([zlib.crc32(f.tobytes()) for f in want])
+    assert keep.tolist() == [True, False, True, False, True, True, False]
+    q = smh.IngestQueue(vision, W, H, slots=3, capacity=8)
+    for k, (lay, px) in enumerate(seq):
+        if k == 2:                                            # straight into pinned staging, then commit with the layout
+            buf = q.acquire()
+            buf.reshape(-1)[:px.size] = px.reshape(-1)
+            q.commit_pixels(lay)
+        else:
+            q.push_pixels(px, lay)
+    ptr, n, crc = q.batch()
+    assert n == int(keep.sum()) and crc == last and q.counts() == (4, 3)
+    nb = W * H * 4
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for i, f in enumerate([f for f, k in zip(want, keep) if k]):
+        got = np.empty((H, W, 4), np.uint8)
+        assert hip.hipMemcpy(got.ctypes.data, C.c_void_p(ptr + i * nb), nb, 2) == 0    # hipMemcpyDeviceToHost
+        assert np.array_equal(got, f), i
+        assert smh.crc32_device(vision, ptr + i * nb, nb) == zlib.crc32(f.tobytes())
+    with pytest.raises(KeyError):
+        q.push_pixels(rgb, "rgb16")
+    with pytest.raises(ValueError):
+        q.push_pixels(rgb, "rgba")
+
+
+def test_load_frame_view_is_load_frame_of_the_repacked_rectangle(vision):
+    """vision-gpu/src/lib.rs:175-179: a VisionFrame that is a rectangle of a larger image gives the results of its tight copy."""
+    from squad_mortar_helper_amd import synth
+    W, H = 1600, 900
+    f, _ = synth.make_frame(W, H, 21, n_lines=3)
+    rng = np.random.default_rng(3)
+    parent = rng.integers(0, 256, (H + 37, W + 51, 4), dtype=np.uint8)
+    x, y = 29, 17
+    parent[y:y + H, x:x + W] = f
+    ref = o.process_frame(f, stages=0xF, want_images=True)
+    for view in (True, False):
+        if view:
+            vision.load_frame_view(parent, x, y, W, H)
+        else:
+            big = np.zeros((H + 5, W, 4), np.uint8); big[3:3 + H] = f
+            vision.load_frame_view(big, 0, 3, W, H)            # full rows: the tight fast path
+        ui, roi = vision.crop_to_map(True)
+        vision.isolate_map_markers(); vision.mask_marker_lines()
+        assert np.array_equal(ui, ref["ui_map"]) and np.array_equal(vision.find_marker_lines(15), ref["lines"])
+        assert np.array_equal(vision.get_cpu_frame(), f)
+    import squad_mortar_helper_amd as smh
+    with pytest.raises(smh.VisionError):
+        vision.load_frame_view(parent, W, 0, 100, 100)

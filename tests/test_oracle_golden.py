@@ -381,3 +381,17 @@ def test_brq_stages_second_restatement():
     frame, e, g_ = fx.load_fixture("point_intersect_png")
     brq = o.crop_to_map(frame)["cropped_brq"]
     assert np.array_equal(ocr(brq), o.ocr_preprocess(brq))
+
+
+def test_into_bgra8_restatement_on_hand_vectors():
+    """image 0.23.14 `into_bgra8` for 8-bit decoder outputs (src/ui/debug.rs:169): channel order and the alpha rule."""
+    rgb = np.array([[[1, 2, 3], [250, 128, 0]]], np.uint8)
+    assert o.into_bgra8(rgb, "rgb").tolist() == [[[3, 2, 1, 255], [0, 128, 250, 255]]]
+    rgba = np.array([[[1, 2, 3, 4], [9, 8, 7, 0]]], np.uint8)
+    assert o.into_bgra8(rgba, "rgba").tolist() == [[[3, 2, 1, 4], [7, 8, 9, 0]]]
+    assert o.into_bgra8(np.array([[7, 200]], np.uint8), "l").tolist() == [[[7, 7, 7, 255], [200, 200, 200, 255]]]
+    assert o.into_bgra8(np.array([[[7, 1], [200, 77]]], np.uint8), "la").tolist() == [[[7, 7, 7, 1], [200, 200, 200, 77]]]
+    bgra = np.arange(16, dtype=np.uint8).reshape(1, 4, 4)
+    assert np.array_equal(o.into_bgra8(bgra, "bgra"), bgra)
+    # the round trip the fake-input path relies on: a BGRA frame saved as RGBA and decoded again is the same frame
+    assert np.array_equal(o.into_bgra8(bgra[..., [2, 1, 0, 3]], "rgba"), bgra)
