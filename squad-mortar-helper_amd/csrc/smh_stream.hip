@@ -895,6 +895,8 @@ uint32_t map_brq_lds_bytes(const Geom &g) { return map_brq_static_lds() + (g.m_b
 hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
                                const LaunchTuning *tune) {
 	uint32_t RB = MAPQ_RB_MAX;
+	static const int rb_env = [] { const char *e = getenv("SMH_MAP_RB"); return e ? atoi(e) : 0; }();   // diagnostic: band height
+	if (rb_env >= 8 && rb_env <= (int)MAPQ_RB_MAX) RB = (uint32_t)rb_env;
 	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
 	const uint32_t nbands = (g.rh + RB - 1) / RB, items = nbands * n;
 	// diagnostics (override the caller's policy): SMH_MAP_LDS_PAD=<bytes> enlarges the LDS request (fewer streaming workgroups
