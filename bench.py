@@ -591,7 +591,7 @@ def main():
         raise SystemExit("bench.py: pipeline slots %s hold records that differ from slot 0's (same frames, same stages)" % bad)
 
     # ---- the same workload with ONE batch in flight, and one pass alone for the per-stage durations in isolation ----
-    value_d1 = ms_d1 = iso_ms = d1_minmax = None
+    value_d1 = ms_d1 = iso_ms = d1_minmax = b2b_ms = None
     if not args.no_depth1 or not args.no_stage_timing:
         pipe1 = smh.Pipeline(vision, W, H, n, 1)
         if not args.no_depth1:
@@ -615,6 +615,29 @@ def main():
             iso_ms = fb_iso.stage_ms()
             assert bytes(fb_iso.read_results(0, n)) == slot_bytes[0], "a plain smhv_batch_run's records differ from the pipeline's"
             fb_iso.close()
+            if (stages & 0xC) and (stages & 0x3):
+                # The streaming pass back to back with itself: plain runs WITHOUT the line search (debug knob) on four
+                # streams, so that one launch's tail overlaps the next one's head -- the kernel's steady rate, which is what
+                # the device-copy calibration below measures for a copy (ten copies back to back).  One launch alone pays a
+                # fixed 0.08-0.11 ms on top ("the fixed cost of a streaming-pass launch").
+                lib = smh._lib.load()
+                fbs = [smh.FrameBatch(vision, W, H, n) for _ in range(4)]
+                sts = [torch.cuda.Stream() for _ in fbs]
+                try:
+                    smh._lib.check(lib.smhv_debug_skip_line_search(1))
+                    reps = 8
+                    for timed_round in (False, True):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(reps if timed_round else 2):
+                            for fbk, stk in zip(fbs, sts):
+                                fbk.run(fptr, n, stages=stages, grayscale=True, max_gap=15, anchors=anchors, stream=stk.cuda_stream)
+                        torch.cuda.synchronize()
+                        b2b_ms = (time.perf_counter() - t0) * 1e3 / (reps * len(fbs))
+                finally:
+                    smh._lib.check(lib.smhv_debug_skip_line_search(0))
+                    for fbk in fbs:
+                        fbk.close()
         pipe1.close()
 
     # ---- result sanity + workload statistics (outside the timed region) ----
@@ -701,6 +724,12 @@ def main():
             a2 = n * kernel_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9
             out["roofline_isolated"] = {"kernel": kname, "achieved": a2, "frac": a2 / HBM_PEAK_GBS, "unit": "GB/s",
                                         "launch_ms": iso_ms["map_pass"], "stages_ms": iso_ms}
+            if b2b_ms is not None:
+                a3 = n * kernel_bytes / (b2b_ms * 1e-3) / 1e9
+                out["roofline_isolated"]["back_to_back"] = {
+                    "ms_per_pass": b2b_ms, "achieved": a3, "frac": a3 / HBM_PEAK_GBS, "unit": "GB/s",
+                    "what": "button + streaming pass + record kernel of plain runs on four streams, line search skipped "
+                            "(smhv_debug_skip_line_search): wall time per pass; algorithmic bytes of the streaming pass only"}
             # calibration on THIS box (they differ by 10 %): a plain device-to-device copy moving the same number of bytes
             # (half read, half written); outside every timed region
             try:

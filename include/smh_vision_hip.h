@@ -245,6 +245,10 @@ SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
  * find_lines launch, 128..1024 (multiples of 64) force k_lsd_tile with that workgroup size, 0 restores the library's choice.
  * The tests run every scene through all three kernels. */
 SMHV_API int smhv_debug_lsd_threads(uint32_t threads);
+/* diagnostic (process-wide; also SMH_SKIP_LSD=1): batched runs launch everything but the line search, so that the streaming
+ * pass can be timed back to back with itself (bench.py, roofline_isolated.back_to_back).  The records of such a run hold no
+ * valid lines. */
+SMHV_API int smhv_debug_skip_line_search(int on);
 /* diagnostic (process-wide): idle polls (about 0.25 us each) a wave of k_lsd_tile may spend without progress before the
  * watchdog gives its frame up (SMHV_FRAME_LSD_STUCK).  0 restores the default (4,000,000: about a second).  The tests lower
  * it to 1 to force the error path. */

@@ -384,6 +384,7 @@ extern "C" SMHV_API int smhv_thread_ctx(smhv_ctx *c) {
 	return SMHV_OK;
 }
 
+static std::atomic<bool> g_skip_lsd{[] { const char *e = getenv("SMH_SKIP_LSD"); return e && atoi(e) != 0; }()};
 extern "C" SMHV_API int smhv_debug_lsd_classic(int on) {
 	lsd_set_classic(on != 0);
 	return SMHV_OK;
@@ -391,6 +392,11 @@ extern "C" SMHV_API int smhv_debug_lsd_classic(int on) {
 
 extern "C" SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap) {
 	lsd_set_tile_cap(cap);
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_debug_skip_line_search(int on) {
+	g_skip_lsd.store(on != 0, std::memory_order_relaxed);
 	return SMHV_OK;
 }
 
@@ -642,7 +648,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	HIPCHK(hipEventRecord(b->ev_map_done, s));
 	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[1], s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
-	static const bool skip_lsd = [] { const char *e = getenv("SMH_SKIP_LSD"); return e && atoi(e) != 0; }();   // diagnostic: time the streaming pass with every output, no search
+	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (SMH_SKIP_LSD=1, smhv_debug_skip_line_search): the streaming pass with every output, no search
 	STAGE_BEGIN(3, sl);
 	if ((stages & SMHV_STAGE_MARKERS) && !skip_lsd) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic,
 	                                                      (mflags && qflags) ? b->tune.lsd_tile_limit : 0u,   // (the limit makes room for the fused pass's reservation: no fused pass, no limit)
