@@ -93,6 +93,7 @@ struct BatchError {
 // (mask, pixel)).  Every word below is ONE 8-byte agent-scope atomic (a granule is never torn, needs no fence); the three
 // payload words of a result are stored, drained (s_waitcnt vmcnt(0)), then the tagged word.
 #define SMH_FARM_RING 4u
+#define SMH_REC_ON 0x80000000u
 struct FarmEntry {                  // 64 bytes
 	unsigned long long post;        // owner -> helper: epoch16 << 48 | (k + 1)24 << 24 | py12 << 12 | px12   (k = posts so far)
 	unsigned long long best;        // helper -> owner: max over rays of (len^2 bits << 32 | ray index)
@@ -111,7 +112,12 @@ struct FarmFrame {                  // one per helper workgroup of the launch
 struct Buffers {
 	BatchError *err;         // device address of the batch's mailbox (null: none)
 	FarmFrame *farm;         // helper exchange of k_lsd_tile, n_farm entries (null / 0: no helpers in this launch)
-	uint32_t n_farm, farm_pad;
+	uint32_t n_farm;
+	// k_lsd_tile writes the frame's record itself (smh_record.inc: scale ratio + derived marker outputs) when SMH_REC_ON is set:
+	// rec_stages = SMH_REC_ON | the run's stage mask (SMHV_STAGE_SCALES cleared when the run has no anchors), rec_bars = the
+	// scale-bar debug slab or null
+	uint32_t rec_stages;
+	uint32_t *rec_bars;
 	const uint8_t *frames;   // n * frame_bytes
 	uint8_t *ui, *mask, *ocr, *scales;
 	uint32_t *bits;
@@ -175,8 +181,10 @@ bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame
 // better: smhv_pipeline at depth 2 on frames up to 1080p) or the process-wide diagnostic switch is.
 // tile_bs: threads per workgroup of k_lsd_tile (0: 512; a batch that runs alone takes 1024); 64 selects k_lsd_seq, the
 // one-wave-per-frame sequential scan (deep pipelines: least wave-time per frame, longest time to a frame's result)
+// record_fused (optional) <- whether the launch writes the frames' records itself (b.rec_stages has SMH_REC_ON and the kernel
+// picked is k_lsd_tile); otherwise the caller launches the record kernel behind it
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs = 0,
-                      bool prefer_classic = false, uint32_t tile_limit = 0, uint32_t n_helpers = 0);
+                      bool prefer_classic = false, uint32_t tile_limit = 0, uint32_t n_helpers = 0, bool *record_fused = nullptr);
 size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocation, zeroed per launch)
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);

@@ -13,6 +13,7 @@
 
 #include "smh_device.h"
 #include "smh_proximity.h"
+#include "smh_record.inc"
 
 namespace smh {
 
@@ -1339,7 +1340,8 @@ uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit) {
 }
 
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs, bool prefer_classic,
-                      uint32_t tile_limit, uint32_t n_helpers) {
+                      uint32_t tile_limit, uint32_t n_helpers, bool *record_fused) {
+	if (record_fused) *record_fused = false;
 	const unsigned lds_full = LSD_DYN_LDS_BYTES;
 	// more than 64 KB of dynamic LDS has to be allowed per function and per device
 	static std::atomic<uint64_t> attr_devices{0};
@@ -1377,6 +1379,7 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u + lds_pad, LSD_TILE_DYN_LDS_MAX);
 		Buffers bh = b;                                          // helper workgroups beyond the frames (smh_kernels.h, FarmFrame)
 		bh.n_farm = bh.farm ? n_helpers : 0u;
+		if (record_fused) *record_fused = (bh.rec_stages & SMH_REC_ON) != 0u;
 		hipLaunchKernelGGL(k_lsd_tile, dim3(n + bh.n_farm), dim3(bs), t_lds, s, g, bh, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed), tile_list_cap_for(g), n);
 		return hipGetLastError();
 	}

@@ -11,95 +11,9 @@
 // part of the contract.  Semantics follow the reference's CPU back-end (vision-cpu/src/lib.rs) bit for bit;
 // structure does not follow its CUDA file at all (SURVEY.md Appendix A lists how that differs).
 #include "smh_device.h"
+#include "smh_record.inc"
 
 namespace smh {
-
-// ------------------------------------------------------------------------------------------------
-// k_scale_ratio: src/vision/mpx_ratio.rs.  One wave per OCR label anchor (<= 3 per frame).  The scan
-// order of the reference is kept (rows downwards from the anchor; first tick column to the right,
-// then to the left), but each "first column whose 4 pixels below are all 0" search tests 64 columns
-// per step and takes the first hit with a ballot.  Pixels below the image count as non-zero
-// (reference: unchecked read).
-// ------------------------------------------------------------------------------------------------
-__device__ bool find_scale_width(const uint8_t *img, size_t pitch, uint32_t w, uint32_t h, uint32_t meters, uint32_t x, uint32_t y, double *ratio,
-                                 uint32_t bar[3]) {
-	const uint32_t lane = threadIdx.x & 63u;
-	if (y < SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT || x >= w) return false;
-	// ((20.0 / 640.0) * w as f64).round(): 0.03125*w has at most 5 fractional bits, so t + 0.5 is exact
-	// and floor(t + 0.5) is round-half-away-from-zero for t >= 0
-	const double t = (20.0 / 640.0) * (double)w;
-	const uint32_t max_off = (uint32_t)floor(t + 0.5);
-	const uint32_t y_end = min(h, y + max_off);
-	auto tick = [&](uint32_t xx, uint32_t yy) -> bool {    // rows yy..yy+3 of column xx all 0
-		bool all0 = true;
-		for (uint32_t ty = yy; ty < yy + SMH_MIN_SCALE_VERTICAL_BAR_HEIGHT; ++ty) all0 = all0 && ty < h && img[(size_t)ty * pitch + xx] == 0;
-		return all0;
-	};
-	for (uint32_t yy = y; yy < y_end; ++yy) {
-		if (img[(size_t)yy * pitch + x] != 0) continue;      // wave-uniform
-		uint32_t right = 0;
-		for (uint32_t base = x; base < w; base += 64u) {     // Go right...
-			const uint32_t xx = base + lane;
-			const uint64_t hit = __ballot(xx < w && tick(xx, yy));
-			if (hit) { right = base + (uint32_t)__builtin_ctzll(hit); break; }
-		}
-		if (right == 0) continue;
-		right -= 1;
-		uint32_t left = 0;
-		bool found = false;
-		for (uint32_t base = 0; base < x; base += 64u) {     // Go left... (columns x-1, x-2, ...)
-			const uint32_t off = base + lane;
-			const uint64_t hit = __ballot(off < x && tick(x - 1u - off, yy));
-			if (hit) { left = x - 1u - (base + (uint32_t)__builtin_ctzll(hit)); found = true; break; }
-		}
-		(void)found;
-		if (left == 0) continue;
-		left += 1;
-		const uint32_t width = right - left;   // wraps like release Rust (mpx_ratio.rs:58)
-		if (width < SMH_MIN_SCALE_WIDTH) continue;
-		bar[0] = left; bar[1] = yy; bar[2] = right;
-		*ratio = (double)meters / (double)width;
-		return true;
-	}
-	return false;
-}
-
-// (block of 64 * SMHV_MAX_SCALES threads; ends with the result in results[f].has_mpx / mpx, written by thread 0)
-__device__ __forceinline__ void scale_ratio_body(const Geom &g, const Buffers &b, uint32_t f, uint32_t *bars) {
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	__shared__ double s_ratio[SMHV_MAX_SCALES];
-	__shared__ uint32_t s_ok[SMHV_MAX_SCALES];
-	smhv_frame_result *res = &b.results[f];
-	const bool open = b.aux[f].open != 0;
-	const smhv_anchors an = b.anchors[f];
-	const uint32_t n = open ? min(an.n, (uint32_t)SMHV_MAX_SCALES) : 0u;
-	const bool valid = an.scales_start_y <= g.qh;
-	{
-		double r = 0.0;
-		uint32_t bar[3] = {0, 0, 0};
-		bool ok = false;
-		if (wave < n && valid) {                               // wave-uniform
-			const uint8_t *img = b.scales + (size_t)f * g.ocr_stride + g.q_xoff;
-			ok = find_scale_width(img, g.ocr_pitch, g.qw, g.qh, an.scales[wave][0], an.scales[wave][1], an.scales[wave][2], &r, bar);
-		}
-		if (lane == 0) {
-			s_ratio[wave] = r; s_ok[wave] = ok ? 1u : 0u;
-			if (bars) {
-				uint32_t *o = bars + ((size_t)f * SMHV_MAX_SCALES + wave) * 4;
-				o[0] = bar[0]; o[1] = bar[1]; o[2] = bar[2]; o[3] = ok ? 1u : 0u;
-			}
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		// the "Rayon ladder" (mpx_ratio.rs:93-125): mean of the successes, summed in index order
-		double sum = 0.0; uint32_t k = 0;
-		for (uint32_t i = 0; i < SMHV_MAX_SCALES; ++i)
-			if (s_ok[i]) { sum = k ? sum + s_ratio[i] : s_ratio[i]; ++k; }
-		res->has_mpx = k ? 1u : 0u;
-		res->mpx = k == 0 ? 0.0 : (k == 1 ? sum : sum / (double)k);
-	}
-}
 
 __global__ void __launch_bounds__(64 * SMHV_MAX_SCALES) k_scale_ratio(Geom g, Buffers b, uint32_t *bars) { scale_ratio_body(g, b, blockIdx.x, bars); }
 
@@ -176,55 +90,6 @@ __global__ void __launch_bounds__(256) k_find_minimap(Geom g, Buffers b) {
 	const uint32_t v = find_edge(roi0, g.W, g.rw, g.rh, g.rw / 2u, g.rh / 2u, dir);
 	if (lane == 0) res->minimap[wave] = v;
 	if (threadIdx.x == 0) res->has_minimap = 1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_finalize: per-frame record header + ui::Marker::new / angle (src/ui/mod.rs:131-140, markers.rs:98)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void finalize_body(const Geom &g, const Buffers &b, uint32_t f, uint32_t stages) {
-	const uint32_t l = threadIdx.x;
-	smhv_frame_result *res = &b.results[f];
-	const FrameAux aux = b.aux[f];
-	const bool open = aux.open != 0;
-	const bool markers = (stages & SMHV_STAGE_MARKERS) != 0;
-	const uint32_t n = (open && markers) ? res->n_lines : 0u;
-	const bool has_mpx = open && (stages & SMHV_STAGE_SCALES) && res->has_mpx;
-	const double mpx = has_mpx ? res->mpx : 0.0;
-	if (l < SMHV_MAX_LINES) {
-		double len = 0.0, met = 0.0;
-		float ang = 0.0f;
-		smhv_line ln = {0.0f, 0.0f, 0.0f, 0.0f};
-		if (l < n) {
-			ln = res->lines[l];
-			const double ax = (double)ln.x0 - (double)ln.x1, ay = (double)ln.y0 - (double)ln.y1;
-			len = sqrt(ax * ax + ay * ay);
-			met = has_mpx ? len * mpx : 0.0;
-			ang = atan2f(ln.y0 - ln.y1, ln.x0 - ln.x1);
-		}
-		res->lines[l] = ln;
-#ifdef SMH_LSD_PROFILE
-		if (l < 20)
-#endif
-		res->length_px[l] = len;
-#ifdef SMH_LSD_PROFILE
-		if (l < 16)
-#endif
-		res->angle[l] = ang;
-#ifdef SMH_LSD_PROFILE
-		if (l < 20)
-#endif
-		res->meters[l] = met;
-	}
-	if (l == 0) {
-		res->map_open = open ? 1u : 0u;
-		res->n_lines = n;
-		res->mpx = mpx; res->has_mpx = has_mpx ? 1u : 0u;
-		res->n_mask_px = (open && markers) ? aux.n_mask_px : 0u;
-		res->red_pixels = aux.red;
-		if (!(open && markers)) { res->rounds = 0; res->ray_steps = 0; }
-		if (!(stages & SMHV_STAGE_MINIMAP)) { res->has_minimap = 0; res->minimap[0] = 0; res->minimap[1] = 0; res->minimap[2] = 0; res->minimap[3] = 0; }
-		if (!(open && markers)) res->status = SMHV_FRAME_OK;          // otherwise the line search's verdict stands
-	}
 }
 
 __global__ void __launch_bounds__(64) k_finalize(Geom g, Buffers b, uint32_t stages) { finalize_body(g, b, blockIdx.x, stages); }

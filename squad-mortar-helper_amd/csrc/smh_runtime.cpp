@@ -290,7 +290,7 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
 	bf.err = b->d_err;
-	bf.farm = b->d_farm; bf.n_farm = 0u; bf.farm_pad = 0u;
+	bf.farm = b->d_farm; bf.n_farm = 0u; bf.rec_stages = 0u; bf.rec_bars = nullptr;
 	bf.cull_tab = nullptr;
 	bf.ray_off = b->ctx->d_ray_off;
 	bf.frames = frames;
@@ -650,14 +650,24 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (SMH_SKIP_LSD=1, smhv_debug_skip_line_search): the streaming pass with every output, no search
 	STAGE_BEGIN(3, sl);
+	// The workgroups of k_lsd_tile write their frames' records themselves (scale ratio + derived marker outputs, smh_record.inc):
+	// one kernel less in the batch's chain on its hardware queue (with stage timing on, the record's share is then inside the
+	// search's and stage 4 reads zero).  Not with the minimap stage: its kernel comes in between.
+	bool record_fused = false;
+	static const bool fuse_off = [] { const char *e = getenv("SMH_FUSE_RECORD"); return e && atoi(e) == 0; }();   // diagnostic: SMH_FUSE_RECORD=0
+	if (!fuse_off && !(stages & SMHV_STAGE_MINIMAP)) {
+		bf.rec_stages = SMH_REC_ON | (scales ? stages : (stages & ~SMHV_STAGE_SCALES));
+		bf.rec_bars = b->d_bars;
+	}
 	if ((stages & SMHV_STAGE_MARKERS) && !skip_lsd) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic,
 	                                                      (mflags && qflags) ? b->tune.lsd_tile_limit : 0u,   // (the limit makes room for the fused pass's reservation: no fused pass, no limit)
-	                                                      lsd_helpers_for(b, n)));
+	                                                      lsd_helpers_for(b, n), &record_fused));
 	STAGE_END(3, sl);
 	if (b->probe) { HIPCHK(hipEventRecord(b->ev_probe[2], sl)); b->probe_valid = (stages & SMHV_STAGE_MARKERS) && mflags && qflags; }
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
 	STAGE_BEGIN(4, sl);
-	if (scales) HIPCHK(launch_scales_finalize(g, bf, n, stages, b->d_bars, sl));
+	if (record_fused) { /* written by the search's own workgroups */ }
+	else if (scales) HIPCHK(launch_scales_finalize(g, bf, n, stages, b->d_bars, sl));
 	else HIPCHK(launch_finalize(g, bf, n, stages & ~SMHV_STAGE_SCALES, sl));
 	STAGE_END(4, sl);
 #undef STAGE_BEGIN
