@@ -27,12 +27,24 @@ __global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_ope
 	__syncthreads();
 	uint32_t cnt = 0;
 	const uint32_t npx = g.bw * g.bh;
-	for (uint32_t i = threadIdx.x; i < npx; i += blockDim.x) {
-		const uint32_t y = i / g.bw, x = i - y * g.bw;
-		const uint32_t p = *(const uint32_t *)(fp + ((size_t)(g.by + y) * g.W + g.bx + x) * 4);   // B | G<<8 | R<<16 | A<<24
-		const uint32_t bb = p & 255u, gg = (p >> 8) & 255u, rr = (p >> 16) & 255u;
-		cnt += (absdiff(SMH_BUTTON_R, rr) <= SMH_BUTTON_TOLERANCE && absdiff(SMH_BUTTON_G, gg) <= SMH_BUTTON_TOLERANCE &&
-		        absdiff(SMH_BUTTON_B, bb) <= SMH_BUTTON_TOLERANCE) ? 1u : 0u;
+	// eight pixels per thread and round, loaded together: the kernel is a chain of load latencies (10 k pixels per frame), and
+	// in a pipeline it sits at the head of every batch's chain
+	constexpr uint32_t U = 8;
+	for (uint32_t i0 = threadIdx.x; i0 < npx; i0 += blockDim.x * U) {
+		uint32_t p[U];
+#pragma unroll
+		for (uint32_t k = 0; k < U; ++k) {
+			const uint32_t i = min(i0 + k * blockDim.x, npx - 1u);
+			const uint32_t y = i / g.bw, x = i - y * g.bw;
+			p[k] = *(const uint32_t *)(fp + ((size_t)(g.by + y) * g.W + g.bx + x) * 4);   // B | G<<8 | R<<16 | A<<24
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < U; ++k) {
+			const uint32_t bb = p[k] & 255u, gg = (p[k] >> 8) & 255u, rr = (p[k] >> 16) & 255u;
+			const bool red = absdiff(SMH_BUTTON_R, rr) <= SMH_BUTTON_TOLERANCE && absdiff(SMH_BUTTON_G, gg) <= SMH_BUTTON_TOLERANCE &&
+			                 absdiff(SMH_BUTTON_B, bb) <= SMH_BUTTON_TOLERANCE;
+			cnt += (red && i0 + k * blockDim.x < npx) ? 1u : 0u;
+		}
 	}
 	cnt = wave_sum32(cnt);
 	if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, cnt);
