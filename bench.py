@@ -87,6 +87,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
+    ap.add_argument("--no-back-to-back", action="store_true",
+                    help="skip the back-to-back leg of the streaming pass (profiled runs: its overlapping launches would be averaged "
+                         "into the kernel's isolated duration)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-box testing of the N>1 code path)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -615,7 +618,7 @@ def main():
             iso_ms = fb_iso.stage_ms()
             assert bytes(fb_iso.read_results(0, n)) == slot_bytes[0], "a plain smhv_batch_run's records differ from the pipeline's"
             fb_iso.close()
-            if (stages & 0xC) and (stages & 0x3):
+            if (stages & 0xC) and (stages & 0x3) and not args.no_back_to_back:
                 # The streaming pass back to back with itself: plain runs WITHOUT the line search (debug knob) on four
                 # streams, so that one launch's tail overlaps the next one's head -- the kernel's steady rate, which is what
                 # the device-copy calibration below measures for a copy (ten copies back to back).  One launch alone pays a

@@ -1,0 +1,14 @@
+#!/bin/bash
+# tools/profile_final.sh <tag> -- run ON THE GPU BOX: everything profiles/<tag>_* is made of, one box for all of it:
+# the GPU test suite, profile_round.sh (kernel stats depth 1 / 4, PMC traffic, bench configs 1-3, depth 1), SQ counters at depth 1
+# and 4, bench configs 0 and 4, the sample-screenshot bench.
+set -u
+TAG=${1:-rXX}
+mkdir -p gpurun_out
+[ -n "${SKIP_TESTS:-}" ] || { timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_tests.log 2>&1; tail -2 gpurun_out/${TAG}_gpu_tests.log; }
+bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile_round.log 2>&1
+bash tools/profile_sq.sh $TAG > /dev/null 2>&1
+PDEPTH=4 bash tools/profile_sq.sh ${TAG}_d4 > /dev/null 2>&1
+for C in 0 4; do timeout 900 python bench.py --config $C 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_config$C.json; done
+timeout 600 python tools/bench_samples.py 128 4 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/${TAG}_samples.txt
+ls -la gpurun_out | grep "${TAG}_" | head -40

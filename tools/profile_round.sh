@@ -11,7 +11,7 @@ R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1"   # profiled runs: only warm-up, timed and isolated passes
+B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back"   # profiled runs: only warm-up, timed and isolated passes
 for C in 2 3; do
   P=""; [ $C = 3 ] && P="c3_"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${P}d1 -- $B --config $C --steps 3 --warmup 1 --pipeline-depth 1 > $OUT/${TAG}_${P}bench_profiled_d1.json 2>/dev/null
