@@ -55,6 +55,12 @@ def main():
     print("rounds per frame: %s" % [int(r.rounds) for r in ref])
     print("GPU: %.0f frames/s (%.3f ms per %d-frame step, smhv_pipeline depth %d); lines + rounds equal to the oracle: %s" % (n * steps / dt, dt / steps * 1e3, n, depth, ok))
     print("CPU oracle: %.1f frames/s on %d threads (%.2f s for %d frames)" % (k / cdt, min(os.cpu_count() or 1, k), cdt, k))
+    import json
+    print(json.dumps({"metric": "map frames/sec (2560x1440 sample screenshots, stages 0x%x), one GPU" % STAGES, "value": n * steps / dt, "unit": "frames/s",
+                      "ms_per_step": dt / steps * 1e3, "config": {"workload": "%d distinct 2560x1440 frames rebuilt from tests/golden, cycled through a batch of %d" % (k, n),
+                                                                "batch": n, "pipeline_depth": depth, "stages": STAGES},
+                      "rounds_per_frame": [int(r.rounds) for r in ref], "records_equal_oracle": bool(ok),
+                      "cpu_oracle_frames_per_s": k / cdt, "cpu_threads": min(os.cpu_count() or 1, k), "data": "the reference's sample screenshots"}))
     sys.exit(0 if ok else 1)
 
 

@@ -10,5 +10,6 @@ bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile_round.log 2>&1
 bash tools/profile_sq.sh $TAG > /dev/null 2>&1
 PDEPTH=4 bash tools/profile_sq.sh ${TAG}_d4 > /dev/null 2>&1
 for C in 0 4; do timeout 900 python bench.py --config $C 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_config$C.json; done
-timeout 600 python tools/bench_samples.py 128 4 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/${TAG}_samples.txt
+timeout 600 python tools/bench_samples.py 128 4 2>&1 | grep -v amdgpu.ids | tail -5 > gpurun_out/${TAG}_samples.txt
+tail -1 gpurun_out/${TAG}_samples.txt > gpurun_out/${TAG}_samples.json
 ls -la gpurun_out | grep "${TAG}_" | head -40
