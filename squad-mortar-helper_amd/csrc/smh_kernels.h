@@ -94,6 +94,7 @@ struct BatchError {
 // payload words of a result are stored, drained (s_waitcnt vmcnt(0)), then the tagged word.
 #define SMH_FARM_RING 4u
 #define SMH_REC_ON 0x80000000u
+#define SMH_LSD_LATE_HELP 1u
 struct FarmEntry {                  // 64 bytes
 	unsigned long long post;        // owner -> helper: epoch16 << 48 | (k + 1)24 << 24 | py12 << 12 | px12   (k = posts so far)
 	unsigned long long best;        // helper -> owner: max over rays of (len^2 bits << 32 | ray index)
@@ -102,10 +103,13 @@ struct FarmEntry {                  // 64 bytes
 	unsigned long long done;        //   tag32 << 32 | steps, tag = epoch16 << 16 | (k + 1)16: written last
 	unsigned long long pad[3];
 };
-struct FarmFrame {                  // one per helper workgroup of the launch
+struct FarmFrame {                  // one per helper workgroup of the launch (late helpers: one per frame)
 	unsigned long long attached;    // helper -> owner: epoch when the helper has built its tile store and listens
 	unsigned long long owner_done;  // owner -> helper: epoch when the frame is finished
-	unsigned long long pad[6];
+	// late helpers (SMH_LSD_LATE_HELP): a workgroup that has finished its own frame helps one that is still at work
+	unsigned long long want;        // owner -> anybody: epoch16 << 48 | survivor-list entries still to visit (refreshed now and then)
+	unsigned long long claimed;     // finished workgroup -> the others: epoch when one of them has taken this frame (compare-and-swap)
+	unsigned long long pad[4];
 	FarmEntry ring[SMH_FARM_RING];
 };
 
@@ -118,6 +122,8 @@ struct Buffers {
 	// scale-bar debug slab or null
 	uint32_t rec_stages;
 	uint32_t *rec_bars;
+	uint32_t lsd_flags, lsd_late_kc; // SMH_LSD_LATE_HELP: `farm` holds one entry per frame and finished workgroups help frames still at work
+	                                 // lsd_late_kc x 1024 cycles after they began
 	const uint8_t *frames;   // n * frame_bytes
 	uint8_t *ui, *mask, *ocr, *scales;
 	uint32_t *bits;

@@ -290,7 +290,7 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
 	bf.err = b->d_err;
-	bf.farm = b->d_farm; bf.n_farm = 0u; bf.rec_stages = 0u; bf.rec_bars = nullptr;
+	bf.farm = b->d_farm; bf.n_farm = 0u; bf.rec_stages = 0u; bf.rec_bars = nullptr; bf.lsd_flags = 0u; bf.lsd_late_kc = 0u;
 	bf.cull_tab = nullptr;
 	bf.ray_off = b->ctx->d_ray_off;
 	bf.frames = frames;
@@ -476,7 +476,7 @@ static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_f
 	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
 	ALLOC0(b->d_lsd_ctl, lsd_coop_ctl_bytes(max_frames));
 	ALLOC0(b->d_lsd_req, sizeof(uint32_t) * SMH_LSD_REQ_CAP * n);
-	ALLOC0(b->d_farm, sizeof(FarmFrame) * ((n + 1) / 2));
+	ALLOC0(b->d_farm, sizeof(FarmFrame) * n);                  // (static helpers use up to n / 2 entries, late helpers one per frame)
 	ALLOC0(b->d_lsd_cache, sizeof(LsdCacheEntry) * SMH_LSD_CACHE_SLOTS * n);
 #undef ALLOC0
 	{
@@ -653,6 +653,10 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	// The workgroups of k_lsd_tile write their frames' records themselves (scale ratio + derived marker outputs, smh_record.inc):
 	// one kernel less in the batch's chain on its hardware queue (with stage timing on, the record's share is then inside the
 	// search's and stage 4 reads zero).  Not with the minimap stage: its kernel comes in between.
+	// opt-in (SMH_LSD_LATE=1, or =<thousands of cycles a frame must have been at work>): workgroups of k_lsd_tile that have finished
+	// their frame help one that is still at work (smh_kernels.h, FarmFrame::want)
+	static const int late_help = [] { const char *e = getenv("SMH_LSD_LATE"); return e ? atoi(e) : 0; }();
+	if (late_help > 0 && lsd_helpers_for(b, n) == 0u) { bf.lsd_flags |= SMH_LSD_LATE_HELP; bf.lsd_late_kc = late_help == 1 ? 1074u : (uint32_t)late_help; }
 	bool record_fused = false;
 	static const bool fuse_off = [] { const char *e = getenv("SMH_FUSE_RECORD"); return e && atoi(e) == 0; }();   // diagnostic: SMH_FUSE_RECORD=0
 	if (!fuse_off && !(stages & SMHV_STAGE_MINIMAP)) {

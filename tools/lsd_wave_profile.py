@@ -42,5 +42,10 @@ print("dispatch->retire latency: accepted %.3g cycles (%.1f per frame), rejected
 NWV = int(os.environ.get('SMH_W_BS', '1024')) // 64
 ft = P[:, 7] / NWV
 print("frame cycles (wave total / waves): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
-for i in np.argsort(-ft)[:4]:
-    print("  frame %d rounds %d units %d cands %d: %.3g cycles; shares %s" % (i, rounds[i], D[i, 0], D[i, 1], ft[i], ["%.0f%%" % (100 * P[i, k] / P[i, 7]) for k in range(7)]))
+mpx = np.array([raw[i].n_mask_px for i in range(N)])
+rank = np.argsort(np.argsort(-mpx))
+for i in np.argsort(-ft)[:8]:
+    print("  frame %d rounds %d units %d cands %d: %.3g cycles; mask px %d (rank %d of %d); cast by a helper %d; shares %s" % (
+        i, rounds[i], D[i, 0], D[i, 1], ft[i], mpx[i], rank[i], N, raw[i].length_px[27], ["%.0f%%" % (100 * P[i, k] / P[i, 7]) for k in range(7)]))
+print("mask px: median %d, 90th percentile %d, max %d; correlation of frame cycles with mask px %.2f, with rounds %.2f, with units %.2f" % (
+    np.median(mpx), np.percentile(mpx, 90), mpx.max(), np.corrcoef(ft, mpx)[0, 1], np.corrcoef(ft, rounds)[0, 1], np.corrcoef(ft, D[:, 0])[0, 1]))
