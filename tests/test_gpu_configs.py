@@ -820,3 +820,35 @@ def test_host_supplied_ray_table(vision):
     finally:
         vision.set_ray_table(dx, dy)
     assert np.array_equal(st.process(vision, frame).markers, g["lines"])
+
+
+def test_tracked_load_fallback_of_the_streaming_pass_gives_the_same_outputs():
+    """`make tracked` (what the build falls back to when tools/check_untracked_loads.py rejects the compiled streaming pass): the
+    same records and the same output images as the library with the hand-placed waits.  Own processes: one library each."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tracked = os.path.join(root, "squad-mortar-helper_amd", "libsmh_vision_hip_tracked.so")
+    if not os.path.exists(tracked):
+        pytest.skip("libsmh_vision_hip_tracked.so not built (__graft_entry__.build() builds it)")
+    code = ("import sys; sys.path.insert(0, %r); import hashlib, numpy as np, torch, squad_mortar_helper_amd as smh\n"
+            "from squad_mortar_helper_amd import synth\n"
+            "h = hashlib.sha256()\n"
+            "for (W, H, n) in ((1920, 1080, 12), (2560, 1440, 6), (1282, 1023, 5)):\n"
+            "    fr, inf = synth.make_batch(W, H, n, first_idx=4100, n_lines=3)\n"
+            "    a = smh.make_anchors([(i['scales_start_y'], i['anchors']) for i in inf]); d = torch.from_numpy(fr).cuda(); v = smh.HipVision.init(0)\n"
+            "    p = smh.Pipeline(v, W, H, n, 4); [p.submit(d.data_ptr(), n, anchors=a) for _ in range(5)]; p.wait()\n"
+            "    fb = smh.FrameBatch(v, W, H, n); fb.run(d.data_ptr(), n, anchors=a); torch.cuda.synchronize()\n"
+            "    for b in (p.slots[0], fb):\n"
+            "        h.update(bytes(b.read_results(0, n)))\n"
+            "        for f in range(n):\n"
+            "            for w in (smh._lib.IMAGE_UI_MAP, smh._lib.VIEW_LSD_INPUT, smh._lib.VIEW_OCR_INPUT, smh._lib.VIEW_FIND_SCALES_INPUT):\n"
+            "                h.update(b.read_image(w, f).tobytes())\n"
+            "print('SHA', h.hexdigest(), 'maps', open('/proc/self/maps').read().count('_tracked.so') > 0)\n") % root
+    outs = []
+    for env in ({}, dict(SMH_VISION_HIP_LIB=tracked)):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][-1].split())
+    assert outs[0][1] == outs[1][1], outs
+    assert outs[0][3] == "False" and outs[1][3] == "True", outs     # each process really had the library it was meant to have

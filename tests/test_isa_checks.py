@@ -13,3 +13,23 @@ def test_untracked_loads_of_the_streaming_pass_are_released_before_use():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_untracked_loads.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "4 instantiations checked, 0 problems" in r.stdout
+
+
+def test_build_falls_back_to_tracked_loads_when_the_check_fails(tmp_path):
+    """The Makefile's post-link gate: a compiler whose code the checker rejects must not produce a library with hand-placed
+    waits -- the library is rebuilt with loads the compiler tracks (-DSMH_TRACKED_LOADS), loudly; SMH_STRICT_ISA=1 fails instead."""
+    import ctypes
+    csrc = os.path.join(ROOT, "squad-mortar-helper_amd", "csrc")
+    out = str(tmp_path / "libsmh_fallback.so")
+    env = dict(os.environ, SMH_CHECK_FORCE_FAIL="1")
+    r = subprocess.run(["make", "-C", csrc, "-B", "OUT=" + out], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rebuilding with -DSMH_TRACKED_LOADS" in r.stdout and os.path.exists(out) and not os.path.exists(out + ".tmp")
+    code = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", out], capture_output=True, text=True)   # (just that it is a loadable object)
+    assert code.returncode == 0
+    lib = ctypes.CDLL(out)
+    assert hasattr(lib, "smhv_batch_run")
+    # the strict mode: no library at all
+    out2 = str(tmp_path / "libsmh_strict.so")
+    r = subprocess.run(["make", "-C", csrc, "-B", "OUT=" + out2], env=dict(env, SMH_STRICT_ISA="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and not os.path.exists(out2)

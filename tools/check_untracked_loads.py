@@ -109,6 +109,9 @@ def check_kernel(name, lines):
 
 
 def main():
+    if os.environ.get("SMH_CHECK_FORCE_FAIL"):                 # test hook: exercise the Makefile's fallback (tests/test_isa_checks.py)
+        print("k_map_brq_pass: check forced to fail (SMH_CHECK_FORCE_FAIL)")
+        return 1
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.run([HIPCC] + build_flags() + ["-x", "hip", os.path.realpath(SRC), "-c", "--save-temps", "-o", "out.o"], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
