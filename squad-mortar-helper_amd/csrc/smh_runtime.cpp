@@ -973,6 +973,9 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 			bb->probe_valid = false;
 		}
 		bb->tune = p->tune_on ? p->tuning : LaunchTuning{0u, 0u, 0u, 0u};
+		// a sample every fourth round of the slots is plenty for a running average, and the three timed events sit in the batch's
+		// chain on its hardware queue (the hand-over before the search: 33 us with them, 14 without)
+		bb->probe = (p->submitted / p->depth) % 4u == 0u;
 	}
 	hipStream_t st, sl;
 	if (p->stream_cus) {
