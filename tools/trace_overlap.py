@@ -34,3 +34,17 @@ for k in ("map", "search", "button", "record"):
     if d:
         print("  %-7s n %3d  mean %6.0f us  min %6.0f  max %6.0f" % (k, len(d), statistics.mean(d), min(d), max(d)))
 print("  kernels per queue:", dict(collections.Counter(e[3] for e in ev)))
+# the chain of a batch on its hardware queue: idle time in front of every kind of kernel (median per queue, then over the queues)
+byq = collections.defaultdict(list)
+for e in ev:
+    byq[e[3]].append(e)
+gap = collections.defaultdict(list)
+for q, es in byq.items():
+    es.sort()
+    for a, b2 in zip(es, es[1:]):
+        gap[b2[2]].append((b2[0] - a[1]) / 1e3)
+print("  idle time on a queue in front of: " + ", ".join("%s %.0f us" % (k, statistics.median(v)) for k, v in sorted(gap.items())))
+chain = sum(statistics.mean([(e[1] - e[0]) / 1e3 for e in ev if e[2] == k]) for k in ("map", "search", "button", "record") if any(e[2] == k for e in ev))
+chain += sum(statistics.median(v) for v in gap.values())
+nq = len(byq)
+print("  one batch's chain: %.0f us of kernels and hand-overs; %d queues -> %.3f ms per pass if nothing else bounds it" % (chain, nq, chain / nq / 1e3))
