@@ -171,6 +171,7 @@ struct smhv_batch {
 	// threads per workgroup of the line search (k_lsd_tile): 1024 for a batch that has the chip to itself, 512 for the batches of
 	// a pipeline (two workgroups per CU, and room for the streaming pass of the other batches beside them)
 	uint32_t lsd_farm_pct = 0;            // helper workgroups of k_lsd_tile, in percent of the frames of a run
+	uint32_t lsd_late_kc = 0;             // late helpers of k_lsd_tile: thousands of cycles a frame works alone before it asks (0 = none)
 	uint32_t lsd_bs = 1024;
 	bool lsd_prefer_classic = false;      // set by smhv_pipeline_create where the workgroup-synchronous k_lsd measures faster
 	LaunchTuning tune{0u, 0u, 0u, 0u};        // occupancy policy of a pipelined batch (smh_kernels.h); all zero for a batch that runs alone
@@ -650,13 +651,15 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (SMH_SKIP_LSD=1, smhv_debug_skip_line_search): the streaming pass with every output, no search
 	STAGE_BEGIN(3, sl);
+	// late helpers: workgroups of k_lsd_tile that have finished their frame help one that is still at work (smh_kernels.h,
+	// FarmFrame::want).  smhv_pipeline switches them on for search-bound workloads; SMH_LSD_LATE=0 / 1 / <thousands of cycles a
+	// frame must have been at work> overrides
+	static const int late_env = [] { const char *e = getenv("SMH_LSD_LATE"); return e ? atoi(e) : -1; }();   // -1: the batch's own setting (smhv_pipeline sets it for search-bound workloads)
+	const uint32_t late_kc = late_env < 0 ? b->lsd_late_kc : (late_env == 1 ? 1074u : (uint32_t)late_env);
+	if (late_kc > 0u && lsd_helpers_for(b, n) == 0u) { bf.lsd_flags |= SMH_LSD_LATE_HELP; bf.lsd_late_kc = late_kc; }
 	// The workgroups of k_lsd_tile write their frames' records themselves (scale ratio + derived marker outputs, smh_record.inc):
 	// one kernel less in the batch's chain on its hardware queue (with stage timing on, the record's share is then inside the
 	// search's and stage 4 reads zero).  Not with the minimap stage: its kernel comes in between.
-	// opt-in (SMH_LSD_LATE=1, or =<thousands of cycles a frame must have been at work>): workgroups of k_lsd_tile that have finished
-	// their frame help one that is still at work (smh_kernels.h, FarmFrame::want)
-	static const int late_help = [] { const char *e = getenv("SMH_LSD_LATE"); return e ? atoi(e) : 0; }();
-	if (late_help > 0 && lsd_helpers_for(b, n) == 0u) { bf.lsd_flags |= SMH_LSD_LATE_HELP; bf.lsd_late_kc = late_help == 1 ? 1074u : (uint32_t)late_help; }
 	bool record_fused = false;
 	static const bool fuse_off = [] { const char *e = getenv("SMH_FUSE_RECORD"); return e && atoi(e) == 0; }();   // diagnostic: SMH_FUSE_RECORD=0
 	if (!fuse_off && !(stages & SMHV_STAGE_MINIMAP)) {
@@ -667,7 +670,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	                                                      (mflags && qflags) ? b->tune.lsd_tile_limit : 0u,   // (the limit makes room for the fused pass's reservation: no fused pass, no limit)
 	                                                      lsd_helpers_for(b, n), &record_fused));
 	STAGE_END(3, sl);
-	if (b->probe) { HIPCHK(hipEventRecord(b->ev_probe[2], sl)); b->probe_valid = (stages & SMHV_STAGE_MARKERS) && mflags && qflags; }
+	if (b->probe) { HIPCHK(hipEventRecord(b->ev_probe[2], sl)); b->probe_valid = (stages & SMHV_STAGE_MARKERS) && mflags; }
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
 	STAGE_BEGIN(4, sl);
 	if (record_fused) { /* written by the search's own workgroups */ }
@@ -853,6 +856,7 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 #define SMH_LDS_PER_CU 163840u
 #define SMH_ADAPT_OFF 3.5f              // line search / streaming pass, launch durations: above -> no occupancy policy
 #define SMH_ADAPT_ON 1.6f               // ... below -> policy on again
+#define SMH_LATE_KC_SEARCH_BOUND 400u   // late helpers of a search-bound pipeline: a frame asks for help after 0.17 ms
 static LaunchTuning pipeline_tuning(const Geom &g) {
 	LaunchTuning t{0u, 0u, 0u, 0u};
 	static const bool off = [] { const char *e = getenv("SMH_PIPE_TUNING"); return e && atoi(e) == 0; }();   // diagnostic: SMH_PIPE_TUNING=0
@@ -926,7 +930,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 			p->tuning = pipeline_tuning(p->batch[i]->g);
 			p->batch[i]->tune = p->tuning;
 			static const bool adapt_off = [] { const char *e = getenv("SMH_PIPE_ADAPT"); return e && atoi(e) == 0; }();   // diagnostic
-			if (p->tuning.map_lds_total && !adapt_off && !stream_cus) {
+			if (!adapt_off && !stream_cus) {
 				p->adapt = true;
 				hipError_t e2 = hipSuccess;
 				for (int k = 0; k < 3 && e2 == hipSuccess; ++k) e2 = hipEventCreate(&p->batch[i]->ev_probe[k]);
@@ -973,6 +977,10 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 			bb->probe_valid = false;
 		}
 		bb->tune = p->tune_on ? p->tuning : LaunchTuning{0u, 0u, 0u, 0u};
+		// ... and a search-bound pipeline lets the workgroups of k_lsd_tile that have finished their frame help the ones still at
+		// work after SMH_LATE_KC_SEARCH_BOUND thousand cycles (sample screenshots, batch 128: 96 -> 106 k frames/s at depth 4,
+		// 127 -> 138 k at depth 8; the synthetic pipeline, ratio 1.3, loses 3 % with them and keeps them off)
+		bb->lsd_late_kc = p->tune_on ? 0u : SMH_LATE_KC_SEARCH_BOUND;
 		// a sample every fourth round of the slots is plenty for a running average, and the three timed events sit in the batch's
 		// chain on its hardware queue (the hand-over before the search: 33 us with them, 14 without)
 		bb->probe = (p->submitted / p->depth) % 4u == 0u;
