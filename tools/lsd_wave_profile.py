@@ -39,6 +39,10 @@ print("per frame: units cast %.1f, candidates set up %.1f, skipped at retire %.1
 L = np.array([[raw[i].length_px[28 + k] for k in range(4)] for i in range(N)])
 print("dispatch->retire latency: accepted %.3g cycles (%.1f per frame), rejected %.3g cycles (%.1f per frame)" % (
     L[:, 0].sum() / max(L[:, 1].sum(), 1), L[:, 1].mean(), L[:, 2].sum() / max(L[:, 3].sum(), 1), L[:, 3].mean()))
+L2 = np.array([[raw[i].length_px[22 + k] for k in range(4)] for i in range(N)])
+cnt = max(L2[:, 3].sum(), 1)
+print("a local candidate's life: dispatch -> set up %.3g cycles, set up -> last unit merged %.3g, merged -> retired %.3g (%d candidates)" % (
+    L2[:, 0].sum() / cnt, L2[:, 1].sum() / cnt, L2[:, 2].sum() / cnt, cnt))
 NWV = int(os.environ.get('SMH_W_BS', '1024')) // 64
 ft = P[:, 7] / NWV
 print("frame cycles (wave total / waves): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
