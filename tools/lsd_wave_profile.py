@@ -43,6 +43,9 @@ L2 = np.array([[raw[i].length_px[22 + k] for k in range(4)] for i in range(N)])
 cnt = max(L2[:, 3].sum(), 1)
 print("a local candidate's life: dispatch -> set up %.3g cycles, set up -> last unit merged %.3g, merged -> retired %.3g (%d candidates)" % (
     L2[:, 0].sum() / cnt, L2[:, 1].sum() / cnt, L2[:, 2].sum() / cnt, cnt))
+Y = np.array([[raw[i].angle[20 + k] for k in range(4)] for i in range(N)], dtype=np.float64)
+print("idle polls that found nothing to retire and nothing to dispatch: %.0f per frame -- speculation width full %.0f%%, no free window %.0f%%, list exhausted %.0f%%" % (
+    Y[:, 3].mean(), 100 * Y[:, 0].sum() / max(Y[:, 3].sum(), 1), 100 * Y[:, 1].sum() / max(Y[:, 3].sum(), 1), 100 * Y[:, 2].sum() / max(Y[:, 3].sum(), 1)))
 NWV = int(os.environ.get('SMH_W_BS', '1024')) // 64
 ft = P[:, 7] / NWV
 print("frame cycles (wave total / waves): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
