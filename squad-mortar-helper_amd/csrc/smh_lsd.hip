@@ -152,6 +152,27 @@ __device__ __forceinline__ uint32_t tile_raw(const Win &m, float x, float y) {
 	const int xi = (int)x;
 	return tile_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u);
 }
+// Eight consecutive LSD_MODE_TILE samples of a ray: the eight index entries, then the eight tile words, then the bits -- two
+// LDS round trips for the group.  Written sample by sample (tile_raw in an unrolled loop) the compiler waits for every
+// sample's index entry before it issues that sample's word read: sixteen dependent round trips per group, and a long ray
+// is nothing but such groups.  Same additions in the same order as the scalar form (x = xo + xs, then xo += dx).
+__device__ __forceinline__ void tile_raw8(const Win &m, float xs, float ys, float dx, float dy, float &xo, float &yo, float &x, float &y, uint32_t &Wm) {
+	int yi[8], xi[8];
+	uint32_t t[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		x = xo + xs; y = yo + ys;
+		yi[j] = (int)__builtin_amdgcn_fmed3f(y, -1.0f, m.hf);
+		xi[j] = (int)x;
+		xo += dx; yo += dy;
+	}
+#pragma unroll
+	for (int j = 0; j < 8; ++j) t[j] = m.t_idx[__mul24(yi[j] >> 3, (int)m.t_pitch) + (xi[j] >> 5)];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) t[j] = m.t_tiles[(t[j] << 3) + ((uint32_t)yi[j] & 7u)];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) Wm = __builtin_amdgcn_alignbit(t[j] >> ((uint32_t)xi[j] & 31u), Wm, 1);
+}
 // LSD_MODE_WIN2 sample straight from the float position (bit 0 = the pixel).  No clamp: the caller guarantees the position
 // lies inside the window (rows and columns outside the image are zero there); (int) of a position in (-1, 0) is 0 -- an
 // out-of-image sample either way, masked by the caller like every sample behind the image's edge.
@@ -245,6 +266,8 @@ __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float
 	uint32_t taken = 0;
 #pragma unroll 1
 	for (int jj = 0; jj < 4; ++jj) {
+		if constexpr (MODE == LSD_MODE_TILE) tile_raw8(m, xs, ys, dx, dy, xo, yo, x, y, Wm);
+		else
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			x = xo + xs; y = yo + ys;                   // x = x_offset + x_start
