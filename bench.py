@@ -756,6 +756,15 @@ def main():
         out["stages_ms"] = stages_ms
         out["pipeline_algorithmic_GBps"] = value / world * full_bytes / 1e9
         out["pipeline_hbm_frac"] = value / world * full_bytes / 1e9 / HBM_PEAK_GBS
+        # the same with the MEASURED bytes of a whole pass (every kernel; committed PMC run) and against what this box copies at
+        try:
+            if tj.get("frame") == [W, H] and stages == tj.get("stages", 0xF) and tj.get("pass_bytes") and tj.get("frames"):
+                out["pipeline_traffic_GBps"] = value / world * tj["pass_bytes"] / tj["frames"] / 1e9
+                copy = out.get("roofline_isolated", {}).get("device_copy_GBps")
+                if copy:
+                    out["pipeline_traffic_frac_of_device_copy"] = out["pipeline_traffic_GBps"] / copy
+        except NameError:
+            pass
         t_lsd = stages_ms["lsd"] * 1e-3
         out["lsd"] = {"rounds_per_frame": rounds_pf, "ray_steps_per_frame": ray_steps, "lines_per_frame": n_lines,
                       "ray_steps_per_s": (n * ray_steps / t_lsd) if t_lsd > 0 else None,
