@@ -1249,11 +1249,21 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 				mine = false;
 			}
 		}
+		// the kernel that owns a frame's record also completes it (scale ratio + derived outputs, smh_record.inc) when the run asks
+		// for that: frames nobody searches belong to the ROWS kernel, the others to the kernel of their mode
+		bool record = mode == 0 && (b.rec_stages & SMH_REC_ON) != 0u && !mine && MODE == LSD_MODE_ROWS;
 		if (mine && lsd_mode_for(g, aux) != MODE) mine = false;
 		if (mine) {
 			const bool cull = mode == 0 && b.cull_tab != nullptr && max_gap > 0.0f && max_gap <= 49.0f;
 			if (cull) { for (uint32_t i = threadIdx.x; i < SMH_CULL_TAB_WORDS; i += LSD_BS) cull_tab[i] = b.cull_tab[i]; have_tab = true; }   // visible after the barrier in frame_setup
 			lsd_frame<MODE>(g, b, f, max_gap, mode, spx, spy, aux, smem, sh, cull_tab, (COOP && coop) ? &b.co.coop[f] : nullptr);
+			record = mode == 0 && (b.rec_stages & SMH_REC_ON) != 0u;
+		}
+		if (record) {
+			struct Head { Geom g; Buffers b; };
+			const Head *ka = (const Head *)__builtin_amdgcn_kernarg_segment_ptr();   // (the kernel's own parameter list)
+			__syncthreads();
+			frame_record_tail(&ka->g, &ka->b, f);
 		}
 		if (!COOP || !coop) return;
 		__syncthreads();
@@ -1430,6 +1440,7 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		if (e != hipSuccess) return e;
 		s1 = fk->s1; s2 = fk->s2;
 	}
+	if (record_fused && mode == 0) *record_fused = (b.rec_stages & SMH_REC_ON) != 0u;   // (every frame's record has exactly one owner among the kernels below)
 	if (coop) hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, true>), dim3(n + extra), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	else hipLaunchKernelGGL((k_lsd<LSD_MODE_ROWS, false>), dim3(n), dim3(LSD_BS), lds_full, s, g, b, max_gap, mode, px, py, n);
 	if (!rows_only) {
