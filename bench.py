@@ -74,8 +74,10 @@ def parse_args():
     ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
     ap.add_argument("--pipeline-depth", type=int, default=4, help="batches in flight (smhv_pipeline_create depth)")
-    ap.add_argument("--distinct", type=int, default=0,
-                    help="distinct synthetic frames per GPU (0 = every frame distinct); fewer are tiled on the device (quick runs)")
+    ap.add_argument("--distinct", type=int, default=None,
+                    help="distinct synthetic frames per GPU (0 = every frame distinct); fewer are tiled on the device.  Default: every "
+                         "frame distinct, except config 4 (1024 frames per GPU): 256 distinct frames per GPU, tiled four times -- "
+                         "generating 1024 frames per rank on the host cores is minutes of set-up before the first GPU call")
     ap.add_argument("--node", action="store_true",
                     help="ONE process drives all --gpus devices through the C ABI (smhv_node_run + smhv_node_gather) instead of one rank per GPU")
     ap.add_argument("--tile-cap", type=int, default=0,
@@ -86,6 +88,7 @@ def parse_args():
                     help="CUs of every 32 reserved for the streaming kernels (smhv_pipeline_create_partitioned); default: the library's choice")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-real-samples", action="store_true", help="skip the leg on the reference's own 1440p screenshots (real_samples)")
     ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
     ap.add_argument("--no-back-to-back", action="store_true",
                     help="skip the back-to-back leg of the streaming pass (profiled runs: its overlapping launches would be averaged "
@@ -225,6 +228,52 @@ def records_equal_oracle(np, rec, ref):
             and np.array_equal(rec["lines"], lines) and rec["mpx"] == (ref.mpx if ref.has_mpx else None))
 
 
+def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
+    """The reference's own screenshots beside the synthetic scene (never `value`): the 2560x1440 open-map fixtures of
+    tests/golden (crops of vision-common/samples/*, the images the reference's one GPU test runs on, vision-gpu/src/lib.rs:571)
+    rebuilt into full frames and cycled through a batch of `batch` frames, ui_map + markers, through the same smhv_pipeline.
+    A real scene's cost per frame is anything from 0 to 372 find_longest_line rounds; the synthetic generator's is 16-157."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixtures as fx
+    from oracle import oracle as orc                   # checker only, outside every timed region
+    frames, stems = [], []
+    for stem in fx.OPEN_STEMS:
+        f, _e, _g = fx.load_fixture(stem)
+        if f.shape[:2] == (1440, 2560):
+            frames.append(f)
+            stems.append(stem)
+    k = len(frames)
+    d = torch.from_numpy(np.stack([frames[i % k] for i in range(batch)])).cuda()
+    pipe = smh.Pipeline(vision, 2560, 1440, batch, depth=depth)
+    stages = 0x3
+    for _ in range(2 * depth):
+        pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
+    pipe.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        slot = pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
+    pipe.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    got = smh.results_to_dicts(pipe.slots[slot].read_results(0, batch))
+    pipe.close()
+    ref = orc.process_batch(np.stack(frames), cpu_threads(k), stages=stages, max_gap=15)
+    ok = True
+    for i in range(batch):
+        r = ref[i % k]
+        rl = np.array([[r.lines[a][b] for b in range(4)] for a in range(r.n_lines)], np.float32).reshape(-1, 4)
+        ok = ok and got[i]["n_lines"] == r.n_lines and np.array_equal(got[i]["lines"], rl) and got[i]["rounds"] == r.rounds and got[i]["n_mask_px"] == r.n_mask_px
+    rounds = [int(r.rounds) for r in ref]
+    return {"frames_per_s": batch * steps / dt, "ms_per_pass": dt / steps * 1e3,
+            "workload": "%d distinct 2560x1440 open-map screenshots of vision-common/samples (committed fixtures), cycled through a batch of %d; ui_map + markers" % (k, batch),
+            "batch": batch, "pipeline_depth": depth, "stages": stages, "passes": steps,
+            "rounds_per_frame": {"min": min(rounds), "max": max(rounds), "mean": float(np.mean(rounds)), "all": rounds},
+            "lines_per_frame_mean": float(np.mean([int(r.n_lines) for r in ref])),
+            "records_equal_oracle": bool(ok), "note": "outside the timed region of `value`; the headline stays the synthetic configs[2] scene"}
+
+
 def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, H, n):
     """PCIe-inclusive rate (never `value`): frames travel pinned host memory -> HBM through the ingest queue (async
     copy, device CRC-32 duplicate test, slab append) and every full slab goes through the same pipeline; two queues
@@ -290,6 +339,7 @@ def upload_synthetic(torch, synth, W, H, n, first, lines, distinct, device, keep
     d = torch.empty((n, H, W, 4), dtype=torch.uint8, device=device)
     infos, host = [], np.empty((min(keep_host, k), H, W, 4), np.uint8)
     h2d = 0.0
+    t_gen = time.perf_counter()
     for c0 in range(0, k, chunk):
         c = min(chunk, k - c0)
         _, inf = synth.make_batch(W, H, c, first_idx=first + c0, n_lines=lines, out=stage.numpy()[:c])
@@ -306,6 +356,8 @@ def upload_synthetic(torch, synth, W, H, n, first, lines, distinct, device, keep
         d[c0:c0 + c].copy_(d[:c])
     infos = [infos[i % k] for i in range(n)]
     torch.cuda.synchronize(device)
+    print("bench.py[%s]: %d distinct %dx%d frames generated and uploaded in %.1f s (%.1f s of it H2D), tiled to %d resident frames"
+          % (device, k, W, H, time.perf_counter() - t_gen, h2d, n), file=sys.stderr)
     return d, infos, host, h2d
 
 
@@ -472,6 +524,8 @@ def main():
     stages = cfg["stages"] if args.stages is None else args.stages
     rounds = args.rounds_per_step or cfg["rounds"]
     custom = (n, W, H, stages) != (cfg["frames"], cfg["width"], cfg["height"], cfg["stages"])
+    if args.distinct is None:
+        args.distinct = 256 if args.config == 4 else 0
 
     if args.rendezvous_only:                           # the launch / rendezvous path alone (CPU test of the self-launch)
         import torch
@@ -529,16 +583,32 @@ def main():
     # work already enqueued there); all buffers are allocated once, up front.
     gather = None
     if world > 1:
-        gather = sdist.RecordGather(dist, n, world, rank, device=("cuda" if nccl else "cpu"))
+        gather = sdist.RecordGather(dist, n, world, rank, device=("cuda" if nccl else "cpu"), slots=max(8, depth))
         rec_views = [sdist.device_records_view(b.device_ptrs()["results"], n) for b in pipe.slots]
 
+    # A pass's records are complete when its slowest frame is (the library's line search is frame-granular: completion is
+    # a host-visible counter, not a point on a stream), so the gather of pass k is issued when its slot comes round again
+    # -- or at the next barrier -- behind a host wait for that slot; `hold` orders the slot's next pass behind the gather.
+    pending = [False] * depth
+    gather_stream = torch.cuda.Stream() if gather is not None else None
+    submitted = [0]
+
+    def flush_gather(slot):
+        pipe.wait(slot)
+        with torch.cuda.stream(gather_stream):
+            gather.run(rec_views[slot] if nccl else rec_views[slot].cpu(), slot)
+        pipe.hold(slot, gather_stream.cuda_stream)      # the gather reads the slot's records: its next pass waits for it
+        pending[slot] = False
+
     def one_pass(p):
+        if gather is not None and p is pipe:
+            nxt = submitted[0] % depth
+            if pending[nxt]:
+                flush_gather(nxt)
         slot = p.submit(fptr, n, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
         if gather is not None and p is pipe:
-            st = p.stream_of(slot)
-            with torch.cuda.stream(torch.cuda.ExternalStream(st)):
-                gather.run(rec_views[slot] if nccl else rec_views[slot].cpu(), slot)
-            p.hold(slot, st)                           # the gather reads the slot's records: its next pass waits for it
+            submitted[0] += 1
+            pending[slot] = True
         return slot
 
     def step(p=pipe):
@@ -546,6 +616,11 @@ def main():
             one_pass(p)
 
     def barrier():
+        if gather is not None:
+            for s_ in range(depth):
+                k_ = (submitted[0] + s_) % depth           # oldest first
+                if pending[k_]:
+                    flush_gather(k_)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()           # all streams of the device
@@ -585,6 +660,7 @@ def main():
     value = median(rates)
     dt_total = sum(dt for dt, _ in regions)
 
+    svc_stats = pipe.search_stats()                     # the frame-granular line search's own counters (None: batch-granular search)
     # ---- every slot of the pipeline must hold the same records (same frames, same stages): byte for byte ----
     used = min(depth, args.steps * rounds + args.warmup * rounds)
     slot_bytes = [bytes(pipe.slots[s].read_results(0, n)) for s in range(used)]
@@ -697,6 +773,7 @@ def main():
         "per_gpu_frames_per_s": value / world,
         "value_depth1": value_d1, "value_depth1_min_max": d1_minmax, "ms_per_pass_depth1": (ms_d1 / rounds if ms_d1 is not None else None),
         "h2d_seconds_for_batch": h2d_s,
+        "search_service": svc_stats,
         "all_map_open": bool(all_open),
         "slots_identical": bool(slots_identical), "slots_compared": used,
     }
@@ -770,6 +847,8 @@ def main():
                       "ray_steps_per_s": (n * ray_steps / t_lsd) if t_lsd > 0 else None,
                       "time_share": stages_ms["lsd"] / max(sum(stages_ms.values()), 1e-9)}
 
+    if not args.no_real_samples and world == 1 and args.config == 2 and not custom:
+        out["real_samples"] = real_samples_leg(smh, torch, vision, depth)
     if args.ingest_frames > 0 and world == 1 and args.config == 2 and not custom:
         out["ingest"] = ingest_leg(smh, torch, vision, pipe, frames_host, anchors, stages, args.ingest_frames, W, H, n)
 

@@ -285,6 +285,11 @@ SMHV_API int smhv_pipeline_wait(smhv_pipeline *p, uint32_t slot);
 SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p);
 SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv_batch **batch, void **stream);
 SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream);
+/* diagnostic: the frame-granular line search of a pipeline of depth >= 3 (synchronises the device).  out[0] = 1 when the
+ * pipeline has one, [1] launches of the search kernel so far, [2] frames it searched, [3] waves that came and went, [4] cycles
+ * those waves spent on frames, [5] cycles they were resident, [6] waves per launch, [7] submissions completed, [8..11] the cycles of [4] by phase: cache invalidation after the claim,
+ * tile store + search, record (scale ratio + derived outputs), write-back + counting the frame off. */
+SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[12]);
 SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
                                               uint32_t stream_cus_of_32, smhv_pipeline **out);
 

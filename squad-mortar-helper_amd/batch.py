@@ -117,7 +117,13 @@ class FrameBatch:
         recs = (L.FrameResult * n)()
         rc = self._lib.smhv_batch_read_results(self._b, first, n, recs)
         if rc != 0 and not (rc == L.E_STATE and not check):
-            L.check(rc)
+            try:
+                L.check(rc)
+            except L.VisionError as e:
+                # the library reports the condition ONCE and has copied the records out: they travel with the exception
+                # (frames whose status is set are to be dropped; the others are valid), a retry would not see the error again
+                e.records = recs if rc == L.E_STATE else None
+                raise
         return recs
 
     def read_image(self, which, frame):
@@ -170,6 +176,19 @@ class Pipeline:
         slot = C.c_uint32(0)
         L.check(self._lib.smhv_pipeline_submit(self._p, C.c_void_p(frames_ptr), n, stages, int(bool(grayscale)), max_gap, a, C.c_void_p(after_stream), C.byref(slot)))
         return int(slot.value)
+
+    def search_stats(self):
+        """Diagnostic (synchronises): the frame-granular line search of a pipeline of depth >= 3 -> dict, or None."""
+        out = (C.c_uint64 * 12)()
+        L.check(self._lib.smhv_debug_pipeline_stats(self._p, out))
+        if not out[0]:
+            return None
+        keys = ("launches", "frames", "waves", "busy_cycles", "resident_cycles", "waves_per_launch", "submissions")
+        d = dict(zip(keys, [int(v) for v in out[1:8]]))
+        d["cycles_per_frame_by_phase"] = dict(zip(("acquire", "search", "record", "release"), [int(v) / max(d["frames"], 1) for v in out[8:12]]))
+        d["cycles_per_frame"] = d["busy_cycles"] / max(d["frames"], 1)
+        d["busy_fraction"] = d["busy_cycles"] / max(d["resident_cycles"], 1)
+        return d
 
     def wait(self, slot=None):
         if slot is None:

@@ -151,6 +151,65 @@ struct Buffers {
 #define SMH_CULL_CELLS (SMH_SECTOR_DIM * 4)
 #define SMH_CULL_TAB_WORDS (SMH_CULL_CELLS + (SMH_SECTOR_ENTRIES + 3) / 4)
 
+// ---- the frame-granular line search of a pipeline (k_lsd_service, smh_service.inc; round 4) -------------------------------
+// A batch-granular search launch lasts as long as its slowest frame, and the slot cannot be resubmitted before.  A pipeline of
+// depth >= 3 therefore runs ONE long-lived search kernel per device: its waves pull (slot, frame) items from a ring in device
+// memory, search the frame (one wave per frame: the reference's sequential scan as it stands, smh_lsd_seq.inc), write the
+// frame's record and count it off against its submission; the wave that finishes a submission's last frame stores the
+// submission's sequence number into host-mapped memory, which is what smhv_pipeline_wait polls.  The streaming side of a
+// submission ends with k_svc_publish, which writes the slot's descriptor and the items.
+//   SvcSlot   per pipeline slot, device memory: what the waves need to know about the slot's current submission
+//   SvcCtl    per pipeline, device memory: the ring and its counters
+//   SvcHost   per pipeline, mapped host memory: life-cycle handshake and completion flags
+// Life cycle: the kernel is launched by the submission that finds it not alive and closes ITSELF when every submitted
+// batch is complete and nothing has arrived for `idle_short` cycles -- atomically with respect to the host's next submission
+// (compare-and-swap on SvcHost::state), so a device-wide synchronize by anybody still returns.
+#define SVC_MAX_SLOTS 16u
+struct SvcSlot {
+	Buffers b;                          // the submission's buffers, record stages, anchors, ... (as the batch kernels get them)
+	uint32_t n;                         // frames of the submission
+	uint32_t seq;                       // its sequence number (never 0)
+	uint32_t done;                      // frames finished so far
+	uint32_t pad;
+};
+struct SvcCtl {
+	int32_t avail;                      // items published and not yet claimed (semaphore; transiently negative)
+	uint32_t head;                      // tickets handed out
+	uint32_t reserve;                   // ring entries reserved by publishers
+	uint32_t closing;                   // epoch of the service launch that has closed
+	uint32_t completed;                 // submissions finished (counts like SvcHost::state >> 1)
+	uint32_t busy;                      // waves working on a frame
+	uint32_t stat_items, stat_waves;    // diagnostics (smhv_debug_pipeline_stats): frames searched; waves that have come and gone
+	unsigned long long stat_busy, stat_life;   // cycles spent on frames / between a wave's first poll and its exit, summed over those waves
+	unsigned long long stat_phase[4];   // of stat_busy: acquire (cache invalidation), tile store + search, record (scale ratio + derived outputs), release + count
+	uint32_t pad[4];
+	// ring entries follow: gen32 << 32 | slot << 24 | frame, gen = (ticket >> log2 cap) + 1
+};
+struct SvcHost {
+	uint32_t state;                     // submissions so far << 1 | service alive
+	uint32_t launches;                  // service launches so far (diagnostic)
+	uint32_t done_seq[SVC_MAX_SLOTS];   // per slot: sequence number of its last completed submission
+	uint32_t pad[14];
+};
+struct SvcParams {
+	SvcCtl *ctl;
+	unsigned long long *ring;
+	SvcSlot *slots;
+	SvcHost *host;                      // device address of the mapped host block
+	const uint32_t *cull_tab;           // the sector table every submission of this launch uses (null: every ray is cast)
+	float max_gap;
+	uint32_t tile_cap, list_cap;        // per-wave tile store and list sizes
+	uint32_t part_words;                // LDS words per wave (WShared + tile store + lists + window)
+	uint32_t ring_log2;
+	uint32_t epoch;                     // of this launch (> 0)
+	uint32_t idle_short, idle_long;     // in units of 1024 cycles
+	uint32_t flags;                     // experiments (SMH_SVC_FLAGS; results may be WRONG): 1 = no cache invalidation per item, 2 = no write-back per frame
+};
+// waves per service workgroup and LDS per workgroup for this frame size (0 waves: the frame size does not fit -> no service)
+uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes);
+hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s);
+hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s);
+
 enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u };
 enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 

@@ -720,8 +720,9 @@ struct FrameView {
 	uint32_t c_pitch, c_cap_rows;      // GLOBAL: geometry of the LDS row cache
 };
 
-template <int MODE>
+template <int MODE, bool WAVE = false>   // WAVE (LSD_MODE_GLOBAL only): called by one wave on its own (k_lsd_service): nothing in LDS to wait for
 __device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uint32_t f, const FrameAux &aux, uint32_t *smem, FrameView &v) {
+	static_assert(!WAVE || MODE == LSD_MODE_GLOBAL, "only the global-memory view is built without the workgroup");
 	const uint32_t tid = threadIdx.x;
 	const uint32_t *gbits = b.bits + (size_t)f * g.bits_stride_w;
 	Win &m = v.m;
@@ -775,7 +776,7 @@ __device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uin
 		m.y_lo = 0; m.rows_hi = g.rh - 1u;
 		m.xbias = (int)g.m_xoff; m.cols_hi = g.bits_pitch_w - 1u;
 	}
-	__syncthreads();
+	if (!WAVE) __syncthreads();
 }
 
 // GLOBAL: (re)load the row cache so that it covers rows [lo, hi] (a uniform decision).  Rows outside it are read from
@@ -1286,6 +1287,7 @@ __global__ void __launch_bounds__(LSD_BS) __attribute__((amdgpu_waves_per_eu(5, 
 
 #include "smh_lsd_wave.inc"
 #include "smh_lsd_seq.inc"
+#include "smh_service.inc"
 
 // ------------------------------------------------------------------------------------------------
 // Sector culling for find_lines (k_lsd).  lsd.rs:94 keeps a candidate only if its longest ray has
@@ -1456,6 +1458,46 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 			if (e != hipSuccess) return e;
 		}
 	}
+	return hipGetLastError();
+}
+
+// ---- the frame-granular search service (smh_service.inc) ----
+static uint32_t lsd_service_static_lds() {
+	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_lsd_service) == hipSuccess ? (uint32_t)a.sharedSizeBytes : SMH_CULL_TAB_WORDS * 4u; }();
+	return v;
+}
+// Waves per service workgroup (one workgroup per CU) for this frame size: as many as fit beside two workgroups of the
+// streaming pass, at most SVC_MAX_WAVES -- one per SIMD, which leaves three 128-register wave slots per SIMD to the streaming
+// pass.  0: not even one wave fits (8K frames: the tile index alone is 106 KB) -> the pipeline keeps its batch-granular search.
+uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes) {
+	const uint32_t cap = lsd_tile_cap_of(g, tile_limit), lc = tile_list_cap_for(g);
+	const uint32_t part = (SVC_WS_WORDS + tile_mask_words(g.rw, g.rh, cap) + 2u * lc + W_WIN_STRIDE + 3u) & ~3u;
+	const uint32_t lds_cu = 160u * 1024u, beside = 2u * ((map_brq_lds_bytes(g) + 1023u) & ~1023u) + 1024u;
+	uint32_t w = SVC_MAX_WAVES;
+	while (w > 0u && lsd_service_static_lds() + w * part * 4u + beside > lds_cu) --w;
+	if (part_words) *part_words = part;
+	if (tile_cap) *tile_cap = cap;
+	if (list_cap) *list_cap = lc;
+	if (lds_bytes) *lds_bytes = w * part * 4u;
+	return w;
+}
+
+hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s) {
+	hipLaunchKernelGGL(k_svc_publish, dim3(1), dim3(256), 0, s, ctl, ring, slots, slot, b, n, seq, ring_log2);
+	return hipGetLastError();
+}
+
+hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s) {
+	static std::atomic<uint64_t> attr_devices{0};
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
+		e = hipFuncSetAttribute((const void *)k_lsd_service, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)lsd_service_static_lds());
+		if (e != hipSuccess) return e;
+		if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
+	}
+	hipLaunchKernelGGL(k_lsd_service, dim3(workgroups), dim3(64u * waves), lds_bytes, s, g, p);
 	return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <vector>
 #include <new>
@@ -589,8 +590,11 @@ static uint32_t lsd_helpers_for(const smhv_batch *b, uint32_t n) {
 
 // s: the streaming kernels (button test, the fused map / quadrant pass); sl: the line-segment search and the record kernel.
 // sl == s for a plain smhv_batch_run; a pipeline with partitioned CUs passes two streams (sl waits for the streaming pass).
+// svc != null: the batch belongs to a pipeline with a frame-granular search service (smh_kernels.h): the streaming side ends
+// with the publication of the frames, and the service's waves search them and write their records.
+struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; };
 static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
-                          const smhv_anchors *anchors, hipStream_t s, hipStream_t sl) {
+                          const smhv_anchors *anchors, hipStream_t s, hipStream_t sl, const SvcPublish *svc = nullptr) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
 	CTX_OPEN(b->ctx);
 	if ((stages & (SMHV_STAGE_ALL | SMHV_STAGE_MINIMAP)) == 0) return fail(SMHV_E_INVALID, "no stage selected");
@@ -598,8 +602,12 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	HIPCHK(hipSetDevice(b->ctx->device));
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
+	// the helper exchange of k_lsd_tile tags its words with 16 bits of the launch epoch: start every 65,536th launch of a batch
+	// from a clean slate, so that a stale word of the launch 65,536 ago can never read as this launch's
+	if ((bf.co.epoch & 0xFFFFu) == 0u && b->d_farm) HIPCHK(hipMemsetAsync(b->d_farm, 0, sizeof(FarmFrame) * (size_t)b->max_frames, s));
 	if (stages & SMHV_STAGE_LSD_HELPERS) bf.co.ctl = (LsdCtl *)b->d_lsd_ctl;
-	if ((stages & SMHV_STAGE_MARKERS) && !(stages & SMHV_STAGE_EXACT_STATS)) {
+	if (svc && svc->have_cull) bf.cull_tab = svc->cull_tab;     // (looked up by the caller: the service is launched with it)
+	else if ((stages & SMHV_STAGE_MARKERS) && !(stages & SMHV_STAGE_EXACT_STATS)) {
 		int rc = sector_table_for(b->ctx, max_gap, s, &bf);
 		if (rc) return rc;
 	}
@@ -650,6 +658,20 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[1], s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (SMH_SKIP_LSD=1, smhv_debug_skip_line_search): the streaming pass with every output, no search
+	if (svc) {
+		// ---- frame-granular: publish the frames; the service searches them and writes the records (minimap first: its kernel
+		// needs nothing of the search and the record keeps what it wrote) ----
+		if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, s));
+		bf.rec_stages = SMH_REC_ON | (scales ? stages : (stages & ~SMHV_STAGE_SCALES));
+		bf.rec_bars = b->d_bars;
+		STAGE_BEGIN(3, s);
+		HIPCHK(launch_svc_publish(svc->ctl, svc->ring, svc->slots, svc->slot, bf, n, svc->seq, svc->ring_log2, s));
+		STAGE_END(3, s);
+		STAGE_BEGIN(4, s);
+		STAGE_END(4, s);
+		if (t) b->timed_runs++;
+		return SMHV_OK;
+	}
 	STAGE_BEGIN(3, sl);
 	// late helpers: workgroups of k_lsd_tile that have finished their frame help one that is still at work (smh_kernels.h,
 	// FarmFrame::want).  smhv_pipeline switches them on for search-bound workloads; SMH_LSD_LATE=0 / 1 / <thousands of cycles a
@@ -820,12 +842,34 @@ struct smhv_pipeline {
 	float ratio_ema = 0.0f;
 	uint64_t submitted = 0;             // submissions so far
 	uint64_t round_start = 0;           // index of the first submission after the pipeline last ran empty
+	// ---- frame-granular search service (smh_kernels.h, smh_service.inc): depth >= 3 ----
+	// stream[] then holds svc_streams streams that the submissions' streaming sides take in turn, s_search carries the
+	// service kernel (a stream with its own hardware queue: nothing else may queue behind a kernel that lives for seconds)
+	bool svc = false;
+	uint32_t svc_streams = 0, svc_waves = 0, svc_part_words = 0, svc_tile_cap = 0, svc_list_cap = 0, svc_lds = 0, svc_wgs = 0, svc_ring_log2 = 0;
+	SvcCtl *d_svc_ctl = nullptr;
+	unsigned long long *d_svc_ring = nullptr;
+	SvcSlot *d_svc_slots = nullptr;
+	SvcHost *h_svc = nullptr, *d_svc_host = nullptr;
+	hipStream_t s_search = nullptr;
+	std::vector<hipEvent_t> ev_pub;     // per slot: the slot's items have been published
+	std::vector<uint32_t> seq;          // per slot: sequence number of its most recent submission (0: none yet)
+	std::vector<hipStream_t> slot_st;   // per slot: the stream its most recent streaming side ran on
+	uint32_t seq_counter = 0, svc_epoch = 0;
+	bool svc_key_valid = false;         // the running / next service's sector table and gap threshold
+	const uint32_t *svc_cull = nullptr;
+	uint32_t svc_max_gap = 0;
 };
+static int svc_wait_slot(smhv_pipeline *p, uint32_t slot);
+static int svc_launch(smhv_pipeline *p, uint32_t slot);
+static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                      const smhv_anchors *anchors, void *after_stream, uint32_t *slot_out);
 
 extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (!p) return;
 	if (p->ctx) (void)hipSetDevice(p->ctx->device);
-	(void)hipDeviceSynchronize();
+	if (p->svc) for (uint32_t i = 0; i < p->depth; ++i) (void)svc_wait_slot(p, i);   // (a stalled service is relaunched by the wait)
+	(void)hipDeviceSynchronize();                             // the service closes by itself once every submission is complete
 	for (auto b : p->batch) if (b) smhv_batch_destroy(b);
 	for (auto e : p->done) if (e) (void)hipEventDestroy(e);
 	for (auto e : p->hold) if (e) (void)hipEventDestroy(e);
@@ -833,6 +877,12 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	for (auto st : p->stream) if (st) (void)hipStreamDestroy(st);
 	if (p->s_stream) (void)hipStreamDestroy(p->s_stream);
 	for (auto st : p->s_lsd) if (st) (void)hipStreamDestroy(st);
+	if (p->s_search) (void)hipStreamDestroy(p->s_search);
+	for (auto e : p->ev_pub) if (e) (void)hipEventDestroy(e);
+	if (p->d_svc_ctl) (void)hipFree(p->d_svc_ctl);
+	if (p->d_svc_ring) (void)hipFree(p->d_svc_ring);
+	if (p->d_svc_slots) (void)hipFree(p->d_svc_slots);
+	if (p->h_svc) (void)hipHostFree(p->h_svc);
 	ctx_release(p->ctx);
 	delete p;
 }
@@ -886,15 +936,24 @@ static LaunchTuning pipeline_tuning(const Geom &g) {
 // stream_cus: 0 = every kernel may use every CU; 1..31 = the streaming kernels get that many CUs of every 32 (of each XCD's
 // share), the line-segment search the rest (hipExtStreamCreateWithCUMask).
 static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, uint32_t stream_cus, smhv_pipeline **out) {
-	if (!c || !out || max_frames == 0 || depth == 0 || depth > 8 || stream_cus > 31) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..8, stream CUs 0..31 of 32)");
+	if (!c || !out || max_frames == 0 || depth == 0 || depth > SVC_MAX_SLOTS || stream_cus > 31) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..16, stream CUs 0..31 of 32)");
 	*out = nullptr;
 	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
 	if (depth == 1) stream_cus = 0;                           // nothing overlaps: every kernel gets the whole chip
+	Geom g0;
+	{ int rc = compute_geom(W, H, &g0); if (rc) return rc; }
 	smhv_pipeline *p = new (std::nothrow) smhv_pipeline();
 	if (!p) return fail(SMHV_E_INVALID, "out of host memory");
 	c->refs.fetch_add(1, std::memory_order_relaxed);
 	p->ctx = c; p->depth = depth; p->stream_cus = stream_cus;
+	// Frame-granular search (smh_kernels.h): depth >= 3, no CU partition, a frame size whose tile store fits beside the
+	// streaming pass.  SMH_SVC=0: the batch-granular search of rounds 2-3 (diagnostic A/B).
+	static const int svc_env = [] { const char *e = getenv("SMH_SVC"); return e ? atoi(e) : -1; }();
+	if (depth >= 3 && !stream_cus && svc_env != 0 && max_frames < (1u << 24)) {
+		p->svc_waves = svc_waves_for(g0, SMH_PIPE_TILE_LIMIT(g0), &p->svc_part_words, &p->svc_tile_cap, &p->svc_list_cap, &p->svc_lds);
+		p->svc = p->svc_waves > 0u;
+	}
 	p->batch.assign(depth, nullptr); p->done.assign(depth, nullptr); p->hold.assign(depth, nullptr); p->held.assign(depth, 0); p->last_sl.assign(depth, nullptr);
 	uint32_t m_stream[8], m_lsd[8];
 	uint32_t word = stream_cus ? ((1u << stream_cus) - 1u) : 0xFFFFFFFFu;
@@ -908,12 +967,40 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 	} else {
 		// The streams are created back to back, before any other object of the pipeline: HIP deals streams onto the
 		// hardware queues in creation order, so consecutive streams never share one, whatever the host created earlier.
-		p->stream.assign(depth, nullptr);
-		for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking);
+		static const int ns_env = [] { const char *e = getenv("SMH_SVC_STREAMS"); return e ? atoi(e) : 0; }();   // diagnostic
+		p->svc_streams = p->svc ? std::min<uint32_t>(depth, ns_env > 0 ? (uint32_t)ns_env : 2u) : 0u;
+		const uint32_t ns = p->svc ? p->svc_streams : depth;
+		p->stream.assign(ns, nullptr);
+		for (uint32_t i = 0; i < ns && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking);
+		if (p->svc && e == hipSuccess) {
+			// a stream with a CU mask gets a hardware queue of its own (the mask is a property of the queue): the service kernel
+			// lives as long as the pipeline is busy, and whatever shared its queue would wait that long
+			const uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+			e = create_stream(&p->s_search, full);
+		}
 	}
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
 	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
 	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->hold[i], hipEventDisableTiming);
+	if (p->svc && e == hipSuccess) {
+		p->ev_pub.assign(depth, nullptr); p->seq.assign(depth, 0u); p->slot_st.assign(depth, nullptr);
+		for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_pub[i], hipEventDisableTiming);
+		uint32_t lg = 8;
+		while ((1ull << lg) < (uint64_t)depth * max_frames) ++lg;
+		p->svc_ring_log2 = lg;
+		int cus = 0;
+		if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+		static const int wgs_env = [] { const char *e = getenv("SMH_SVC_WGS"); return e ? atoi(e) : 0; }();   // diagnostic
+		p->svc_wgs = wgs_env > 0 ? (uint32_t)wgs_env : (uint32_t)std::max(cus, 1);
+		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ctl, sizeof(SvcCtl));
+		if (e == hipSuccess) e = hipMemset(p->d_svc_ctl, 0, sizeof(SvcCtl));
+		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ring, sizeof(unsigned long long) << lg);
+		if (e == hipSuccess) e = hipMemset(p->d_svc_ring, 0, sizeof(unsigned long long) << lg);
+		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_slots, sizeof(SvcSlot) * depth);
+		if (e == hipSuccess) e = hipMemset(p->d_svc_slots, 0, sizeof(SvcSlot) * depth);
+		if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_svc, sizeof(SvcHost), hipHostMallocMapped | hipHostMallocCoherent);
+		if (e == hipSuccess) { memset(p->h_svc, 0, sizeof(SvcHost)); e = hipHostGetDevicePointer((void **)&p->d_svc_host, p->h_svc, 0); }
+	}
 	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline streams / events: %s", hipGetErrorString(e)); }
 	for (uint32_t i = 0; i < depth; ++i) {
 		int rc = batch_create_impl(c, W, H, max_frames, stream_cus ? m_lsd : nullptr, &p->batch[i]);
@@ -926,7 +1013,10 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		static const bool seq = [] { const char *e = getenv("SMH_LSD_SEQ"); return e && atoi(e) != 0; }();
 		p->batch[i]->lsd_bs = seq ? 64u : (depth >= 2 ? 512u : 1024u);
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
-		if (depth >= 3) {
+		if (p->svc) {
+			// no occupancy policy: the service's resident waves (one per SIMD, most of a CU's LDS) are what caps the streaming
+			// pass at three workgroups per CU
+		} else if (depth >= 3) {
 			p->tuning = pipeline_tuning(p->batch[i]->g);
 			p->batch[i]->tune = p->tuning;
 			static const bool adapt_off = [] { const char *e = getenv("SMH_PIPE_ADAPT"); return e && atoi(e) == 0; }();   // diagnostic
@@ -954,15 +1044,120 @@ extern "C" SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *c, uint32_t W
 	return pipeline_create_impl(c, W, H, max_frames, depth, stream_cus_of_32, out);
 }
 
+// ---- the host side of the frame-granular search service --------------------------------------------------------------
+static inline uint32_t svc_state(smhv_pipeline *p) { return __atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE); }
+
+// Launch the service kernel behind the publication of `slot`'s items.  The alive flag is set first: from then on only the
+// device clears it (smh_service.inc, svc_pop).
+static int svc_launch(smhv_pipeline *p, uint32_t slot) {
+	SvcParams sp;
+	sp.ctl = p->d_svc_ctl; sp.ring = p->d_svc_ring; sp.slots = p->d_svc_slots; sp.host = p->d_svc_host;
+	sp.cull_tab = p->svc_cull; sp.max_gap = (float)p->svc_max_gap;
+	sp.tile_cap = p->svc_tile_cap; sp.list_cap = p->svc_list_cap; sp.part_words = p->svc_part_words; sp.ring_log2 = p->svc_ring_log2;
+	sp.epoch = ++p->svc_epoch;
+	if (sp.epoch == 0u) sp.epoch = ++p->svc_epoch;
+	static const int idle_env = [] { const char *e = getenv("SMH_SVC_IDLE_US"); return e ? atoi(e) : 0; }();   // diagnostic
+	sp.idle_short = idle_env > 0 ? (uint32_t)idle_env * 2u : 100u;      // x 1024 cycles: ~45 us without work and nothing outstanding
+	static const int flags_env = [] { const char *e = getenv("SMH_SVC_FLAGS"); return e ? atoi(e) : 0; }();   // experiments only
+	sp.flags = (uint32_t)flags_env;
+	sp.idle_long = 50000u;                                               // ~20 ms without work, nobody at work: the streaming side is stuck
+	__atomic_fetch_or(&p->h_svc->state, 1u, __ATOMIC_ACQ_REL);
+	hipError_t e = hipStreamWaitEvent(p->s_search, p->ev_pub[slot], 0);
+	if (e == hipSuccess) e = launch_lsd_service(p->batch[slot]->g, sp, p->svc_wgs, p->svc_waves, p->svc_lds, p->s_search);
+	if (e != hipSuccess) {
+		__atomic_fetch_and(&p->h_svc->state, ~1u, __ATOMIC_ACQ_REL);
+		return fail(SMHV_E_HIP, "launching the line-search service: %s", hipGetErrorString(e));
+	}
+	p->h_svc->launches++;
+	return SMHV_OK;
+}
+
+// Host wait for the slot's most recent submission: the wave that finishes its last frame stores the submission's sequence
+// number into mapped host memory.
+static int svc_wait_slot(smhv_pipeline *p, uint32_t slot) {
+	const uint32_t target = p->seq[slot];
+	if (target == 0u) return SMHV_OK;
+	volatile uint32_t *flag = &p->h_svc->done_seq[slot];
+	uint64_t spins = 0;
+	struct timespec t0;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != target) {
+		if (!(svc_state(p) & 1u)) {
+			// not alive with work outstanding: the service gave way (its streaming side did not move for idle_long): again
+			if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == target) break;
+			int rc = svc_launch(p, slot);
+			if (rc) return rc;
+		}
+		if (++spins < 4000u) { __builtin_ia32_pause(); continue; }
+		struct timespec ts = {0, 20000};
+		nanosleep(&ts, nullptr);
+		if ((spins & 1023u) == 0u) {
+			struct timespec t1;
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			if (t1.tv_sec - t0.tv_sec > 60) return fail(SMHV_E_STATE, "pipeline_wait: slot %u did not complete within 60 s (line-search service stalled)", slot);
+		}
+	}
+	return SMHV_OK;
+}
+
+static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
+                      const smhv_anchors *anchors, void *after_stream, uint32_t *slot_out) {
+	smhv_batch *b = p->batch[slot];
+	if (!d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b->max_frames);
+	// the slot's previous submission owns its buffers until its last frame has been counted off
+	int rc = svc_wait_slot(p, slot);
+	if (rc) return rc;
+	if (batch_check_errors(b, "pipeline_submit (the slot's previous submission, never waited for)") != SMHV_OK) logf(p->ctx, 2, "%s", t_last_error.c_str());
+	hipStream_t st = p->stream[p->submitted % p->svc_streams];
+	// the sector table of this gap threshold is a launch parameter of the service: a submission with another one waits for
+	// the service to finish what it has and close (a host that alternates thresholds pays a drain per change)
+	Buffers probe{};
+	const bool want_cull = (stages & SMHV_STAGE_MARKERS) && !(stages & SMHV_STAGE_EXACT_STATS);
+	if (want_cull) { rc = sector_table_for(p->ctx, max_gap, st, &probe); if (rc) return rc; }
+	if (!p->svc_key_valid || p->svc_cull != probe.cull_tab || p->svc_max_gap != max_gap) {
+		for (uint32_t i = 0; i < p->depth; ++i) { rc = svc_wait_slot(p, i); if (rc) return rc; }
+		while (svc_state(p) & 1u) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+		p->svc_key_valid = true; p->svc_cull = probe.cull_tab; p->svc_max_gap = max_gap;
+	}
+	if (after_stream) {
+		HIPCHK(hipEventRecord(p->ev_after, (hipStream_t)after_stream));
+		HIPCHK(hipStreamWaitEvent(st, p->ev_after, 0));
+	}
+	if (p->held[slot]) {
+		HIPCHK(hipStreamWaitEvent(st, p->hold[slot], 0));
+		p->held[slot] = 0;
+	}
+	uint32_t seq = ++p->seq_counter;
+	if (seq == 0u) seq = ++p->seq_counter;
+	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true};
+	rc = batch_run_impl(b, d_frames, n, stages, grayscale, max_gap, anchors, st, st, &pub);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(p->ev_pub[slot], st));
+	p->seq[slot] = seq;
+	p->slot_st[slot] = st;
+	p->last_sl[slot] = st;
+	// count the submission; whoever finds the service not alive launches it (ordered behind this submission's items)
+	const uint32_t old = __atomic_fetch_add(&p->h_svc->state, 2u, __ATOMIC_ACQ_REL);
+	if (!(old & 1u)) { rc = svc_launch(p, slot); if (rc) return rc; }
+	p->submitted++;
+	if (slot_out) *slot_out = slot;
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                                              const smhv_anchors *anchors, void *after_stream, uint32_t *slot_out) {
 	if (!p) return fail(SMHV_E_INVALID, "null pipeline");
 	CTX_OPEN(p->ctx);
 	HIPCHK(hipSetDevice(p->ctx->device));
 	const uint32_t slot = (uint32_t)(p->submitted % p->depth);
+	if (p->svc) return svc_submit(p, slot, d_frames, n, stages, grayscale, max_gap, anchors, after_stream, slot_out);
 	// the slot's previous submission (depth submissions ago) owns its output buffers until it has finished: this is the
 	// only place the call can wait, and only when more than `depth` submissions would be in flight
 	HIPCHK(hipEventSynchronize(p->done[slot]));
+	// frames the slot's previous submission gave up, if nobody waited for it: reported (logged) now, with that submission,
+	// not by some later wait with the wrong run's frame index
+	if (batch_check_errors(p->batch[slot], "pipeline_submit (the slot's previous submission, never waited for)") != SMHV_OK)
+		logf(p->ctx, 2, "%s", t_last_error.c_str());
 	if (p->adapt) {
 		smhv_batch *bb = p->batch[slot];
 		if (bb->probe_valid) {                                // the slot's previous submission has finished: its three events are there
@@ -1028,14 +1223,18 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 extern "C" SMHV_API int smhv_pipeline_wait(smhv_pipeline *p, uint32_t slot) {
 	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_wait: bad arguments");
 	HIPCHK(hipSetDevice(p->ctx->device));
-	HIPCHK(hipEventSynchronize(p->done[slot]));
+	if (p->svc) { int rc = svc_wait_slot(p, slot); if (rc) return rc; }
+	else HIPCHK(hipEventSynchronize(p->done[slot]));
 	return batch_check_errors(p->batch[slot], "pipeline_wait");
 }
 
 extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
 	if (!p) return fail(SMHV_E_INVALID, "null pipeline");
 	HIPCHK(hipSetDevice(p->ctx->device));
-	for (uint32_t i = 0; i < p->depth; ++i) HIPCHK(hipEventSynchronize(p->done[i]));
+	for (uint32_t i = 0; i < p->depth; ++i) {
+		if (p->svc) { int r = svc_wait_slot(p, i); if (r) return r; }
+		else HIPCHK(hipEventSynchronize(p->done[i]));
+	}
 	int rc = SMHV_OK;
 	for (uint32_t i = 0; i < p->depth; ++i) {                 // every slot is checked (and cleared); the first failure is the one returned
 		std::string keep = t_last_error;
@@ -1044,6 +1243,20 @@ extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
 		else if (r) t_last_error = keep;
 	}
 	return rc;
+}
+
+extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[12]) {
+	if (!p || !out) return fail(SMHV_E_INVALID, "bad arguments");
+	memset(out, 0, sizeof(uint64_t) * 12);
+	if (!p->svc) return SMHV_OK;
+	HIPCHK(hipSetDevice(p->ctx->device));
+	HIPCHK(hipDeviceSynchronize());                           // (the service closes by itself once nothing is outstanding)
+	SvcCtl c;
+	HIPCHK(hipMemcpy(&c, p->d_svc_ctl, sizeof c, hipMemcpyDeviceToHost));
+	out[0] = 1u; out[1] = p->h_svc->launches; out[2] = c.stat_items; out[3] = c.stat_waves; out[4] = c.stat_busy; out[5] = c.stat_life;
+	out[6] = (uint64_t)p->svc_wgs * p->svc_waves; out[7] = c.completed;
+	for (int k = 0; k < 4; ++k) out[8 + k] = c.stat_phase[k];
+	return SMHV_OK;
 }
 
 extern "C" SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream) {
@@ -1057,6 +1270,15 @@ extern "C" SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void
 extern "C" SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv_batch **batch, void **stream) {
 	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_slot: bad arguments");
 	if (batch) *batch = p->batch[slot];
+	if (stream && p->svc) {
+		// frame-granular search: a submission's completion is not a point on a stream; the call waits for the slot's records
+		// on the host, after which any stream will do
+		HIPCHK(hipSetDevice(p->ctx->device));
+		int rc = svc_wait_slot(p, slot);
+		if (rc) return rc;
+		*stream = (void *)(p->slot_st[slot] ? p->slot_st[slot] : p->stream[0]);
+		return SMHV_OK;
+	}
 	// the stream on which the slot's most recent record kernel runs (what a consumer has to order itself after)
 	if (stream) *stream = (void *)(p->last_sl[slot] ? p->last_sl[slot] : (p->stream_cus ? p->s_lsd[0] : p->stream[slot]));
 	return SMHV_OK;

@@ -38,7 +38,11 @@ class Node:
         tot = C.c_uint32(0)
         rc = self._lib.smhv_node_gather(self._h, self._out, C.byref(tot))
         if rc != 0 and not (rc == L.E_STATE and not check):
-            L.check(rc)
+            try:
+                L.check(rc)
+            except L.VisionError as e:
+                e.records = (self._out, int(tot.value)) if rc == L.E_STATE else None   # reported once; the records were gathered
+                raise
         return self._out, int(tot.value)
 
     def close(self):

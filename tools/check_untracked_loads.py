@@ -115,7 +115,10 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.run([HIPCC] + build_flags() + ["-x", "hip", os.path.realpath(SRC), "-c", "--save-temps", "-o", "out.o"], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        asm = [f for f in os.listdir(tmp) if f.endswith(".s") and "gfx950" in f]
+        arch = next((f.split("=", 1)[1] for f in build_flags() if f.startswith("--offload-arch=")), "gfx950")   # (the Makefile's ARCH)
+        asm = [f for f in os.listdir(tmp) if f.endswith(".s") and arch in f]
+        if not asm:
+            raise RuntimeError("--save-temps left no device assembly for %s in %s" % (arch, sorted(os.listdir(tmp))))
         text = open(os.path.join(tmp, asm[0])).read().split("\n")
     errors, found = [], 0
     i = 0
@@ -133,6 +136,8 @@ def main():
         if int(km.group(2)) > (128 if loop else 0):
             errors.append("%s uses %s bytes of scratch (allowed: %s)" % (km.group(1)[:44], km.group(2), "the prologue / epilogue spills of the grid-stride loop's state, <= 128"
                           if loop else "none: the variant without the loop is the one whose HBM traffic is profiled"))
+    if found == 0:
+        raise RuntimeError("no k_map_brq_pass instantiation in the device assembly")
     if found != 4:
         errors.append("expected four instantiations of k_map_brq_pass (GRAY x LOOP), found %d" % found)
     for e in errors:
@@ -142,4 +147,12 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    # exit codes: 0 = the compiled code is fine, 1 = the check REJECTED it (the Makefile then builds the tracked-load fallback),
+    # 3 = the check itself could not run (compiler failed, no kernel found, ...): a broken tool is not a rejection, the build stops
+    try:
+        sys.exit(main())
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        print("check_untracked_loads.py could not run: %s: %s" % (type(e).__name__, e), file=sys.stderr)
+        sys.exit(3)

@@ -1,0 +1,47 @@
+"""Round 4 experiment aid: throughput of an smhv_pipeline and the frame-granular search's own counters, without bench.py's
+checks (usage: svc_rate.py [N=256] [depth=16] [passes=400] [stages=0xF] [W H]); prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import squad_mortar_helper_amd as smh
+from squad_mortar_helper_amd import synth
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+passes = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+stages = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0xF
+W = int(sys.argv[5]) if len(sys.argv) > 5 else 1920
+H = int(sys.argv[6]) if len(sys.argv) > 6 else 1080
+K = min(N, int(os.environ.get("SVC_RATE_DISTINCT", "64")))
+frames, infos = synth.make_batch(W, H, K, first_idx=0)
+frames = np.concatenate([frames] * ((N + K - 1) // K))[:N]
+infos = [infos[i % K] for i in range(N)]
+anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 8 else None
+d = torch.from_numpy(frames).cuda()
+vision = smh.HipVision.init(0)
+fb = smh.FrameBatch(vision, W, H, N)
+fb.run(d.data_ptr(), N, stages=stages, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
+want = bytes(fb.read_results(0, N))
+fb.close()
+pipe = smh.Pipeline(vision, W, H, N, depth)
+for _ in range(2 * depth):
+    pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
+pipe.wait()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(passes):
+    slot = pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
+pipe.wait()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+equal = [bytes(pipe.slots[s].read_results(0, N)) == want for s in range(min(depth, passes))]
+st = pipe.search_stats()
+pipe.close()
+print(json.dumps({"frames_per_s": N * passes / dt, "ms_per_pass": dt / passes * 1e3, "N": N, "depth": depth, "stages": stages, "frame": [W, H],
+                  "slots_equal_plain_run": all(equal), "env": {k: v for k, v in os.environ.items() if k.startswith("SMH_")}, "search_service": st}))
