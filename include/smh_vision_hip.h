@@ -288,8 +288,14 @@ SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream);
 /* diagnostic: the frame-granular line search of a pipeline of depth >= 3 (synchronises the device).  out[0] = 1 when the
  * pipeline has one, [1] launches of the search kernel so far, [2] frames it searched, [3] waves that came and went, [4] cycles
  * those waves spent on frames, [5] cycles they were resident, [6] waves per launch, [7] submissions completed, [8..11] the cycles of [4] by phase: cache invalidation after the claim,
- * tile store + search, record (scale ratio + derived outputs), write-back + counting the frame off. */
-SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[12]);
+ * tile store + search, record (scale ratio + derived outputs), write-back + counting the frame off; [12] cycles the waves spent
+ * casting candidates for other waves' frames (not part of [4]). */
+SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[16]);
+/* diagnostic, does NOT synchronise the device (usable from another thread while a wait is stuck): [0] submissions counted,
+ * [1] epoch of the search launch alive (0: none), [2] launches, [3] last sequence number handed out, [4..9] the ring's
+ * counters (available, head, reserved, closing epoch, submissions completed, waves at work), [10..13] slots 0-3:
+ * sequence number of the latest submission << 32 | of the last one completed. */
+SMHV_API int smhv_debug_pipeline_peek(smhv_pipeline *p, uint64_t out[16]);
 SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
                                               uint32_t stream_cus_of_32, smhv_pipeline **out);
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "smhv_pipeline_create_partitioned": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "smhv_pipeline_hold": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "smhv_debug_pipeline_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "smhv_debug_pipeline_peek": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "smhv_pipeline_destroy": (None, [C.c_void_p]),
     "smhv_pipeline_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "smhv_pipeline_wait": (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -179,15 +179,26 @@ class Pipeline:
 
     def search_stats(self):
         """Diagnostic (synchronises): the frame-granular line search of a pipeline of depth >= 3 -> dict, or None."""
-        out = (C.c_uint64 * 12)()
+        out = (C.c_uint64 * 16)()
         L.check(self._lib.smhv_debug_pipeline_stats(self._p, out))
         if not out[0]:
             return None
         keys = ("launches", "frames", "waves", "busy_cycles", "resident_cycles", "waves_per_launch", "submissions")
         d = dict(zip(keys, [int(v) for v in out[1:8]]))
         d["cycles_per_frame_by_phase"] = dict(zip(("acquire", "search", "record", "release"), [int(v) / max(d["frames"], 1) for v in out[8:12]]))
+        d["help_cycles_per_frame"] = int(out[12]) / max(d["frames"], 1)
         d["cycles_per_frame"] = d["busy_cycles"] / max(d["frames"], 1)
         d["busy_fraction"] = d["busy_cycles"] / max(d["resident_cycles"], 1)
+        return d
+
+    def peek(self):
+        """Diagnostic, no device-wide synchronisation: the search service's life-cycle words and ring counters."""
+        out = (C.c_uint64 * 16)()
+        L.check(self._lib.smhv_debug_pipeline_peek(self._p, out))
+        keys = ("submissions", "alive_epoch", "launches", "last_seq", "avail", "head", "reserved", "closing_epoch", "completed", "busy")
+        d = dict(zip(keys, [int(v) for v in out[:10]]))
+        d["avail"] = d["avail"] - (1 << 64) if d["avail"] >= (1 << 63) else d["avail"]
+        d["slots"] = [(int(v) >> 32, int(v) & 0xFFFFFFFF) for v in out[10:14]]
         return d
 
     def wait(self, slot=None):

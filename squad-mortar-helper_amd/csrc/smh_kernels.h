@@ -163,7 +163,8 @@ struct Buffers {
 //   SvcHost   per pipeline, mapped host memory: life-cycle handshake and completion flags
 // Life cycle: the kernel is launched by the submission that finds it not alive and closes ITSELF when every submitted
 // batch is complete and nothing has arrived for `idle_short` cycles -- atomically with respect to the host's next submission
-// (compare-and-swap on SvcHost::state), so a device-wide synchronize by anybody still returns.
+// (compare-and-swap on SvcHost::state, which names the launch that is alive), so a device-wide synchronize by anybody still
+// returns.
 #define SVC_MAX_SLOTS 16u
 struct SvcSlot {
 	Buffers b;                          // the submission's buffers, record stages, anchors, ... (as the batch kernels get them)
@@ -173,23 +174,32 @@ struct SvcSlot {
 	uint32_t pad;
 };
 struct SvcCtl {
+	// (avail and closing are what an idle wave looks at: one 8-byte load.  Every idle wave of the chip polls this one address,
+	// i.e. one memory channel: smh_service.inc spaces the polls out -- at 2 us per wave the streaming pass beside them took 1.6 ms
+	// instead of 0.9: a pass is as slow as its slowest channel)
 	int32_t avail;                      // items published and not yet claimed (semaphore; transiently negative)
+	uint32_t closing;                   // epoch of the service launch that has closed
 	uint32_t head;                      // tickets handed out
 	uint32_t reserve;                   // ring entries reserved by publishers
-	uint32_t closing;                   // epoch of the service launch that has closed
 	uint32_t completed;                 // submissions finished (counts like SvcHost::state >> 1)
 	uint32_t busy;                      // waves working on a frame
 	uint32_t stat_items, stat_waves;    // diagnostics (smhv_debug_pipeline_stats): frames searched; waves that have come and gone
 	unsigned long long stat_busy, stat_life;   // cycles spent on frames / between a wave's first poll and its exit, summed over those waves
 	unsigned long long stat_phase[4];   // of stat_busy: acquire (cache invalidation), tile store + search, record (scale ratio + derived outputs), release + count
-	uint32_t pad[4];
+	unsigned long long stat_help;       // cycles spent casting candidates for other waves' frames (not in stat_busy)
+	uint32_t pad[2];
 	// ring entries follow: gen32 << 32 | slot << 24 | frame, gen = (ticket >> log2 cap) + 1
 };
 struct SvcHost {
-	uint32_t state;                     // submissions so far << 1 | service alive
+	// submissions so far << 32 | epoch of the service launch that is alive (0: none).  The host adds submissions and -- only
+	// when it finds the low half 0 -- puts a new launch's epoch there; only waves of THAT launch clear it again (64-bit
+	// compare-and-swap over PCIe), and a wave that finds another launch's epoch (or none) there leaves: no launch can outlive
+	// its own entry, whatever the interleaving.
+	unsigned long long state;
 	uint32_t launches;                  // service launches so far (diagnostic)
+	uint32_t pad0;
 	uint32_t done_seq[SVC_MAX_SLOTS];   // per slot: sequence number of its last completed submission
-	uint32_t pad[14];
+	uint32_t pad[12];
 };
 struct SvcParams {
 	SvcCtl *ctl;
@@ -197,13 +207,14 @@ struct SvcParams {
 	SvcSlot *slots;
 	SvcHost *host;                      // device address of the mapped host block
 	const uint32_t *cull_tab;           // the sector table every submission of this launch uses (null: every ray is cast)
+	const float *ray_off;               // Buffers::ray_off of the context (the same for every slot)
 	float max_gap;
 	uint32_t tile_cap, list_cap;        // per-wave tile store and list sizes
 	uint32_t part_words;                // LDS words per wave (WShared + tile store + lists + window)
 	uint32_t ring_log2;
 	uint32_t epoch;                     // of this launch (> 0)
 	uint32_t idle_short, idle_long;     // in units of 1024 cycles
-	uint32_t flags;                     // experiments (SMH_SVC_FLAGS; results may be WRONG): 1 = no cache invalidation per item, 2 = no write-back per frame
+	uint32_t flags;                     // experiments (SMH_SVC_FLAGS; results may be WRONG): 1 = no cache invalidation per item, 2 = no write-back per frame, 4 = s_setprio 3, 8 = no helping among the waves of a workgroup
 };
 // waves per service workgroup and LDS per workgroup for this frame size (0 waves: the frame size does not fit -> no service)
 uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes);
@@ -230,7 +241,6 @@ struct LaunchTuning {
 // LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
 uint32_t map_brq_lds_bytes(const Geom &g);
 uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit);
-uint32_t lsd_seq_lds_bytes(const Geom &g, uint32_t tile_limit);      // k_lsd_seq (one wave per frame: tile_bs = 64)
 hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
                                const LaunchTuning *tune = nullptr);
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
@@ -244,8 +254,7 @@ bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame
 // b.co (if present) is zeroed on `s` before the launch; extra_helpers: additional workgroups that only help (small batches).
 // find_lines runs on k_lsd_tile unless the buffers carry the helper scheme (b.co), prefer_classic is set (the schedule knows
 // better: smhv_pipeline at depth 2 on frames up to 1080p) or the process-wide diagnostic switch is.
-// tile_bs: threads per workgroup of k_lsd_tile (0: 512; a batch that runs alone takes 1024); 64 selects k_lsd_seq, the
-// one-wave-per-frame sequential scan (deep pipelines: least wave-time per frame, longest time to a frame's result)
+// tile_bs: threads per workgroup of k_lsd_tile (0: 512; a batch that runs alone takes 1024)
 // record_fused (optional) <- whether the launch writes the frames' records itself (b.rec_stages has SMH_REC_ON and the kernel
 // picked is k_lsd_tile); otherwise the caller launches the record kernel behind it
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs = 0,
@@ -265,7 +274,7 @@ size_t lsd_lds_bytes();
 void lsd_set_classic(bool on);
 // diagnostic: cap the tile store of k_lsd_tile (0 = what fits), to exercise the path of frames with more tiles than that
 void lsd_set_tile_cap(uint32_t cap);
-// diagnostic: threads per workgroup of every find_lines launch that is not k_lsd (0 = the caller's choice; 64 = k_lsd_seq)
+// diagnostic: threads per workgroup of every k_lsd_tile launch (0 = the caller's choice; 128 .. 1024)
 void lsd_set_threads(uint32_t threads);
 // diagnostic: watchdog budget of k_lsd_tile in idle polls (0 = default)
 void lsd_set_spin_limit(uint32_t polls);

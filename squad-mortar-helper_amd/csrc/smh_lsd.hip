@@ -1363,13 +1363,6 @@ static uint32_t lsd_tile_cap_of(const Geom &g, uint32_t tile_limit) {
 	if (cap_o) cap = std::min(cap_o, tile_cap_for(g));
 	return cap;
 }
-static uint32_t lsd_seq_static_lds() {
-	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_lsd_seq) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 17408u; }();
-	return v;
-}
-uint32_t lsd_seq_lds_bytes(const Geom &g, uint32_t tile_limit) {
-	return lsd_seq_static_lds() + (tile_mask_words(g.rw, g.rh, lsd_tile_cap_of(g, tile_limit)) + 2u * tile_list_cap_for(g) + W_WIN_STRIDE) * 4u;
-}
 uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit) {
 	return lsd_tile_static_lds() + (tile_mask_words(g.rw, g.rh, lsd_tile_cap_of(g, tile_limit)) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u;
 }
@@ -1389,7 +1382,6 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 		                     (const void *)k_lsd<LSD_MODE_ROWS, true>, (const void *)k_lsd<LSD_MODE_XWIN, true>, (const void *)k_lsd<LSD_MODE_GLOBAL, true>};
 		for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSD_TILE_DYN_LDS_MAX);
-		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSD_TILE_DYN_LDS_MAX);
 		if (e != hipSuccess) return e;
 		if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 	}
@@ -1400,15 +1392,10 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	// workgroup-synchronous k_lsd (with helper workgroups when the batch asks for them, for Vision::find_longest_line, and
 	// on request: smhv_debug_lsd_classic / SMH_LSD_KERNEL=classic).
 	if (mode == 0 && !coop && !prefer_classic && !lsd_classic_flag().load(std::memory_order_relaxed)) {
-		static const uint32_t bs_env = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= LSD_TILE_BS && v % 64 == 0) ? (uint32_t)v : 0u; }();
+		static const uint32_t bs_env = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 128 && v <= LSD_TILE_BS && v % 64 == 0) ? (uint32_t)v : 0u; }();
 		const uint32_t bs_o = g_bs_override.load(std::memory_order_relaxed);
-		const uint32_t bs = bs_o ? bs_o : (bs_env ? bs_env : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u));
+		const uint32_t bs = std::max<uint32_t>(128u, bs_o ? bs_o : (bs_env ? bs_env : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u)));
 		const uint32_t cap = lsd_tile_cap_of(g, tile_limit);
-		if (bs == LSD_SEQ_BS) {                                  // one wave per frame (smh_lsd_seq.inc): what a deep pipeline asks for
-			const unsigned q_lds = (tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_WIN_STRIDE) * 4u;
-			hipLaunchKernelGGL(k_lsd_seq, dim3(n), dim3(LSD_SEQ_BS), q_lds, s, g, b, max_gap, cap, tile_list_cap_for(g));
-			return hipGetLastError();
-		}
 		// diagnostic: SMH_W_LDS_PAD=<bytes> enlarges the request (fewer workgroups of this kernel per CU, the rest of the CU left to other kernels)
 		static const unsigned lds_pad = [] { const char *e = getenv("SMH_W_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
 		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u + lds_pad, LSD_TILE_DYN_LDS_MAX);

@@ -403,7 +403,7 @@ extern "C" SMHV_API int smhv_debug_skip_line_search(int on) {
 }
 
 extern "C" SMHV_API int smhv_debug_lsd_threads(uint32_t threads) {
-	if (threads != 0 && (threads < 64 || threads > 1024 || threads % 64)) return fail(SMHV_E_INVALID, "lsd_threads: 0 or a multiple of 64 up to 1024");
+	if (threads != 0 && (threads < 128 || threads > 1024 || threads % 64)) return fail(SMHV_E_INVALID, "lsd_threads: 0 or a multiple of 64 from 128 to 1024");
 	lsd_set_threads(threads);
 	return SMHV_OK;
 }
@@ -592,7 +592,10 @@ static uint32_t lsd_helpers_for(const smhv_batch *b, uint32_t n) {
 // sl == s for a plain smhv_batch_run; a pipeline with partitioned CUs passes two streams (sl waits for the streaming pass).
 // svc != null: the batch belongs to a pipeline with a frame-granular search service (smh_kernels.h): the streaming side ends
 // with the publication of the frames, and the service's waves search them and write their records.
-struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; };
+// s_pro: the pipeline's prologue stream -- the anchor upload and the button test of a submission run there, ahead of time, so
+// that the chain on a streaming stream is pass -> publication -> pass: the button test (45 us inside a busy pipeline, plus a
+// hand-over) is off it.
+struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro; };
 static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                           const smhv_anchors *anchors, hipStream_t s, hipStream_t sl, const SvcPublish *svc = nullptr) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
@@ -612,6 +615,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 		if (rc) return rc;
 	}
 	const bool scales = (stages & SMHV_STAGE_SCALES) && anchors;
+	const hipStream_t sb = (svc && svc->s_pro) ? svc->s_pro : s;   // where the anchor upload and the button test go
 	if (scales) {
 		// Pinned staging for the anchor upload (a pageable source would make hipMemcpyAsync synchronous).  A staging
 		// buffer is reused once the copy that read it has completed; if none is free another one is allocated, so this call
@@ -628,16 +632,20 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 			st = &b->anchor_stage.back();
 		}
 		memcpy(st->h, anchors, sizeof(smhv_anchors) * n);
-		HIPCHK(hipMemcpyAsync(b->d_anchors, st->h, sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, s));
-		HIPCHK(hipEventRecord(st->done, s));
+		HIPCHK(hipMemcpyAsync(b->d_anchors, st->h, sizeof(smhv_anchors) * n, hipMemcpyHostToDevice, sb));
+		HIPCHK(hipEventRecord(st->done, sb));
 	}
 	const bool t = b->timing;
 	hipEvent_t *ev = t ? b->ev[b->timed_runs % smhv_batch::TIMING_RING] : nullptr;
 #define STAGE_BEGIN(i, st) do { if (t) HIPCHK(hipEventRecord(ev[2 * (i)], (st))); } while (0)
 #define STAGE_END(i, st) do { if (t) HIPCHK(hipEventRecord(ev[2 * (i) + 1], (st))); } while (0)
-	STAGE_BEGIN(0, s);
-	HIPCHK(launch_button(g, bf, n, 0, s));
-	STAGE_END(0, s);
+	STAGE_BEGIN(0, sb);
+	HIPCHK(launch_button(g, bf, n, 0, sb));
+	STAGE_END(0, sb);
+	if (sb != s) {
+		HIPCHK(hipEventRecord(svc->ev_pro, sb));
+		HIPCHK(hipStreamWaitEvent(s, svc->ev_pro, 0));
+	}
 	// ---- ONE streaming pass: ui_map, marker mask + dilation, and -- on the pixels it has loaded anyway -- the two
 	// bottom-right-quadrant images (ocr_preprocess, find_scales_preprocess).  Everything runs on the caller's stream: the
 	// schedule does not depend on how HIP happens to map extra streams onto hardware queues.
@@ -851,8 +859,9 @@ struct smhv_pipeline {
 	unsigned long long *d_svc_ring = nullptr;
 	SvcSlot *d_svc_slots = nullptr;
 	SvcHost *h_svc = nullptr, *d_svc_host = nullptr;
-	hipStream_t s_search = nullptr;
+	hipStream_t s_search = nullptr, s_pro = nullptr;   // (s_pro: anchor uploads and button tests, ahead of the streaming streams)
 	std::vector<hipEvent_t> ev_pub;     // per slot: the slot's items have been published
+	std::vector<hipEvent_t> ev_pro;     // per slot: its button test has run
 	std::vector<uint32_t> seq;          // per slot: sequence number of its most recent submission (0: none yet)
 	std::vector<hipStream_t> slot_st;   // per slot: the stream its most recent streaming side ran on
 	uint32_t seq_counter = 0, svc_epoch = 0;
@@ -878,7 +887,9 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (p->s_stream) (void)hipStreamDestroy(p->s_stream);
 	for (auto st : p->s_lsd) if (st) (void)hipStreamDestroy(st);
 	if (p->s_search) (void)hipStreamDestroy(p->s_search);
+	if (p->s_pro) (void)hipStreamDestroy(p->s_pro);
 	for (auto e : p->ev_pub) if (e) (void)hipEventDestroy(e);
+	for (auto e : p->ev_pro) if (e) (void)hipEventDestroy(e);
 	if (p->d_svc_ctl) (void)hipFree(p->d_svc_ctl);
 	if (p->d_svc_ring) (void)hipFree(p->d_svc_ring);
 	if (p->d_svc_slots) (void)hipFree(p->d_svc_slots);
@@ -977,14 +988,17 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 			// lives as long as the pipeline is busy, and whatever shared its queue would wait that long
 			const uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
 			e = create_stream(&p->s_search, full);
+			static const bool pro_off = [] { const char *e = getenv("SMH_SVC_PROLOGUE"); return e && atoi(e) == 0; }();   // diagnostic A/B
+			if (e == hipSuccess && !pro_off) e = hipStreamCreateWithFlags(&p->s_pro, hipStreamNonBlocking);
 		}
 	}
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
 	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
 	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->hold[i], hipEventDisableTiming);
 	if (p->svc && e == hipSuccess) {
-		p->ev_pub.assign(depth, nullptr); p->seq.assign(depth, 0u); p->slot_st.assign(depth, nullptr);
+		p->ev_pub.assign(depth, nullptr); p->ev_pro.assign(depth, nullptr); p->seq.assign(depth, 0u); p->slot_st.assign(depth, nullptr);
 		for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_pub[i], hipEventDisableTiming);
+		for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_pro[i], hipEventDisableTiming);
 		uint32_t lg = 8;
 		while ((1ull << lg) < (uint64_t)depth * max_frames) ++lg;
 		p->svc_ring_log2 = lg;
@@ -1007,11 +1021,9 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (rc) { smhv_pipeline_destroy(p); return rc; }
 		// Measured on MI355X: frames whose mask window fits the LDS (<= 1080p) -- depth 1: k_lsd with
 		// helper workgroups, depth 2: k_lsd, depth >= 3: k_lsd_tile with 512-thread workgroups; larger frames: k_lsd_tile always.
-		// k_lsd_seq (one wave per frame) takes a third of k_lsd_tile's wave-time per frame but four times as long to deliver the
-		// batch's slowest frame (4.1 ms against 1.0 for 256 x 1080p), and a slot cannot be resubmitted before that: measured
-		// 200 k frames/s against 455 k at depth 4 and 8.  Opt-in (SMH_LSD_SEQ=1) until a launch no longer waits for its slowest frame.
-		static const bool seq = [] { const char *e = getenv("SMH_LSD_SEQ"); return e && atoi(e) != 0; }();
-		p->batch[i]->lsd_bs = seq ? 64u : (depth >= 2 ? 512u : 1024u);
+		// (The one-wave-per-frame scan, a third of k_lsd_tile's wave-time per frame, runs inside the frame-granular search service
+		// of pipelines of depth >= 3: as a batch launch it blocked the slot for as long as its slowest frame.)
+		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
 		if (p->svc) {
 			// no occupancy policy: the service's resident waves (one per SIMD, most of a CU's LDS) are what caps the streaming
@@ -1045,14 +1057,14 @@ extern "C" SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *c, uint32_t W
 }
 
 // ---- the host side of the frame-granular search service --------------------------------------------------------------
-static inline uint32_t svc_state(smhv_pipeline *p) { return __atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE); }
+static inline bool svc_alive(smhv_pipeline *p) { return (uint32_t)__atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE) != 0u; }
 
 // Launch the service kernel behind the publication of `slot`'s items.  The alive flag is set first: from then on only the
 // device clears it (smh_service.inc, svc_pop).
 static int svc_launch(smhv_pipeline *p, uint32_t slot) {
 	SvcParams sp;
 	sp.ctl = p->d_svc_ctl; sp.ring = p->d_svc_ring; sp.slots = p->d_svc_slots; sp.host = p->d_svc_host;
-	sp.cull_tab = p->svc_cull; sp.max_gap = (float)p->svc_max_gap;
+	sp.cull_tab = p->svc_cull; sp.ray_off = p->ctx->d_ray_off; sp.max_gap = (float)p->svc_max_gap;
 	sp.tile_cap = p->svc_tile_cap; sp.list_cap = p->svc_list_cap; sp.part_words = p->svc_part_words; sp.ring_log2 = p->svc_ring_log2;
 	sp.epoch = ++p->svc_epoch;
 	if (sp.epoch == 0u) sp.epoch = ++p->svc_epoch;
@@ -1061,11 +1073,11 @@ static int svc_launch(smhv_pipeline *p, uint32_t slot) {
 	static const int flags_env = [] { const char *e = getenv("SMH_SVC_FLAGS"); return e ? atoi(e) : 0; }();   // experiments only
 	sp.flags = (uint32_t)flags_env;
 	sp.idle_long = 50000u;                                               // ~20 ms without work, nobody at work: the streaming side is stuck
-	__atomic_fetch_or(&p->h_svc->state, 1u, __ATOMIC_ACQ_REL);
+	__atomic_fetch_or(&p->h_svc->state, (unsigned long long)sp.epoch, __ATOMIC_ACQ_REL);   // (the low half is 0: only then is this called)
 	hipError_t e = hipStreamWaitEvent(p->s_search, p->ev_pub[slot], 0);
 	if (e == hipSuccess) e = launch_lsd_service(p->batch[slot]->g, sp, p->svc_wgs, p->svc_waves, p->svc_lds, p->s_search);
 	if (e != hipSuccess) {
-		__atomic_fetch_and(&p->h_svc->state, ~1u, __ATOMIC_ACQ_REL);
+		__atomic_fetch_and(&p->h_svc->state, 0xFFFFFFFF00000000ull, __ATOMIC_ACQ_REL);
 		return fail(SMHV_E_HIP, "launching the line-search service: %s", hipGetErrorString(e));
 	}
 	p->h_svc->launches++;
@@ -1082,8 +1094,8 @@ static int svc_wait_slot(smhv_pipeline *p, uint32_t slot) {
 	struct timespec t0;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
 	while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != target) {
-		if (!(svc_state(p) & 1u)) {
-			// not alive with work outstanding: the service gave way (its streaming side did not move for idle_long): again
+		if (!svc_alive(p)) {
+			// no launch alive with work outstanding: the service gave way (its streaming side did not move for idle_long): again
 			if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == target) break;
 			int rc = svc_launch(p, slot);
 			if (rc) return rc;
@@ -1094,7 +1106,11 @@ static int svc_wait_slot(smhv_pipeline *p, uint32_t slot) {
 		if ((spins & 1023u) == 0u) {
 			struct timespec t1;
 			clock_gettime(CLOCK_MONOTONIC, &t1);
-			if (t1.tv_sec - t0.tv_sec > 60) return fail(SMHV_E_STATE, "pipeline_wait: slot %u did not complete within 60 s (line-search service stalled)", slot);
+			if (t1.tv_sec - t0.tv_sec > 60) {
+				const unsigned long long st = __atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE);
+				return fail(SMHV_E_STATE, "pipeline_wait: slot %u (sequence %u, last completed %u) did not complete within 60 s: line-search service stalled "
+				            "(submissions %u, launch alive %u, launches %u)", slot, target, *flag, (uint32_t)(st >> 32), (uint32_t)st, p->h_svc->launches);
+			}
 		}
 	}
 	return SMHV_OK;
@@ -1116,29 +1132,40 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	if (want_cull) { rc = sector_table_for(p->ctx, max_gap, st, &probe); if (rc) return rc; }
 	if (!p->svc_key_valid || p->svc_cull != probe.cull_tab || p->svc_max_gap != max_gap) {
 		for (uint32_t i = 0; i < p->depth; ++i) { rc = svc_wait_slot(p, i); if (rc) return rc; }
-		while (svc_state(p) & 1u) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+		while (svc_alive(p)) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
 		p->svc_key_valid = true; p->svc_cull = probe.cull_tab; p->svc_max_gap = max_gap;
 	}
+	// (what the submission has to wait for gates its first kernel: the button test, on the prologue stream when there is one;
+	// the streaming stream waits for that test)
+	const hipStream_t s_first = p->s_pro ? p->s_pro : st;
 	if (after_stream) {
 		HIPCHK(hipEventRecord(p->ev_after, (hipStream_t)after_stream));
-		HIPCHK(hipStreamWaitEvent(st, p->ev_after, 0));
+		HIPCHK(hipStreamWaitEvent(s_first, p->ev_after, 0));
 	}
 	if (p->held[slot]) {
-		HIPCHK(hipStreamWaitEvent(st, p->hold[slot], 0));
+		HIPCHK(hipStreamWaitEvent(s_first, p->hold[slot], 0));
 		p->held[slot] = 0;
 	}
 	uint32_t seq = ++p->seq_counter;
 	if (seq == 0u) seq = ++p->seq_counter;
-	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true};
+	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot]};
+	// The submission is counted BEFORE its kernels are enqueued: from here on the service does not regard itself as drained
+	// (were it counted afterwards, its items could be there -- and a wave at work on them -- while the count still said
+	// "everything complete", and the service would close under that wave).
+	__atomic_fetch_add(&p->h_svc->state, 1ull << 32, __ATOMIC_ACQ_REL);
 	rc = batch_run_impl(b, d_frames, n, stages, grayscale, max_gap, anchors, st, st, &pub);
-	if (rc) return rc;
-	HIPCHK(hipEventRecord(p->ev_pub[slot], st));
+	hipError_t he = rc ? hipSuccess : hipEventRecord(p->ev_pub[slot], st);
+	if (rc || he != hipSuccess) {
+		// nothing of it may have been published: take the count back.  (If the publication did go out -- the event record failed
+		// behind it -- the service's count runs ahead by one and it simply never regards itself as drained early.)
+		if (rc) __atomic_fetch_sub(&p->h_svc->state, 1ull << 32, __ATOMIC_ACQ_REL);
+		return rc ? rc : fail(SMHV_E_HIP, "hipEventRecord: %s", hipGetErrorString(he));
+	}
 	p->seq[slot] = seq;
 	p->slot_st[slot] = st;
 	p->last_sl[slot] = st;
-	// count the submission; whoever finds the service not alive launches it (ordered behind this submission's items)
-	const uint32_t old = __atomic_fetch_add(&p->h_svc->state, 2u, __ATOMIC_ACQ_REL);
-	if (!(old & 1u)) { rc = svc_launch(p, slot); if (rc) return rc; }
+	// whoever finds no launch alive starts one (ordered behind this submission's items)
+	if (!svc_alive(p)) { rc = svc_launch(p, slot); if (rc) return rc; }
 	p->submitted++;
 	if (slot_out) *slot_out = slot;
 	return SMHV_OK;
@@ -1245,9 +1272,9 @@ extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
 	return rc;
 }
 
-extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[12]) {
+extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[16]) {
 	if (!p || !out) return fail(SMHV_E_INVALID, "bad arguments");
-	memset(out, 0, sizeof(uint64_t) * 12);
+	memset(out, 0, sizeof(uint64_t) * 16);
 	if (!p->svc) return SMHV_OK;
 	HIPCHK(hipSetDevice(p->ctx->device));
 	HIPCHK(hipDeviceSynchronize());                           // (the service closes by itself once nothing is outstanding)
@@ -1256,6 +1283,26 @@ extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out
 	out[0] = 1u; out[1] = p->h_svc->launches; out[2] = c.stat_items; out[3] = c.stat_waves; out[4] = c.stat_busy; out[5] = c.stat_life;
 	out[6] = (uint64_t)p->svc_wgs * p->svc_waves; out[7] = c.completed;
 	for (int k = 0; k < 4; ++k) out[8 + k] = c.stat_phase[k];
+	out[12] = c.stat_help;
+	return SMHV_OK;
+}
+
+// (no device-wide synchronisation: usable while a pipeline is stuck)
+extern "C" SMHV_API int smhv_debug_pipeline_peek(smhv_pipeline *p, uint64_t out[16]) {
+	if (!p || !out) return fail(SMHV_E_INVALID, "bad arguments");
+	memset(out, 0, sizeof(uint64_t) * 16);
+	if (!p->svc) return SMHV_OK;
+	HIPCHK(hipSetDevice(p->ctx->device));
+	const unsigned long long st = __atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE);
+	out[0] = st >> 32; out[1] = (uint32_t)st; out[2] = p->h_svc->launches; out[3] = p->seq_counter;
+	static hipStream_t s_peek = nullptr;
+	if (!s_peek) HIPCHK(hipStreamCreateWithFlags(&s_peek, hipStreamNonBlocking));
+	static SvcCtl *h_ctl = nullptr;
+	if (!h_ctl) HIPCHK(hipHostMalloc((void **)&h_ctl, sizeof(SvcCtl)));
+	HIPCHK(hipMemcpyAsync(h_ctl, p->d_svc_ctl, sizeof(SvcCtl), hipMemcpyDeviceToHost, s_peek));
+	HIPCHK(hipStreamSynchronize(s_peek));
+	out[4] = (uint64_t)(int64_t)h_ctl->avail; out[5] = h_ctl->head; out[6] = h_ctl->reserve; out[7] = h_ctl->closing; out[8] = h_ctl->completed; out[9] = h_ctl->busy;
+	for (uint32_t i = 0; i < 4 && i < p->depth; ++i) out[10 + i] = ((uint64_t)p->seq[i] << 32) | __atomic_load_n(&p->h_svc->done_seq[i], __ATOMIC_ACQUIRE);
 	return SMHV_OK;
 }
 

@@ -222,16 +222,25 @@ def test_fuzz_lsd_slice(vision, seed, size, max_gap):
 
 
 def test_both_line_segment_kernels_agree_with_the_oracle(vision):
-    """find_lines has three kernels: the task-based k_lsd_tile (sparse tile store of the mask, reorder buffer, waves claim
-    64-ray units), the workgroup-synchronous k_lsd (smhv_debug_lsd_classic) and k_lsd_seq, one wave per frame running the
-    reference's sequential scan (smhv_debug_lsd_threads(64); what deep pipelines use).  Random scenes and synthetic frames
-    through all of them, culled and exact; the tile-store kernels also with the store capped so low that some (cap 48) or
-    all (cap 4) frames overflow it and are searched on the mask in global memory."""
+    """find_lines has three implementations: the task-based k_lsd_tile (sparse tile store of the mask, reorder buffer, waves
+    claim 64-ray units), the workgroup-synchronous k_lsd (smhv_debug_lsd_classic) and the one-wave-per-frame sequential scan
+    that the frame-granular search service of a pipeline of depth >= 3 runs (k_lsd_service).  Random scenes and synthetic
+    frames through all of them, culled and exact; the tile-store searches also with the store capped so low that some
+    (cap 48) or all (cap 4) frames overflow it and are searched on the mask in global memory.  (A pipeline whose stage set
+    switches between culled and exact statistics also exercises the service's drain-and-relaunch with another sector table.)"""
     import torch
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import synth
     from fuzz_scenes import scene
     lib = smh._lib.load()
+
+    def check(got, ref, n, tag, exact):
+        for i in range(n):
+            assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (i,) + tag
+            assert got[i]["rounds"] == ref[i].rounds, (i,) + tag
+            if exact:
+                assert got[i]["ray_steps"] == ref[i].steps, (i,) + tag
+
     try:
         for seed, (W, H), max_gap in ((31, (1920, 1080), 15), (32, (2560, 1440), 15), (33, (1280, 1024), 30), (34, (1024, 768), 0), (35, (1600, 1024), 50)):
             n = 24
@@ -240,21 +249,29 @@ def test_both_line_segment_kernels_agree_with_the_oracle(vision):
             ref = o.process_batch(frames, min(os.cpu_count() or 1, n), stages=0x1, max_gap=max_gap)
             fb = smh.FrameBatch(vision, W, H, n)
             d = torch.from_numpy(frames).cuda()
-            # (classic, tile cap, threads): threads = 64 is k_lsd_seq, the one-wave-per-frame sequential scan of deep pipelines
-            for classic, cap, threads in ((0, 0, 0), (1, 0, 0), (0, 48, 0), (0, 4, 0), (0, 0, 64), (0, 48, 64), (0, 4, 64), (0, 0, 256)):
+            for classic, cap, threads in ((0, 0, 0), (1, 0, 0), (0, 48, 0), (0, 4, 0), (0, 0, 256)):
                 lib.smhv_debug_lsd_classic(classic)
                 lib.smhv_debug_lsd_tile_cap(cap)
                 lib.smhv_debug_lsd_threads(threads)
                 for exact in (0, smh.STAGE_EXACT_STATS):
                     for rep in range(2):
                         fb.run(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=max_gap, stream=torch.cuda.current_stream().cuda_stream)
-                        got = smh.results_to_dicts(fb.read_results(0, n))
-                        for i in range(n):
-                            assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (seed, i, classic, cap, threads, bool(exact))
-                            assert got[i]["rounds"] == ref[i].rounds, (seed, i, classic, cap, threads, bool(exact))
-                            if exact:
-                                assert got[i]["ray_steps"] == ref[i].steps, (seed, i, classic, cap, threads)
+                        check(smh.results_to_dicts(fb.read_results(0, n)), ref, n, (seed, classic, cap, threads, bool(exact)), exact)
             fb.close()
+            lib.smhv_debug_lsd_classic(0)
+            lib.smhv_debug_lsd_threads(0)
+            # the one-wave-per-frame scan: through the search service of a depth-3 pipeline (the tile cap is read when the
+            # pipeline is created)
+            for cap in (0, 48, 4):
+                lib.smhv_debug_lsd_tile_cap(cap)
+                pipe = smh.Pipeline(vision, W, H, n, 3)
+                lib.smhv_debug_lsd_tile_cap(0)
+                for exact in (0, smh.STAGE_EXACT_STATS, 0):
+                    slots = [pipe.submit(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=max_gap) for _ in range(4)]
+                    pipe.wait()
+                    for s_ in sorted(set(slots)):
+                        check(smh.results_to_dicts(pipe.slots[s_].read_results(0, n)), ref, n, (seed, "service", cap, s_, bool(exact)), exact)
+                pipe.close()
     finally:
         lib.smhv_debug_lsd_classic(0)
         lib.smhv_debug_lsd_tile_cap(0)

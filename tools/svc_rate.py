@@ -30,18 +30,58 @@ fb.run(d.data_ptr(), N, stages=stages, anchors=anchors, stream=torch.cuda.curren
 want = bytes(fb.read_results(0, N))
 fb.close()
 pipe = smh.Pipeline(vision, W, H, N, depth)
+
+
+def watchdog():
+    k = 0
+    while True:
+        time.sleep(15)
+        k += 1
+        try:
+            print("[watchdog %3d s] %s" % (15 * k, pipe.peek()), file=sys.stderr, flush=True)
+        except Exception as e:  # noqa: BLE001
+            print("[watchdog] peek failed: %s" % e, file=sys.stderr, flush=True)
+
+
+import threading
+threading.Thread(target=watchdog, daemon=True).start()
 for _ in range(2 * depth):
     pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
 pipe.wait()
 torch.cuda.synchronize()
+timing = os.environ.get("SVC_RATE_STAGE_MS")
+if timing:
+    for b in pipe.slots:
+        b.enable_timing(True)
 t0 = time.perf_counter()
-for _ in range(passes):
+slow = []
+for k in range(passes):
+    t1 = time.perf_counter()
     slot = pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
+    t2 = time.perf_counter()
+    if t2 - t1 > 0.03:
+        slow.append((k, round((t2 - t1) * 1e3, 1), pipe.peek()))
 pipe.wait()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+for k, ms, pk in slow[:6]:
+    print("[slow submit %d: %.1f ms] %s" % (k, ms, pk), file=sys.stderr, flush=True)
+stage_ms = None
+if timing:
+    per = [b.stage_ms() for b in pipe.slots[:min(depth, passes)]]
+    stage_ms = {k: float(np.mean([p_[k] for p_ in per])) for k in per[0]}
 equal = [bytes(pipe.slots[s].read_results(0, N)) == want for s in range(min(depth, passes))]
 st = pipe.search_stats()
+prof = None
+if os.environ.get("SVC_RATE_WPROF"):
+    # the -DSMH_LSD_WDEBUG build leaves the scan's phase timers in the records (smh_lsd_seq.inc): cycles of list build, dispatch,
+    # set-up, units, verdict; inside the units: first batches, long rays, end points; units cast
+    recs = pipe.slots[0].read_results(0, N)
+    acc = np.zeros(9)
+    for r in recs:
+        acc += np.array([r.meters[20 + k] for k in range(9)])
+    prof = dict(zip(("list_build", "dispatch", "setup", "units", "verdict", "u_first_batches", "u_long_rays", "u_end_points", "n_units"), (acc / N).tolist()))
+    prof["rounds"] = float(np.mean([r.rounds for r in recs]))
 pipe.close()
 print(json.dumps({"frames_per_s": N * passes / dt, "ms_per_pass": dt / passes * 1e3, "N": N, "depth": depth, "stages": stages, "frame": [W, H],
-                  "slots_equal_plain_run": all(equal), "env": {k: v for k, v in os.environ.items() if k.startswith("SMH_")}, "search_service": st}))
+                  "slots_equal_plain_run": all(equal), "env": {k: v for k, v in os.environ.items() if k.startswith("SMH_")}, "search_service": st, "scan_profile_cycles_per_frame": prof, "stage_ms": stage_ms, "slow_submits": len(slow)}))
