@@ -73,7 +73,8 @@ def parse_args():
     ap.add_argument("--stages", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
-    ap.add_argument("--pipeline-depth", type=int, default=4, help="batches in flight (smhv_pipeline_create depth)")
+    ap.add_argument("--pipeline-depth", type=int, default=12,
+                    help="batches in flight (smhv_pipeline_create depth; 12 x 256 frames resident outputs = 16 GB of the 288: what the frame-granular search needs to hide its one-wave-per-frame latency)")
     ap.add_argument("--distinct", type=int, default=None,
                     help="distinct synthetic frames per GPU (0 = every frame distinct); fewer are tiled on the device.  Default: every "
                          "frame distinct, except config 4 (1024 frames per GPU): 256 distinct frames per GPU, tiled four times -- "
@@ -84,8 +85,8 @@ def parse_args():
                     help="diagnostic: cap the tile store of k_lsd_tile (smhv_debug_lsd_tile_cap): fewer tiles = less LDS = more workgroups per CU")
     ap.add_argument("--idle-streams", type=int, default=0,
                     help="diagnostic: create this many HIP streams before the pipeline (the schedule must not depend on them)")
-    ap.add_argument("--stream-cus", type=int, default=None,
-                    help="CUs of every 32 reserved for the streaming kernels (smhv_pipeline_create_partitioned); default: the library's choice")
+    ap.add_argument("--search", default="auto", choices=("auto", "batch", "frame"),
+                    help="line-search schedule of the pipeline (smhv_pipeline_options::search); auto: frame-granular from depth 8 on")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-real-samples", action="store_true", help="skip the leg on the reference's own 1440p screenshots (real_samples)")
@@ -575,7 +576,7 @@ def main():
     idle_streams = [torch.cuda.Stream() for _ in range(max(0, args.idle_streams))]   # noqa: F841 (kept alive on purpose)
     if args.tile_cap > 0:
         smh._lib.load().smhv_debug_lsd_tile_cap(args.tile_cap)
-    pipe = smh.Pipeline(vision, W, H, n, depth, stream_cus=args.stream_cus)
+    pipe = smh.Pipeline(vision, W, H, n, depth, search=args.search)
     anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 0x8 else None
     fptr = frames.data_ptr()
 

@@ -139,7 +139,7 @@ SMHV_API int smhv_get_debug_view(smhv_ctx *ctx, int which, uint8_t *rgba, uint32
                                         cannot hold an acceptable ray (lines, rounds and every other output are identical;
                                         ray_steps then counts only the samples actually taken). */
 
-#define SMHV_STAGE_LSD_HELPERS 0x40u /* tuning: workgroups of the line-segment kernel that have finished their own frame help
+#define SMHV_STAGE_LSD_HELPERS 0x40u /* tuning (smhv_batch_run; a depth-1 pipeline sets it itself): workgroups of k_lsd that have finished their own frame help
                                        the frames still being searched (ray-cast candidates ahead of the owner; results are
                                        identical either way).  Shortens a single batch with a few heavy frames; only gets in
                                        the way when several batches are pipelined, so it is off by default. */
@@ -229,23 +229,20 @@ SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable);
 SMHV_API int smhv_batch_lsd_coop_stats(smhv_batch *b, uint32_t first, uint32_t n, uint32_t *out);
 SMHV_API int smhv_batch_stage_ms(smhv_batch *b, float ms[5]);
 
-/* diagnostic (process-wide): find_lines has two kernels -- the task-based k_lsd_tile (on == 0; the default: waves of a frame's
- * workgroup claim 64-ray units of the oldest candidate in flight, candidates retire in order through a reorder buffer; the mask
- * sits in LDS as a sparse store of 32 x 8 px tiles) and the workgroup-synchronous k_lsd (on != 0, or SMH_LSD_KERNEL=classic in
- * the environment; always used for Vision::find_longest_line and for batches run with SMHV_STAGE_LSD_HELPERS).  Both produce
- * the reference's results bit for bit; the tests run every fuzz scene through both. */
+/* diagnostic (process-wide): batched find_lines launches have two kernels -- the task-based k_lsd_tile (on == 0; the default:
+ * waves of a frame's workgroup claim 64-ray units of the oldest candidate in flight, candidates retire in order through a
+ * reorder buffer; the mask sits in LDS as a sparse store of 32 x 8 px tiles) and the workgroup-synchronous k_lsd (on != 0;
+ * always used for Vision::find_longest_line and for batches run with SMHV_STAGE_LSD_HELPERS).  Both produce the reference's
+ * results bit for bit; the tests run every fuzz scene through both (and through the frame-granular search of a deep pipeline). */
 SMHV_API int smhv_debug_lsd_classic(int on);
 /* diagnostic (process-wide): k_lsd_tile keeps at most `cap` non-empty mask tiles of a frame in LDS (0 = as many as fit: 1023 up
  * to 1440p, 541 at 4K; a marker scene has 40-260); a frame with more is searched on the mask in global memory (slow).  The
  * tests lower the cap to run frames through that path. */
 SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
-/* diagnostic (process-wide): find_lines has a third kernel, k_lsd_seq -- ONE wave per frame runs the reference's sequential scan
- * as it stands (no speculation, no atomics): least wave-time per frame, longest time to a frame's result; what smhv_pipeline
- * uses for its batches at depth >= 3, where throughput is wave slots x time.  threads = 64 forces it for every batched
- * find_lines launch, 128..1024 (multiples of 64) force k_lsd_tile with that workgroup size, 0 restores the library's choice.
- * The tests run every scene through all three kernels. */
+/* diagnostic (process-wide): threads per workgroup of every k_lsd_tile launch: 128..1024 (multiples of 64), 0 restores the
+ * library's choice (1024 for a batch that runs alone, 512 inside pipelines). */
 SMHV_API int smhv_debug_lsd_threads(uint32_t threads);
-/* diagnostic (process-wide; also SMH_SKIP_LSD=1): batched runs launch everything but the line search, so that the streaming
+/* diagnostic (process-wide): batched runs launch everything but the line search, so that the streaming
  * pass can be timed back to back with itself (bench.py, roofline_isolated.back_to_back).  The records of such a run hold no
  * valid lines. */
 SMHV_API int smhv_debug_skip_line_search(int on);
@@ -254,30 +251,53 @@ SMHV_API int smhv_debug_skip_line_search(int on);
  * it to 1 to force the error path. */
 SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
 /* ---- pipeline: several batches in flight, scheduled by the library ----------------------------------------------
- * `depth` output buffer sets (smhv_batch objects) of max_frames frames, each with its own stream.  The streams are
- * created by the library, in a fixed order, and consecutive submissions are started half a period apart, so the
- * throughput does not depend on what streams the host created before or on how it interleaves its calls.
+ * `depth` output buffer sets (smhv_batch objects) of max_frames frames.  The library owns every stream of the schedule (created
+ * in a fixed order: the throughput does not depend on what streams the host created before or on how it interleaves its calls).
  *   submit : asynchronous.  Enqueues the stages for n resident frames on the next slot (round robin) and returns at
  *            once; it only waits when that slot's previous submission (`depth` submissions ago) is still running.
  *            after_stream (optional): a stream whose already enqueued work (e.g. the producer of d_frames) must finish
  *            first.  *slot receives the slot index.
- *   wait   : host waits for the slot's most recent submission.
- *   slot   : the slot's batch object (results, device pointers, images) and the stream its most recent record kernel ran
- *            on (to order a consumer, e.g. an RCCL gather, after it).
+ *   wait   : host waits for the slot's most recent submission (all of its frames' records are in device memory then).
+ *   slot   : the slot's batch object (results, device pointers, images); with `stream` != NULL also a stream a consumer can use
+ *            -- with the frame-granular search the call first WAITS (host) for the slot's submission: a submission's completion
+ *            is a counter the search's waves count down, not a point on a stream.
  *   hold   : a consumer reads the slot's outputs on `stream` (work already enqueued there): the slot's next submission
  *            is ordered behind it.
- * depth: 1..8.  4 is what the library is tuned for; 8 measures the same, 5 and 6 measure 20-25 % lower: HIP deals the streams
- * onto four hardware queues, and with five or six streams two of the queues carry two batches each (setting
- * GPU_MAX_HW_QUEUES=8 does not change that on this runtime).  The pipeline also picks the line-search kernel and its workgroup size for
- * the depth and the frame size (DESIGN.md sections 5 and 7).
- * CU partition (MI355X: 256 CUs in 8 XCDs): smhv_pipeline_create_partitioned gives the streaming kernels (button test, the
- * fused map / quadrant pass: HBM-bound) `stream_cus_of_32` CUs out of every 32 (hipExtStreamCreateWithCUMask; all passes'
- * streaming kernels go through one stream) and the line-segment search the rest (two streams, so consecutive launches
- * overlap).  0 = no partition.  Measured: never better than no partition (on half the CUs the streaming pass is limited by
- * the bytes a CU can keep in flight).  smhv_pipeline_create uses the library's default, no partition (environment
- * SMHV_PIPELINE_STREAM_CUS overrides it). */
+ * depth: 1..16.  Two line-search schedules, chosen by the library from the depth (smhv_pipeline_options::search overrides):
+ *   batch-granular (depth < 8): one search launch per submission on the slot's own stream (k_lsd with helper workgroups at
+ *     depth 1, k_lsd at depth 2 up to 1080p, k_lsd_tile otherwise), staggered starts, and from depth 3 on an occupancy policy
+ *     for the streaming pass that adapts to the workload.  Tuned for depth 4; 5 and 6 measure 20-25 % lower (HIP deals the
+ *     slots' streams onto four hardware queues).
+ *   frame-granular (depth >= 8, frame sizes up to ~4K): ONE long-lived search kernel per pipeline whose waves pull (slot,
+ *     frame) items from a device-side ring -- one wave per frame, the reference's sequential scan, with the other waves of its
+ *     workgroup casting a heavy frame's upcoming candidates -- write the frame's record and count it off against its
+ *     submission; the submissions' streaming sides take two library-owned streams in turn.  A slot is done when its slowest
+ *     frame is, nothing else waits for that frame.  The kernel closes by itself when nothing is outstanding (a device-wide
+ *     synchronize by anybody still returns) and is launched again by the next submission.  Needs ~2000 frames in flight to
+ *     hide the one-wave latency: 455 k frames/s at depth 8, 510 k at depth 12 (256 x 1080p; batch-granular at depth 4: 435 k). */
 typedef struct smhv_pipeline smhv_pipeline;
 SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth, smhv_pipeline **out);
+/* The same with explicit choices: zero-initialise, set `size` = sizeof(smhv_pipeline_options), change what you need (every 0 is
+ * the library's default; there are no environment variables). */
+#define SMHV_SEARCH_AUTO 0u             /* frame-granular from depth 8 on where the frame size allows it, else batch-granular */
+#define SMHV_SEARCH_BATCH 1u
+#define SMHV_SEARCH_FRAME 2u            /* SMHV_E_INVALID when depth < 3 or the frame's mask tiles do not fit the LDS beside the streaming pass (8K) */
+#define SMHV_PIPE_NO_TEAM_HELP 1u       /* flags, diagnostics (A/B): frame-granular search without waves helping the heavy frames of their workgroup */
+#define SMHV_PIPE_NO_STREAM_PRIORITY 2u /*   ... without wave priority for the streaming pass */
+#define SMHV_PIPE_NO_PROLOGUE 4u        /*   ... button test and anchor upload on the streaming streams instead of a stream of their own */
+typedef struct {
+	uint32_t size;
+	uint32_t search;                    /* SMHV_SEARCH_* */
+	uint32_t streams;                   /* frame-granular: streaming streams the submissions take in turn (0 = 2; 1..8) */
+	uint32_t idle_close_us;             /* frame-granular: the search kernel closes after this long without work when nothing is outstanding (0 = 45) */
+	uint32_t occupancy_policy;          /* batch-granular, depth >= 3: 0 = adaptive (on unless the workload is search-bound), 1 = always on, 2 = off */
+	uint32_t late_helpers;              /* batch-granular: workgroups that have finished their frame help one still at work: 0 = when the
+	                                       workload is search-bound, 1 = always, 2 = never */
+	uint32_t service_workgroups;        /* frame-granular, diagnostic: workgroups of the search kernel (0 = one per CU) */
+	uint32_t flags;                     /* SMHV_PIPE_* */
+} smhv_pipeline_options;
+SMHV_API int smhv_pipeline_create_ex(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
+                                     const smhv_pipeline_options *options, smhv_pipeline **out);
 SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p);
 SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                                   const smhv_anchors *anchors, void *after_stream, uint32_t *slot);
@@ -296,8 +316,6 @@ SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[16]);
  * counters (available, head, reserved, closing epoch, submissions completed, waves at work), [10..13] slots 0-3:
  * sequence number of the latest submission << 32 | of the last one completed. */
 SMHV_API int smhv_debug_pipeline_peek(smhv_pipeline *p, uint64_t out[16]);
-SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
-                                              uint32_t stream_cus_of_32, smhv_pipeline **out);
 
 /* ---- node: every GPU of a machine from ONE process -------------------------------------------
  * Frames are independent: a global batch is block-sharded over the devices (smhv_shard_range), each device runs the

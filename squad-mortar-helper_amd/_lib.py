@@ -95,7 +95,7 @@ SIGNATURES = {
     "smhv_batch_lsd_coop_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "smhv_batch_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "smhv_pipeline_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
-    "smhv_pipeline_create_partitioned": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "smhv_pipeline_create_ex": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "smhv_pipeline_hold": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "smhv_debug_pipeline_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "smhv_debug_pipeline_peek": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -128,6 +128,16 @@ SIGNATURES = {
     "smhv_ingest_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "smhv_crc32_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
 }
+
+
+class PipelineOptions(C.Structure):
+    """smhv_pipeline_options (include/smh_vision_hip.h): every 0 is the library's default."""
+    _fields_ = [("size", C.c_uint32), ("search", C.c_uint32), ("streams", C.c_uint32), ("idle_close_us", C.c_uint32), ("occupancy_policy", C.c_uint32),
+                ("late_helpers", C.c_uint32), ("service_workgroups", C.c_uint32), ("flags", C.c_uint32)]
+
+
+SEARCH_AUTO, SEARCH_BATCH, SEARCH_FRAME = 0, 1, 2
+PIPE_NO_TEAM_HELP, PIPE_NO_STREAM_PRIORITY, PIPE_NO_PROLOGUE = 1, 2, 4
 
 
 class VisionError(RuntimeError):

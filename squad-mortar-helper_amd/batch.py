@@ -140,17 +140,24 @@ class FrameBatch:
 
 class Pipeline:
     """`depth` batches in flight on library-owned streams (smhv_pipeline_*): submit() is asynchronous and returns the slot;
-    the library starts consecutive submissions half a period apart and owns every stream of the schedule."""
+    the library owns every stream of the schedule and picks the line-search schedule for the depth (batch-granular below
+    depth 8, the frame-granular search service from there on)."""
 
-    def __init__(self, vision, frame_w, frame_h, max_frames, depth=4, stream_cus=None):
-        """stream_cus: CUs of every 32 reserved for the streaming kernels (None: the library default, 0: no partition)."""
+    def __init__(self, vision, frame_w, frame_h, max_frames, depth=4, search=None, **options):
+        """search: None / "auto" (the library decides from the depth: frame-granular from depth 8 on), "batch", "frame";
+        options: the other fields of smhv_pipeline_options (streams, idle_close_us, occupancy_policy, late_helpers,
+        service_workgroups, flags)."""
         self._lib = L.load()
         self._vision = vision
         p = C.c_void_p()
-        if stream_cus is None:
-            L.check(self._lib.smhv_pipeline_create(vision._ctx, frame_w, frame_h, max_frames, depth, C.byref(p)))
-        else:
-            L.check(self._lib.smhv_pipeline_create_partitioned(vision._ctx, frame_w, frame_h, max_frames, depth, int(stream_cus), C.byref(p)))
+        opt = L.PipelineOptions()
+        opt.size = C.sizeof(L.PipelineOptions)
+        opt.search = {None: L.SEARCH_AUTO, "auto": L.SEARCH_AUTO, "batch": L.SEARCH_BATCH, "frame": L.SEARCH_FRAME}[search]
+        for k, v in options.items():
+            if k not in ("streams", "idle_close_us", "occupancy_policy", "late_helpers", "service_workgroups", "flags"):
+                raise TypeError("Pipeline: unknown option %r" % k)
+            setattr(opt, k, int(v))
+        L.check(self._lib.smhv_pipeline_create_ex(vision._ctx, frame_w, frame_h, max_frames, depth, C.byref(opt), C.byref(p)))
         self._p = p
         self.depth = depth
         self.slots = []
@@ -160,7 +167,8 @@ class Pipeline:
             self.slots.append(FrameBatch(vision, frame_w, frame_h, max_frames, _handle=b))
 
     def stream_of(self, slot):
-        """HIP stream on which the slot's most recent record kernel runs (order consumers after it)."""
+        """A HIP stream to order a consumer of the slot's outputs on (batch-granular search: the stream its record kernel ran
+        on; frame-granular search: the call waits for the slot's submission on the host first)."""
         st = C.c_void_p()
         L.check(self._lib.smhv_pipeline_slot(self._p, slot, None, C.byref(st)))
         return st.value or 0

@@ -85,13 +85,13 @@ struct BatchError {
 	uint32_t pad[5];
 };
 
-// ---- helper workgroups of k_lsd_tile ("farm", round 3) ------------------------------------------------------------------
-// A launch may carry extra workgroups beyond its frames.  Helper h attaches to the frame with the h-th largest marker mask
-// (both sides derive that from FrameAux; no planning kernel), builds the same tile store and casts whole CANDIDATES the
-// owner posts to it: the owner's reorder buffer holds local and remote candidates alike and retires them in order, so lines,
-// rounds and sample counts are the sequential scan's whichever workgroup cast a candidate (casting is a pure function of
-// (mask, pixel)).  Every word below is ONE 8-byte agent-scope atomic (a granule is never torn, needs no fence); the three
-// payload words of a result are stored, drained (s_waitcnt vmcnt(0)), then the tagged word.
+// ---- late helpers of k_lsd_tile (round 3) ---------------------------------------------------------------------------------
+// A workgroup that has written its own frame's record looks once over the launch's frames, takes one that is still at work and
+// has asked for help (FarmFrame::want), builds the same tile store and casts whole CANDIDATES its owner posts to it: the owner's
+// reorder buffer holds local and remote candidates alike and retires them in order, so lines, rounds and sample counts are the
+// sequential scan's whichever workgroup cast a candidate (casting is a pure function of (mask, pixel)).  Every word below is ONE
+// 8-byte agent-scope atomic (a granule is never torn, needs no fence); the three payload words of a result are stored, drained
+// (s_waitcnt vmcnt(0)), then the tagged word.
 #define SMH_FARM_RING 4u
 #define SMH_REC_ON 0x80000000u
 #define SMH_LSD_LATE_HELP 1u
@@ -103,7 +103,7 @@ struct FarmEntry {                  // 64 bytes
 	unsigned long long done;        //   tag32 << 32 | steps, tag = epoch16 << 16 | (k + 1)16: written last
 	unsigned long long pad[3];
 };
-struct FarmFrame {                  // one per helper workgroup of the launch (late helpers: one per frame)
+struct FarmFrame {                  // one per frame of the launch
 	unsigned long long attached;    // helper -> owner: epoch when the helper has built its tile store and listens
 	unsigned long long owner_done;  // owner -> helper: epoch when the frame is finished
 	// late helpers (SMH_LSD_LATE_HELP): a workgroup that has finished its own frame helps one that is still at work
@@ -115,8 +115,7 @@ struct FarmFrame {                  // one per helper workgroup of the launch (l
 
 struct Buffers {
 	BatchError *err;         // device address of the batch's mailbox (null: none)
-	FarmFrame *farm;         // helper exchange of k_lsd_tile, n_farm entries (null / 0: no helpers in this launch)
-	uint32_t n_farm;
+	FarmFrame *farm;         // late-helper exchange of k_lsd_tile, one entry per frame (null: none)
 	// k_lsd_tile writes the frame's record itself (smh_record.inc: scale ratio + derived marker outputs) when SMH_REC_ON is set:
 	// rec_stages = SMH_REC_ON | the run's stage mask (SMHV_STAGE_SCALES cleared when the run has no anchors), rec_bars = the
 	// scale-bar debug slab or null
@@ -221,7 +220,7 @@ uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words,
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s);
 hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s);
 
-enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u };
+enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u, MAP_PRIO = 0x100u };
 enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
@@ -236,7 +235,8 @@ struct LaunchTuning {
 	uint32_t map_lds_total;   // LDS a streaming workgroup occupies, static + dynamic, in bytes (0: what it needs)
 	uint32_t map_grid_cap;    // streaming workgroups per launch (0: one per item)
 	uint32_t lsd_tile_limit;  // k_lsd_tile keeps at most this many mask tiles in LDS (0: what fits the kernel's own budget)
-	uint32_t map_lean_sub;    // > 0: the lean form of the streaming pass with this many bands side by side per workgroup
+	uint32_t map_prio;        // != 0: the streaming waves run at wave priority 3 -- ahead of the search service's waves on their SIMD,
+	                          // which have slack (measured: 470 k -> 516 k frames/s at depth 12; beside the batch-granular search it cost 1-8 %)
 };
 // LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
 uint32_t map_brq_lds_bytes(const Geom &g);
@@ -258,7 +258,7 @@ bool lsd_rows_only(const Geom &g);   // every frame of this size is a ROWS frame
 // record_fused (optional) <- whether the launch writes the frames' records itself (b.rec_stages has SMH_REC_ON and the kernel
 // picked is k_lsd_tile); otherwise the caller launches the record kernel behind it
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs = 0,
-                      bool prefer_classic = false, uint32_t tile_limit = 0, uint32_t n_helpers = 0, bool *record_fused = nullptr);
+                      bool prefer_classic = false, uint32_t tile_limit = 0, bool *record_fused = nullptr);
 size_t lsd_coop_ctl_bytes(uint32_t n);      // LsdCtl + n LsdCoop (one allocation, zeroed per launch)
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s);
 hipError_t launch_find_minimap(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);

@@ -1338,8 +1338,8 @@ __global__ void k_build_sector_table(unsigned long long *tab, uint32_t T) {
 size_t lsd_lds_bytes() { return LSD_DYN_LDS_BYTES; }
 
 static std::atomic<bool> &lsd_classic_flag() {
-	// default: k_lsd_tile; SMH_LSD_KERNEL=classic or smhv_debug_lsd_classic(1) selects the workgroup-synchronous k_lsd
-	static std::atomic<bool> flag{[] { const char *e = getenv("SMH_LSD_KERNEL"); return e && strcmp(e, "classic") == 0; }()};
+	// default: k_lsd_tile; smhv_debug_lsd_classic(1) selects the workgroup-synchronous k_lsd
+	static std::atomic<bool> flag{false};
 	return flag;
 }
 void lsd_set_classic(bool on) { lsd_classic_flag().store(on, std::memory_order_relaxed); }
@@ -1368,7 +1368,7 @@ uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit) {
 }
 
 hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap, int mode, float px, float py, hipStream_t s, const LsdFork *fk, uint32_t tile_bs, bool prefer_classic,
-                      uint32_t tile_limit, uint32_t n_helpers, bool *record_fused) {
+                      uint32_t tile_limit, bool *record_fused) {
 	if (record_fused) *record_fused = false;
 	const unsigned lds_full = LSD_DYN_LDS_BYTES;
 	// more than 64 KB of dynamic LDS has to be allowed per function and per device
@@ -1392,17 +1392,12 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	// workgroup-synchronous k_lsd (with helper workgroups when the batch asks for them, for Vision::find_longest_line, and
 	// on request: smhv_debug_lsd_classic / SMH_LSD_KERNEL=classic).
 	if (mode == 0 && !coop && !prefer_classic && !lsd_classic_flag().load(std::memory_order_relaxed)) {
-		static const uint32_t bs_env = [] { const char *e = getenv("SMH_W_BS"); const int v = e ? atoi(e) : 0; return (v >= 128 && v <= LSD_TILE_BS && v % 64 == 0) ? (uint32_t)v : 0u; }();
 		const uint32_t bs_o = g_bs_override.load(std::memory_order_relaxed);
-		const uint32_t bs = std::max<uint32_t>(128u, bs_o ? bs_o : (bs_env ? bs_env : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u)));
+		const uint32_t bs = std::max<uint32_t>(128u, bs_o ? bs_o : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u));
 		const uint32_t cap = lsd_tile_cap_of(g, tile_limit);
-		// diagnostic: SMH_W_LDS_PAD=<bytes> enlarges the request (fewer workgroups of this kernel per CU, the rest of the CU left to other kernels)
-		static const unsigned lds_pad = [] { const char *e = getenv("SMH_W_LDS_PAD"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
-		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u + lds_pad, LSD_TILE_DYN_LDS_MAX);
-		Buffers bh = b;                                          // helper workgroups beyond the frames (smh_kernels.h, FarmFrame)
-		bh.n_farm = bh.farm ? n_helpers : 0u;
-		if (record_fused) *record_fused = (bh.rec_stages & SMH_REC_ON) != 0u;
-		hipLaunchKernelGGL(k_lsd_tile, dim3(n + bh.n_farm), dim3(bs), t_lds, s, g, bh, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed), tile_list_cap_for(g), n);
+		const unsigned t_lds = std::min<unsigned>((tile_mask_words(g.rw, g.rh, cap) + 2u * tile_list_cap_for(g) + W_NWIN * W_WIN_STRIDE) * 4u, LSD_TILE_DYN_LDS_MAX);
+		if (record_fused) *record_fused = (b.rec_stages & SMH_REC_ON) != 0u;
+		hipLaunchKernelGGL(k_lsd_tile, dim3(n), dim3(bs), t_lds, s, g, b, max_gap, cap, g_spin_limit.load(std::memory_order_relaxed), tile_list_cap_for(g), n);
 		return hipGetLastError();
 	}
 	if (coop) {

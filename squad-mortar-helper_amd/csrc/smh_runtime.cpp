@@ -25,10 +25,6 @@
 #include "smh_consts.h"
 #include "smh_kernels.h"
 
-#ifndef SMH_PIPELINE_STREAM_CUS_DEFAULT
-#define SMH_PIPELINE_STREAM_CUS_DEFAULT 0u   // CUs of every 32 reserved for the streaming kernels of a pipeline (0: none)
-#endif
-
 using namespace smh;
 
 // ------------------------------------------------------------------------------------------------
@@ -144,7 +140,7 @@ struct smhv_batch {
 	smhv_frame_result *d_results = nullptr;   // max_frames (+3 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
 	BatchError *h_err = nullptr, *d_err = nullptr;   // error mailbox: pinned host memory and its device address (smh_kernels.h)
-	FarmFrame *d_farm = nullptr;                     // helper exchange of k_lsd_tile (max_frames / 2 entries)
+	FarmFrame *d_farm = nullptr;                     // late-helper exchange of k_lsd_tile (one entry per frame)
 	// k_lsd cooperation (smh_kernels.h): [LsdCtl][LsdCoop x n] zeroed per launch, request rings, result caches
 	uint8_t *d_lsd_ctl = nullptr;
 	uint32_t *d_lsd_req = nullptr;
@@ -171,7 +167,6 @@ struct smhv_batch {
 	LsdFork lsd_fork{};
 	// threads per workgroup of the line search (k_lsd_tile): 1024 for a batch that has the chip to itself, 512 for the batches of
 	// a pipeline (two workgroups per CU, and room for the streaming pass of the other batches beside them)
-	uint32_t lsd_farm_pct = 0;            // helper workgroups of k_lsd_tile, in percent of the frames of a run
 	uint32_t lsd_late_kc = 0;             // late helpers of k_lsd_tile: thousands of cycles a frame works alone before it asks (0 = none)
 	uint32_t lsd_bs = 1024;
 	bool lsd_prefer_classic = false;      // set by smhv_pipeline_create where the workgroup-synchronous k_lsd measures faster
@@ -292,7 +287,7 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
 	bf.err = b->d_err;
-	bf.farm = b->d_farm; bf.n_farm = 0u; bf.rec_stages = 0u; bf.rec_bars = nullptr; bf.lsd_flags = 0u; bf.lsd_late_kc = 0u;
+	bf.farm = b->d_farm; bf.rec_stages = 0u; bf.rec_bars = nullptr; bf.lsd_flags = 0u; bf.lsd_late_kc = 0u;
 	bf.cull_tab = nullptr;
 	bf.ray_off = b->ctx->d_ray_off;
 	bf.frames = frames;
@@ -386,7 +381,7 @@ extern "C" SMHV_API int smhv_thread_ctx(smhv_ctx *c) {
 	return SMHV_OK;
 }
 
-static std::atomic<bool> g_skip_lsd{[] { const char *e = getenv("SMH_SKIP_LSD"); return e && atoi(e) != 0; }()};
+static std::atomic<bool> g_skip_lsd{false};
 extern "C" SMHV_API int smhv_debug_lsd_classic(int on) {
 	lsd_set_classic(on != 0);
 	return SMHV_OK;
@@ -442,13 +437,7 @@ static hipError_t create_stream(hipStream_t *st, const uint32_t *cu_mask) {
 	return cu_mask ? hipExtStreamCreateWithCUMask(st, 8, cu_mask) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
-static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, const uint32_t *lsd_cu_mask, smhv_batch **out);
-
 extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, smhv_batch **out) {
-	return batch_create_impl(c, W, H, max_frames, nullptr, out);
-}
-
-static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, const uint32_t *lsd_cu_mask, smhv_batch **out) {
 	if (!c || !out || max_frames == 0) return fail(SMHV_E_INVALID, "bad arguments");
 	*out = nullptr;
 	CTX_OPEN(c);
@@ -478,7 +467,7 @@ static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_f
 	ALLOC0(b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 * n);
 	ALLOC0(b->d_lsd_ctl, lsd_coop_ctl_bytes(max_frames));
 	ALLOC0(b->d_lsd_req, sizeof(uint32_t) * SMH_LSD_REQ_CAP * n);
-	ALLOC0(b->d_farm, sizeof(FarmFrame) * n);                  // (static helpers use up to n / 2 entries, late helpers one per frame)
+	ALLOC0(b->d_farm, sizeof(FarmFrame) * n);
 	ALLOC0(b->d_lsd_cache, sizeof(LsdCacheEntry) * SMH_LSD_CACHE_SLOTS * n);
 #undef ALLOC0
 	{
@@ -489,8 +478,8 @@ static int batch_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_f
 		// Only for frame sizes that need them: a process has few hardware queues, and every extra stream makes it more
 		// likely that two independent branches share one (measured: 10 % off the pipelined 1080p throughput).
 		if (max_frames > 1 && !lsd_rows_only(b->g)) {
-			if (e == hipSuccess) e = create_stream(&b->lsd_fork.s1, lsd_cu_mask);
-			if (e == hipSuccess) e = create_stream(&b->lsd_fork.s2, lsd_cu_mask);
+			if (e == hipSuccess) e = create_stream(&b->lsd_fork.s1, nullptr);
+			if (e == hipSuccess) e = create_stream(&b->lsd_fork.s2, nullptr);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&b->lsd_fork.fork, hipEventDisableTiming);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&b->lsd_fork.join1, hipEventDisableTiming);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&b->lsd_fork.join2, hipEventDisableTiming);
@@ -579,15 +568,6 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 	return SMHV_OK;
 }
 
-// Helper workgroups of the line search for a run over n frames (smh_kernels.h, FarmFrame): SMH_LSD_FARM=<percent of n> (diagnostic;
-// default: the batch's own setting, 0 = none)
-static uint32_t lsd_helpers_for(const smhv_batch *b, uint32_t n) {
-	static const int pct = [] { const char *e = getenv("SMH_LSD_FARM"); return e ? atoi(e) : -1; }();
-	const uint32_t p = pct >= 0 ? (uint32_t)pct : b->lsd_farm_pct;
-	const uint32_t h = (uint32_t)((uint64_t)n * p / 100u);
-	return h < (b->max_frames + 1u) / 2u ? h : (b->max_frames + 1u) / 2u;
-}
-
 // s: the streaming kernels (button test, the fused map / quadrant pass); sl: the line-segment search and the record kernel.
 // sl == s for a plain smhv_batch_run; a pipeline with partitioned CUs passes two streams (sl waits for the streaming pass).
 // svc != null: the batch belongs to a pipeline with a frame-granular search service (smh_kernels.h): the streaming side ends
@@ -665,7 +645,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	HIPCHK(hipEventRecord(b->ev_map_done, s));
 	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[1], s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
-	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (SMH_SKIP_LSD=1, smhv_debug_skip_line_search): the streaming pass with every output, no search
+	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (smhv_debug_skip_line_search): the streaming pass with every output, no search
 	if (svc) {
 		// ---- frame-granular: publish the frames; the service searches them and writes the records (minimap first: its kernel
 		// needs nothing of the search and the record keeps what it wrote) ----
@@ -682,23 +662,20 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	}
 	STAGE_BEGIN(3, sl);
 	// late helpers: workgroups of k_lsd_tile that have finished their frame help one that is still at work (smh_kernels.h,
-	// FarmFrame::want).  smhv_pipeline switches them on for search-bound workloads; SMH_LSD_LATE=0 / 1 / <thousands of cycles a
-	// frame must have been at work> overrides
-	static const int late_env = [] { const char *e = getenv("SMH_LSD_LATE"); return e ? atoi(e) : -1; }();   // -1: the batch's own setting (smhv_pipeline sets it for search-bound workloads)
-	const uint32_t late_kc = late_env < 0 ? b->lsd_late_kc : (late_env == 1 ? 1074u : (uint32_t)late_env);
-	if (late_kc > 0u && lsd_helpers_for(b, n) == 0u) { bf.lsd_flags |= SMH_LSD_LATE_HELP; bf.lsd_late_kc = late_kc; }
+	// FarmFrame::want).  smhv_pipeline switches them on for search-bound workloads (smhv_pipeline_options::late_helpers)
+	const uint32_t late_kc = b->lsd_late_kc;
+	if (late_kc > 0u) { bf.lsd_flags |= SMH_LSD_LATE_HELP; bf.lsd_late_kc = late_kc; }
 	// The workgroups of k_lsd_tile write their frames' records themselves (scale ratio + derived marker outputs, smh_record.inc):
 	// one kernel less in the batch's chain on its hardware queue (with stage timing on, the record's share is then inside the
 	// search's and stage 4 reads zero).  Not with the minimap stage: its kernel comes in between.
 	bool record_fused = false;
-	static const bool fuse_off = [] { const char *e = getenv("SMH_FUSE_RECORD"); return e && atoi(e) == 0; }();   // diagnostic: SMH_FUSE_RECORD=0
-	if (!fuse_off && !(stages & SMHV_STAGE_MINIMAP)) {
+	if (!(stages & SMHV_STAGE_MINIMAP)) {
 		bf.rec_stages = SMH_REC_ON | (scales ? stages : (stages & ~SMHV_STAGE_SCALES));
 		bf.rec_bars = b->d_bars;
 	}
 	if ((stages & SMHV_STAGE_MARKERS) && !skip_lsd) HIPCHK(launch_lsd(g, bf, n, (float)max_gap, 0, 0.0f, 0.0f, sl, b->lsd_fork.s1 ? &b->lsd_fork : nullptr, b->lsd_bs, b->lsd_prefer_classic,
 	                                                      (mflags && qflags) ? b->tune.lsd_tile_limit : 0u,   // (the limit makes room for the fused pass's reservation: no fused pass, no limit)
-	                                                      lsd_helpers_for(b, n), &record_fused));
+	                                                      &record_fused));
 	STAGE_END(3, sl);
 	if (b->probe) { HIPCHK(hipEventRecord(b->ev_probe[2], sl)); b->probe_valid = (stages & SMHV_STAGE_MARKERS) && mflags; }
 	if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sl));
@@ -829,12 +806,9 @@ extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t
 struct smhv_pipeline {
 	smhv_ctx *ctx = nullptr;
 	uint32_t depth = 0;
-	uint32_t stream_cus = 0;            // CUs (of every 32) reserved for the streaming kernels; 0: no partition
+	smhv_pipeline_options opt{};        // as given to smhv_pipeline_create_ex (all zero: the defaults)
 	std::vector<smhv_batch *> batch;
-	// no partition: stream[slot] carries the slot's whole pass.  partition: s_stream carries every pass's streaming kernels,
-	// s_lsd[k % 2] the line-segment search + record kernel of pass k (two, so that the tail of one launch overlaps the next)
-	std::vector<hipStream_t> stream;
-	hipStream_t s_stream = nullptr, s_lsd[2] = {nullptr, nullptr};
+	std::vector<hipStream_t> stream;    // batch-granular search: stream[slot] carries the slot's whole pass
 	std::vector<hipEvent_t> done;       // end of the slot's most recent submission
 	std::vector<hipEvent_t> hold;       // smhv_pipeline_hold: a consumer of the slot's outputs on some other stream
 	std::vector<char> held;
@@ -884,8 +858,6 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	for (auto e : p->hold) if (e) (void)hipEventDestroy(e);
 	if (p->ev_after) (void)hipEventDestroy(p->ev_after);
 	for (auto st : p->stream) if (st) (void)hipStreamDestroy(st);
-	if (p->s_stream) (void)hipStreamDestroy(p->s_stream);
-	for (auto st : p->s_lsd) if (st) (void)hipStreamDestroy(st);
 	if (p->s_search) (void)hipStreamDestroy(p->s_search);
 	if (p->s_pro) (void)hipStreamDestroy(p->s_pro);
 	for (auto e : p->ev_pub) if (e) (void)hipEventDestroy(e);
@@ -909,32 +881,12 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 // leaves no room for that (4K and up) get no policy.
 #define SMH_PIPE_TILE_LIMIT(g) ((g).rh > 900u ? 320u : 200u)   // a 1080p scene has 36-126 mask tiles, the 1440p screenshots up to 261
 #define SMH_PIPE_MAP_GRID 1024u
-#ifndef SMH_PIPE_LEAN_DEFAULT
-#define SMH_PIPE_LEAN_DEFAULT 0
-#endif
-#define SMH_PIPE_LEAN_TILE_LIMIT 400u
-#define SMH_PIPE_LEAN_GRID 512u
 #define SMH_LDS_PER_CU 163840u
 #define SMH_ADAPT_OFF 3.5f              // line search / streaming pass, launch durations: above -> no occupancy policy
 #define SMH_ADAPT_ON 1.6f               // ... below -> policy on again
 #define SMH_LATE_KC_SEARCH_BOUND 400u   // late helpers of a search-bound pipeline: a frame asks for help after 0.17 ms
 static LaunchTuning pipeline_tuning(const Geom &g) {
 	LaunchTuning t{0u, 0u, 0u, 0u};
-	static const bool off = [] { const char *e = getenv("SMH_PIPE_TUNING"); return e && atoi(e) == 0; }();   // diagnostic: SMH_PIPE_TUNING=0
-	if (off) return t;
-	// The lean form of the streaming pass (smh_stream.hip, k_map_brq_lean): ONE workgroup of twelve 80-register waves per CU --
-	// three bands side by side at 1080p, two at 1440p -- reserving more than half of the LDS, so that a second one never fits
-	// and a line-search workgroup always does.
-	static const int lean_env = [] { const char *e = getenv("SMH_PIPE_LEAN"); return e ? atoi(e) : -1; }();   // diagnostic: 0 / 1
-	const uint32_t wpb = g.m_block / 64u, nsub = wpb ? 12u / wpb : 0u;
-	if ((lean_env < 0 ? SMH_PIPE_LEAN_DEFAULT : lean_env) && nsub >= 2u && nsub * g.m_block <= 1024u && !(g.m_block % 64u)) {
-		const uint32_t r = 84u * 1024u, need = map_brq_lds_bytes(g) + nsub * wpb * 640u + nsub * g.m_block * 64u;
-		const uint32_t lsd_l = (lsd_tile_lds_bytes(g, SMH_PIPE_LEAN_TILE_LIMIT) + 1023u) & ~1023u;
-		if (need <= r && r + lsd_l + 2048u <= SMH_LDS_PER_CU) {
-			t.map_lds_total = r; t.map_grid_cap = SMH_PIPE_LEAN_GRID; t.lsd_tile_limit = SMH_PIPE_LEAN_TILE_LIMIT; t.map_lean_sub = nsub;
-			return t;
-		}
-	}
 	const uint32_t lsd = (lsd_tile_lds_bytes(g, SMH_PIPE_TILE_LIMIT(g)) + 1023u) & ~1023u;    // (allocation granularity: be generous)
 	if (lsd + 2048u >= SMH_LDS_PER_CU) return t;
 	const uint32_t r = ((SMH_LDS_PER_CU - lsd - 2048u) / 2u) & ~1023u;                           // two streaming workgroups beside one line search
@@ -944,42 +896,46 @@ static LaunchTuning pipeline_tuning(const Geom &g) {
 	return t;
 }
 
-// stream_cus: 0 = every kernel may use every CU; 1..31 = the streaming kernels get that many CUs of every 32 (of each XCD's
-// share), the line-segment search the rest (hipExtStreamCreateWithCUMask).
-static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, uint32_t stream_cus, smhv_pipeline **out) {
-	if (!c || !out || max_frames == 0 || depth == 0 || depth > SVC_MAX_SLOTS || stream_cus > 31) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..16, stream CUs 0..31 of 32)");
+// Defaults of smhv_pipeline_options (all zero): which search a pipeline gets is decided from what was measured on MI355X
+// (DESIGN.md): the frame-granular service needs ~2000 frames in flight to hide its one-wave-per-frame latency (256-frame
+// batches: 455 k frames/s at depth 8 and 510 k at depth 12, against 435 k for the batch-granular search at depth 4), below
+// that the batch-granular search with its occupancy policy is ahead (depth 4: 435 k against 275 k).
+#define SMH_SVC_AUTO_DEPTH 8u
+static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, const smhv_pipeline_options *opt_in, smhv_pipeline **out) {
+	if (!c || !out || max_frames == 0 || depth == 0 || depth > SVC_MAX_SLOTS) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..%u)", SVC_MAX_SLOTS);
 	*out = nullptr;
+	smhv_pipeline_options opt;
+	memset(&opt, 0, sizeof opt);
+	if (opt_in) {
+		if (opt_in->size < 2 * sizeof(uint32_t) || opt_in->size > 4096u) return fail(SMHV_E_INVALID, "pipeline_create_ex: options.size is not set");
+		memcpy(&opt, opt_in, opt_in->size < sizeof opt ? opt_in->size : sizeof opt);   // (a caller built against an older, shorter struct)
+	}
+	if (opt.search > SMHV_SEARCH_FRAME || opt.occupancy_policy > 2u || opt.late_helpers > 2u || opt.streams > 8u)
+		return fail(SMHV_E_INVALID, "pipeline_create_ex: bad option value");
 	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
-	if (depth == 1) stream_cus = 0;                           // nothing overlaps: every kernel gets the whole chip
 	Geom g0;
 	{ int rc = compute_geom(W, H, &g0); if (rc) return rc; }
 	smhv_pipeline *p = new (std::nothrow) smhv_pipeline();
 	if (!p) return fail(SMHV_E_INVALID, "out of host memory");
 	c->refs.fetch_add(1, std::memory_order_relaxed);
-	p->ctx = c; p->depth = depth; p->stream_cus = stream_cus;
-	// Frame-granular search (smh_kernels.h): depth >= 3, no CU partition, a frame size whose tile store fits beside the
-	// streaming pass.  SMH_SVC=0: the batch-granular search of rounds 2-3 (diagnostic A/B).
-	static const int svc_env = [] { const char *e = getenv("SMH_SVC"); return e ? atoi(e) : -1; }();
-	if (depth >= 3 && !stream_cus && svc_env != 0 && max_frames < (1u << 24)) {
+	p->ctx = c; p->depth = depth; p->opt = opt;
+	// Frame-granular search (smh_kernels.h): depth >= 3 and a frame size whose tile store fits beside the streaming pass
+	if (opt.search != SMHV_SEARCH_BATCH && depth >= 3 && (opt.search == SMHV_SEARCH_FRAME || depth >= SMH_SVC_AUTO_DEPTH) && max_frames < (1u << 24)) {
 		p->svc_waves = svc_waves_for(g0, SMH_PIPE_TILE_LIMIT(g0), &p->svc_part_words, &p->svc_tile_cap, &p->svc_list_cap, &p->svc_lds);
 		p->svc = p->svc_waves > 0u;
 	}
+	if (opt.search == SMHV_SEARCH_FRAME && !p->svc) {
+		ctx_release(c);
+		delete p;
+		return fail(SMHV_E_INVALID, "pipeline_create_ex: the frame-granular search needs depth >= 3 and a frame size whose mask tiles fit the LDS beside the streaming pass (%ux%u, depth %u)", W, H, depth);
+	}
 	p->batch.assign(depth, nullptr); p->done.assign(depth, nullptr); p->hold.assign(depth, nullptr); p->held.assign(depth, 0); p->last_sl.assign(depth, nullptr);
-	uint32_t m_stream[8], m_lsd[8];
-	uint32_t word = stream_cus ? ((1u << stream_cus) - 1u) : 0xFFFFFFFFu;
-	if (stream_cus) if (const char *e = getenv("SMHV_PIPELINE_STREAM_MASK")) { const uint32_t w = (uint32_t)strtoul(e, nullptr, 0); if (w && ~w) word = w; }   // diagnostic: raw per-XCD pattern
-	for (int i = 0; i < 8; ++i) { m_stream[i] = word; m_lsd[i] = ~word; }
 	hipError_t e = hipSuccess;
-	if (stream_cus) {
-		e = create_stream(&p->s_stream, m_stream);
-		if (e == hipSuccess) e = create_stream(&p->s_lsd[0], m_lsd);
-		if (e == hipSuccess) e = create_stream(&p->s_lsd[1], m_lsd);
-	} else {
+	{
 		// The streams are created back to back, before any other object of the pipeline: HIP deals streams onto the
 		// hardware queues in creation order, so consecutive streams never share one, whatever the host created earlier.
-		static const int ns_env = [] { const char *e = getenv("SMH_SVC_STREAMS"); return e ? atoi(e) : 0; }();   // diagnostic
-		p->svc_streams = p->svc ? std::min<uint32_t>(depth, ns_env > 0 ? (uint32_t)ns_env : 2u) : 0u;
+		p->svc_streams = p->svc ? std::min<uint32_t>(depth, opt.streams ? opt.streams : 2u) : 0u;
 		const uint32_t ns = p->svc ? p->svc_streams : depth;
 		p->stream.assign(ns, nullptr);
 		for (uint32_t i = 0; i < ns && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking);
@@ -988,8 +944,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 			// lives as long as the pipeline is busy, and whatever shared its queue would wait that long
 			const uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
 			e = create_stream(&p->s_search, full);
-			static const bool pro_off = [] { const char *e = getenv("SMH_SVC_PROLOGUE"); return e && atoi(e) == 0; }();   // diagnostic A/B
-			if (e == hipSuccess && !pro_off) e = hipStreamCreateWithFlags(&p->s_pro, hipStreamNonBlocking);
+			if (e == hipSuccess && !(opt.flags & SMHV_PIPE_NO_PROLOGUE)) e = hipStreamCreateWithFlags(&p->s_pro, hipStreamNonBlocking);
 		}
 	}
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
@@ -1004,8 +959,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		p->svc_ring_log2 = lg;
 		int cus = 0;
 		if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-		static const int wgs_env = [] { const char *e = getenv("SMH_SVC_WGS"); return e ? atoi(e) : 0; }();   // diagnostic
-		p->svc_wgs = wgs_env > 0 ? (uint32_t)wgs_env : (uint32_t)std::max(cus, 1);
+		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(cus, 1);
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ctl, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMemset(p->d_svc_ctl, 0, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ring, sizeof(unsigned long long) << lg);
@@ -1017,22 +971,22 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 	}
 	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline streams / events: %s", hipGetErrorString(e)); }
 	for (uint32_t i = 0; i < depth; ++i) {
-		int rc = batch_create_impl(c, W, H, max_frames, stream_cus ? m_lsd : nullptr, &p->batch[i]);
+		int rc = smhv_batch_create(c, W, H, max_frames, &p->batch[i]);
 		if (rc) { smhv_pipeline_destroy(p); return rc; }
-		// Measured on MI355X: frames whose mask window fits the LDS (<= 1080p) -- depth 1: k_lsd with
-		// helper workgroups, depth 2: k_lsd, depth >= 3: k_lsd_tile with 512-thread workgroups; larger frames: k_lsd_tile always.
-		// (The one-wave-per-frame scan, a third of k_lsd_tile's wave-time per frame, runs inside the frame-granular search service
-		// of pipelines of depth >= 3: as a batch launch it blocked the slot for as long as its slowest frame.)
+		// Batch-granular search, measured on MI355X: frames whose mask window fits the LDS (<= 1080p) -- depth 1:
+		// k_lsd with helper workgroups, depth 2: k_lsd, depth >= 3: k_lsd_tile with 512-thread workgroups; larger frames:
+		// k_lsd_tile always.
 		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
 		if (p->svc) {
 			// no occupancy policy: the service's resident waves (one per SIMD, most of a CU's LDS) are what caps the streaming
-			// pass at three workgroups per CU
+			// pass at three workgroups per CU; the streaming waves go first on their SIMD
+			p->batch[i]->tune.map_prio = (opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u;
 		} else if (depth >= 3) {
-			p->tuning = pipeline_tuning(p->batch[i]->g);
+			if (opt.occupancy_policy != 2u) p->tuning = pipeline_tuning(p->batch[i]->g);
 			p->batch[i]->tune = p->tuning;
-			static const bool adapt_off = [] { const char *e = getenv("SMH_PIPE_ADAPT"); return e && atoi(e) == 0; }();   // diagnostic
-			if (!adapt_off && !stream_cus) {
+			if (opt.late_helpers == 1u) p->batch[i]->lsd_late_kc = 20u;           // every frame asks at once
+			if (opt.occupancy_policy == 0u) {
 				p->adapt = true;
 				hipError_t e2 = hipSuccess;
 				for (int k = 0; k < 3 && e2 == hipSuccess; ++k) e2 = hipEventCreate(&p->batch[i]->ev_probe[k]);
@@ -1046,14 +1000,11 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 }
 
 extern "C" SMHV_API int smhv_pipeline_create(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, smhv_pipeline **out) {
-	// default partition: measured best on MI355X; SMHV_PIPELINE_STREAM_CUS overrides (0 = no partition)
-	uint32_t cus = SMH_PIPELINE_STREAM_CUS_DEFAULT;
-	if (const char *e = getenv("SMHV_PIPELINE_STREAM_CUS")) cus = (uint32_t)atoi(e);
-	return pipeline_create_impl(c, W, H, max_frames, depth, cus > 31 ? 0 : cus, out);
+	return pipeline_create_impl(c, W, H, max_frames, depth, nullptr, out);
 }
 
-extern "C" SMHV_API int smhv_pipeline_create_partitioned(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, uint32_t stream_cus_of_32, smhv_pipeline **out) {
-	return pipeline_create_impl(c, W, H, max_frames, depth, stream_cus_of_32, out);
+extern "C" SMHV_API int smhv_pipeline_create_ex(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, const smhv_pipeline_options *opt, smhv_pipeline **out) {
+	return pipeline_create_impl(c, W, H, max_frames, depth, opt, out);
 }
 
 // ---- the host side of the frame-granular search service --------------------------------------------------------------
@@ -1068,10 +1019,8 @@ static int svc_launch(smhv_pipeline *p, uint32_t slot) {
 	sp.tile_cap = p->svc_tile_cap; sp.list_cap = p->svc_list_cap; sp.part_words = p->svc_part_words; sp.ring_log2 = p->svc_ring_log2;
 	sp.epoch = ++p->svc_epoch;
 	if (sp.epoch == 0u) sp.epoch = ++p->svc_epoch;
-	static const int idle_env = [] { const char *e = getenv("SMH_SVC_IDLE_US"); return e ? atoi(e) : 0; }();   // diagnostic
-	sp.idle_short = idle_env > 0 ? (uint32_t)idle_env * 2u : 100u;      // x 1024 cycles: ~45 us without work and nothing outstanding
-	static const int flags_env = [] { const char *e = getenv("SMH_SVC_FLAGS"); return e ? atoi(e) : 0; }();   // experiments only
-	sp.flags = (uint32_t)flags_env;
+	sp.idle_short = p->opt.idle_close_us ? p->opt.idle_close_us * 2u : 100u;   // x 1024 cycles: ~45 us without work and nothing outstanding
+	sp.flags = (p->opt.flags & SMHV_PIPE_NO_TEAM_HELP) ? 8u : 0u;
 	sp.idle_long = 50000u;                                               // ~20 ms without work, nobody at work: the streaming side is stuck
 	__atomic_fetch_or(&p->h_svc->state, (unsigned long long)sp.epoch, __ATOMIC_ACQ_REL);   // (the low half is 0: only then is this called)
 	hipError_t e = hipStreamWaitEvent(p->s_search, p->ev_pub[slot], 0);
@@ -1202,16 +1151,13 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 		// ... and a search-bound pipeline lets the workgroups of k_lsd_tile that have finished their frame help the ones still at
 		// work after SMH_LATE_KC_SEARCH_BOUND thousand cycles (sample screenshots, batch 128: 96 -> 106 k frames/s at depth 4,
 		// 127 -> 138 k at depth 8; the synthetic pipeline, ratio 1.3, loses 3 % with them and keeps them off)
-		bb->lsd_late_kc = p->tune_on ? 0u : SMH_LATE_KC_SEARCH_BOUND;
+		bb->lsd_late_kc = p->opt.late_helpers == 2u ? 0u : (p->opt.late_helpers == 1u ? 20u : (p->tune_on ? 0u : SMH_LATE_KC_SEARCH_BOUND));
 		// a sample every fourth round of the slots is plenty for a running average, and the three timed events sit in the batch's
 		// chain on its hardware queue (the hand-over before the search: 33 us with them, 14 without)
 		bb->probe = (p->submitted / p->depth) % 4u == 0u;
 	}
 	hipStream_t st, sl;
-	if (p->stream_cus) {
-		st = p->s_stream; sl = p->s_lsd[p->submitted & 1u];
-		// (the wait above also orders the streaming stream behind the slot's previous record kernel: its event has completed)
-	} else {
+	{
 		st = sl = p->stream[slot];
 		bool idle = true;
 		for (uint32_t i = 0; i < p->depth && idle; ++i) idle = hipEventQuery(p->done[i]) == hipSuccess;
@@ -1236,8 +1182,7 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 	// one batch in flight: nothing else can use the CUs of the frames that finish early, so they help the heavy frames (the
 	// helper scheme belongs to the workgroup-synchronous k_lsd and to frames whose mask window fits the LDS: <= 1080p;
 	// larger frames are better off on the tile kernel)
-	static const bool d1_tile = [] { const char *e = getenv("SMH_LSD_D1"); return e && strcmp(e, "tile") == 0; }();
-	if (p->depth == 1 && lsd_rows_only(p->batch[slot]->g) && !d1_tile) stages |= SMHV_STAGE_LSD_HELPERS;
+	if (p->depth == 1 && lsd_rows_only(p->batch[slot]->g)) stages |= SMHV_STAGE_LSD_HELPERS;
 	int rc = batch_run_impl(p->batch[slot], d_frames, n, stages, grayscale, max_gap, anchors, st, sl);
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(p->done[slot], sl));
@@ -1327,7 +1272,7 @@ extern "C" SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv
 		return SMHV_OK;
 	}
 	// the stream on which the slot's most recent record kernel runs (what a consumer has to order itself after)
-	if (stream) *stream = (void *)(p->last_sl[slot] ? p->last_sl[slot] : (p->stream_cus ? p->s_lsd[0] : p->stream[slot]));
+	if (stream) *stream = (void *)(p->last_sl[slot] ? p->last_sl[slot] : p->stream[slot]);
 	return SMHV_OK;
 }
 

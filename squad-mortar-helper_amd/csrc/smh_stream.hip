@@ -459,33 +459,14 @@ typedef const __attribute__((address_space(4))) MapKernelArgs *MapKernelArgsPtr;
 #else
 typedef const MapKernelArgs *MapKernelArgsPtr;                                     // (host pass: the body is only parsed)
 #endif
-// LEAN (round 3): the form deep pipelines launch.  Groups of GR = 2 rows, two register sets of compiler-tracked loads (4 KB in
-// flight per wave instead of 8, 16 registers instead of 48), and a workgroup of SEVERAL bands side by side: band0 + (thread /
-// m_block), so that twelve waves arrive on a CU together -- the three 4-wave workgroups' worth that reach the kernel's full
-// rate, in less than half the register file, as ONE workgroup whose LDS reservation keeps a second one off the CU and leaves
-// the other half to a line-search workgroup.  Everything that decides an output byte is shared with
-// the other form (same lambdas, same masks).
-// A barrier among the nw waves of ONE band of a lean workgroup (the bands of a workgroup run independently of each other: were
-// they to march in step, their prologues and mask epilogues would coincide and leave the CU's memory pipe idle -- measured
-// with a workgroup-wide barrier: 0.52 ms per pass against 0.38 for three independent 4-wave workgroups).  cnt: an LDS word of
-// the band, gen: this wave's count of barriers passed.
-__device__ __forceinline__ void band_barrier(uint32_t *cnt, uint32_t nw, uint32_t &gen) {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	++gen;
-	if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-	while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen * nw) __builtin_amdgcn_s_sleep(1);
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <bool GRAY, int GR, bool LEAN>
-__device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f, uint32_t band0, uint32_t *bar_cnt = nullptr, uint32_t *bar_gen = nullptr) {
+template <bool GRAY>
+__device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f, uint32_t band0) {
+	constexpr int GR = 4;                                       // rows per group (the hand-placed waits count four loads per set)
 	const Geom g = ka->g;
 	const Buffers b = ka->b;
 	const uint32_t flags = ka->flags, qflags = ka->qflags, RB = ka->RB, fixed_start_y = ka->fixed_start_y;
 	const int use_anchor_start = ka->use_anchor_start;
 	if (!b.aux[f].open) return;
-	// LEAN workgroups hold blockDim.x / m_block bands side by side, each walking its own sequence of items
-	const uint32_t sub = LEAN ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / g.m_block)) : 0u;   // (m_block is a multiple of 64: uniform in a wave)
 	const uint32_t band = band0;
 	constexpr bool live = true;
 	uint32_t start_y = fixed_start_y;
@@ -497,8 +478,8 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 		if (an.n == 0 || start_y > g.qh) do_scales = false;
 	}
 	const bool do_ocr = (qflags & BRQ_OCR) != 0;
-	const uint32_t q = LEAN ? threadIdx.x - sub * g.m_block : threadIdx.x, lane = q & 63u, wave = q >> 6;   // quad, lane and wave WITHIN the band
-	const uint32_t nwave = (LEAN ? g.m_block : blockDim.x) >> 6, gwave = threadIdx.x >> 6;                  // waves of a band; wave within the workgroup
+	const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6;   // quad, lane and wave within the band
+	const uint32_t nwave = blockDim.x >> 6, gwave = wave;
 	const int r0 = live ? (int)(band * RB) : 0;
 	const int r1 = live ? min(r0 + (int)RB, (int)g.rh) : 0;
 	const bool qact = q < g.m_quads && live;
@@ -533,18 +514,11 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	const size_t row_bytes = (size_t)g.W * 4;
 
 	uint64_t P[4] = {0, 0, 0, 0}, Wb[4] = {0, 0, 0, 0}, Eb[4] = {0, 0, 0, 0};
-	// LEAN: the white / edge column masks of the quadrant stages live in LDS, eight 64-bit words per thread (the workgroup's
-	// reservation is there anyway): 16 registers less, touched only where the quadrant has bright text pixels
 	extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-	unsigned long long *we = (unsigned long long *)(s_dyn + (blockDim.x >> 6) * 160u) + threadIdx.x;   // word (k, thread) at we[k * blockDim.x]
-	if constexpr (LEAN) {
-#pragma unroll
-		for (int k = 0; k < 8; ++k) we[k * blockDim.x] = 0ull;
-	}
-	auto or_w = [&](int c, uint64_t v) { if constexpr (LEAN) { if (v) atomicOr(&we[c * blockDim.x], (unsigned long long)v); } else Wb[c] |= v; };
-	auto or_e = [&](int c, uint64_t v) { if constexpr (LEAN) { if (v) atomicOr(&we[(4 + c) * blockDim.x], (unsigned long long)v); } else Eb[c] |= v; };
-	auto get_w = [&](int c) -> uint64_t { if constexpr (LEAN) return we[c * blockDim.x]; else return Wb[c]; };
-	auto get_e = [&](int c) -> uint64_t { if constexpr (LEAN) return we[(4 + c) * blockDim.x]; else return Eb[c]; };
+	auto or_w = [&](int c, uint64_t v) { Wb[c] |= v; };
+	auto or_e = [&](int c, uint64_t v) { Eb[c] |= v; };
+	auto get_w = [&](int c) -> uint64_t { return Wb[c]; };
+	auto get_e = [&](int c) -> uint64_t { return Eb[c]; };
 	// rows walked by the streaming loop: r0-1 .. r1, as in k_map_pass (the marker dilation's halo)
 	const int rs = max(r0 - 1, 0), re = min(r1, (int)g.rh - 1);
 	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
@@ -697,7 +671,7 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	// loads of rows beyond the band's last go, all lanes, to one 16-byte location that is always in the L2 (the frame's aux
 	// record) instead of re-reading pixel rows, which by then have been evicted by the pass's own stores (measured: 13 % more
 	// bytes fetched).  Their data is never looked at.
-	if constexpr (!LEAN) {
+	{
 		const uint8_t *dummy = (const uint8_t *)&b.aux[f];
 		auto load4 = [&](u32x4 (&dst)[GR], int r) {
 #pragma unroll
@@ -707,7 +681,6 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 				SMH_LD128(dst[k], inside ? loff : 0u, rowp);
 			}
 		};
-		static_assert(LEAN || GR == 4, "the hand-placed waits count four loads per set");
 		u32x4 S0[GR], S1[GR], S2[GR];
 		load4(S0, rs);
 		load4(S1, rs + 4);
@@ -728,24 +701,6 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 		// the clamped loads of the sets nobody consumed are still in flight: their registers must not be reused before they land
 		asm volatile("s_waitcnt vmcnt(0) ; smh-drain" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(S1[0]), "+v"(S1[1]), "+v"(S1[2]), "+v"(S1[3]),
 		             "+v"(S2[0]), "+v"(S2[1]), "+v"(S2[2]), "+v"(S2[3]) : : "memory");
-	} else if (live) {
-		// LEAN: two sets of GR rows, ordinary loads (the compiler places the waits: with two sets there is exactly one set
-		// in flight behind the one being processed, which is what its conservative count gives anyway); rows beyond the band's
-		// last are clamped onto it (an L2 hit) and never looked at.  Inactive lanes re-read quad 0 of the row.
-		const uint8_t *lbase = fbase + loff;
-		auto loadg = [&](u32x4 (&dst)[GR], int r) {
-#pragma unroll
-			for (int k = 0; k < GR; ++k) dst[k] = *(const u32x4 *)(lbase + (size_t)min(r + k, re) * row_bytes);
-		};
-		u32x4 A[GR], B2[GR];
-		loadg(A, rs);
-		for (int r = rs; r <= re; r += 2 * GR) {
-			loadg(B2, r + GR);
-			group(A, r);
-			if (r + GR > re) break;
-			loadg(A, r + 2 * GR);
-			group(B2, r + GR);
-		}
 	}
 
 	// ---- lane / wave neighbours of the column masks: marker dilation (P) and the 7-row-dilated white masks (V) ----
@@ -759,7 +714,7 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	// (gwave: the wave's place in the workgroup; a band's waves are consecutive, `wave` counts within the band)
 	if (lane == 0) { s_edge_first[gwave] = P[0]; s_first[gwave][0] = V[0]; s_first[gwave][1] = V[1]; s_first[gwave][2] = V[2]; s_first[gwave][3] = V[3]; }
 	if (lane == 63) { s_edge_last[gwave] = P[3]; s_last[gwave][0] = V[0]; s_last[gwave][1] = V[1]; s_last[gwave][2] = V[2]; s_last[gwave][3] = V[3]; }
-	if constexpr (LEAN) band_barrier(bar_cnt, nwave, *bar_gen); else __syncthreads();
+	__syncthreads();
 	if (do_mask) {
 		uint64_t left = __shfl_up(P[3], 1), right = __shfl_down(P[0], 1);
 		if (lane == 0) left = wave > 0 ? s_edge_last[gwave - 1] : 0ull;
@@ -857,37 +812,15 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 #endif
 	static_assert(sizeof(MapKernelArgs) == sizeof(Geom) + sizeof(Buffers) + 7 * 4 + 4 || sizeof(MapKernelArgs) == sizeof(Geom) + sizeof(Buffers) + 7 * 4, "the kernel's parameter list");
 	MapKernelArgsPtr ka = (MapKernelArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+	if (flags & MAP_PRIO) __builtin_amdgcn_s_setprio(3);        // ahead of the search service's waves on the same SIMD (which have slack)
 	if (LOOP) {
 		for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
 			const uint32_t f = item / nbands, band = item - f * nbands;
-			map_brq_item<GRAY, 4, false>(ka, f, band);
+			map_brq_item<GRAY>(ka, f, band);
 			__syncthreads();                                   // the next item reuses the LDS exchange arrays
 		}
 	} else {
-		map_brq_item<GRAY, 4, false>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
-	}
-}
-
-// The lean form (map_brq_item<.., 2, true>): a workgroup = nsub bands of one frame side by side (blockDim.x = nsub * m_block,
-// twelve waves at 1080p and 1440p), a capped grid walking the (frame, band group) items with a grid stride.
-#ifndef SMH_MAP_LEAN_WAVES_PER_EU
-#define SMH_MAP_LEAN_WAVES_PER_EU 6     // <= 80 VGPRs: three waves per SIMD in 240 registers, beside a line-search workgroup's 2 x 128 (or 2 x 136)
-#endif
-template <bool GRAY>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(SMH_MAP_LEAN_WAVES_PER_EU, SMH_MAP_LEAN_WAVES_PER_EU)))
-k_map_brq_lean(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start, uint32_t nbands, uint32_t items, uint32_t nsub) {
-	MapKernelArgsPtr ka = (MapKernelArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-	__shared__ uint32_t s_bar[4];
-	if (threadIdx.x < 4u) s_bar[threadIdx.x] = 0u;
-	__syncthreads();                                           // (the only workgroup-wide barrier: from here on every band is on its own)
-	const uint32_t sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / g.m_block));
-	uint32_t gen = 0;
-	// the bands start a third of an item apart, so that their prologues and epilogues never coincide
-	for (uint32_t k = 0; k < sub * 6u; ++k) __builtin_amdgcn_s_sleep(127);
-	for (uint32_t item = blockIdx.x * nsub + sub; item < items; item += gridDim.x * nsub) {
-		const uint32_t f = item / nbands, band = item - f * nbands;
-		map_brq_item<GRAY, 2, true>(ka, f, band, &s_bar[sub], &gen);
-		band_barrier(&s_bar[sub], g.m_block >> 6, gen);        // the next item reuses the band's LDS exchange arrays
+		map_brq_item<GRAY>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
 	}
 }
 
@@ -919,39 +852,24 @@ uint32_t map_brq_lds_bytes(const Geom &g) { return map_brq_static_lds() + (g.m_b
 hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
                                const LaunchTuning *tune) {
 	uint32_t RB = MAPQ_RB_MAX;
-	static const int rb_env = [] { const char *e = getenv("SMH_MAP_RB"); return e ? atoi(e) : 0; }();   // diagnostic: band height
-	if (rb_env >= 8 && rb_env <= (int)MAPQ_RB_MAX) RB = (uint32_t)rb_env;
 	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
 	const uint32_t nbands = (g.rh + RB - 1) / RB, items = nbands * n;
-	// diagnostics (override the caller's policy): SMH_MAP_LDS_PAD=<bytes> enlarges the LDS request (fewer streaming workgroups
-	// per CU); SMH_MAP_GRID=<workgroups> caps the grid
-	static const int lds_pad = [] { const char *e = getenv("SMH_MAP_LDS_PAD"); return e ? atoi(e) : -1; }();
-	static const int grid_env = [] { const char *e = getenv("SMH_MAP_GRID"); return e ? atoi(e) : -1; }();
 	unsigned lds = (g.m_block / 64u) * 640u;                 // 64 x (pixel, verdict, id) per wave
-	if (lds_pad >= 0) lds += (unsigned)lds_pad;
-	else if (tune && tune->map_lds_total > map_brq_lds_bytes(g)) lds = tune->map_lds_total - map_brq_static_lds();
+	if (tune && tune->map_lds_total > map_brq_lds_bytes(g)) lds = tune->map_lds_total - map_brq_static_lds();
 	if (lds > 65536u) {                                      // more than 64 KB of dynamic LDS has to be allowed per function (and per device)
 		static std::atomic<uint64_t> attr_devices{0};
 		int dev = 0;
 		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess) return e;
 		if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
-			const void *fns[] = {(const void *)k_map_brq_pass<true, true>, (const void *)k_map_brq_pass<false, true>, (const void *)k_map_brq_pass<true, false>, (const void *)k_map_brq_pass<false, false>,
-			                     (const void *)k_map_brq_lean<true>, (const void *)k_map_brq_lean<false>};
+			const void *fns[] = {(const void *)k_map_brq_pass<true, true>, (const void *)k_map_brq_pass<false, true>, (const void *)k_map_brq_pass<true, false>, (const void *)k_map_brq_pass<false, false>};
 			for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 			if (e != hipSuccess) return e;
 			if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 		}
 	}
-	const uint32_t cap = grid_env >= 0 ? (uint32_t)grid_env : (tune ? tune->map_grid_cap : 0u);
-	if (tune && tune->map_lean_sub) {                          // the lean form: nsub bands per workgroup
-		const uint32_t nsub = tune->map_lean_sub, wgs = (items + nsub - 1u) / nsub, litems = items;
-		const dim3 grid(cap ? std::min(cap, wgs) : wgs), block(nsub * g.m_block);
-		const unsigned llds = std::max<unsigned>(lds, nsub * (g.m_block / 64u) * 640u + nsub * g.m_block * 64u);   // (the reservation, or at least:) hit lists + the quadrant masks (64 B per thread)
-		if (grayscale) hipLaunchKernelGGL(k_map_brq_lean<true>, grid, block, llds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, litems, nsub);
-		else hipLaunchKernelGGL(k_map_brq_lean<false>, grid, block, llds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, litems, nsub);
-		return hipGetLastError();
-	}
+	if (tune && tune->map_prio) flags |= MAP_PRIO;
+	const uint32_t cap = tune ? tune->map_grid_cap : 0u;
 	if (cap && cap < items) {
 		if (grayscale) hipLaunchKernelGGL((k_map_brq_pass<true, true>), dim3(cap), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
 		else hipLaunchKernelGGL((k_map_brq_pass<false, true>), dim3(cap), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);

@@ -264,7 +264,7 @@ def test_both_line_segment_kernels_agree_with_the_oracle(vision):
             # pipeline is created)
             for cap in (0, 48, 4):
                 lib.smhv_debug_lsd_tile_cap(cap)
-                pipe = smh.Pipeline(vision, W, H, n, 3)
+                pipe = smh.Pipeline(vision, W, H, n, 3, search="frame")
                 lib.smhv_debug_lsd_tile_cap(0)
                 for exact in (0, smh.STAGE_EXACT_STATS, 0):
                     slots = [pipe.submit(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=max_gap) for _ in range(4)]
@@ -404,10 +404,10 @@ def test_fused_streaming_pass_on_threshold_frames(vision):
 
 
 def test_pipeline_object_gives_the_records_of_plain_runs(vision):
-    """smhv_pipeline_*: depth 1..4, with and without the CU partition (streaming kernels on their own CUs, the line-segment
-    search on the rest), with idle streams the host created beforehand; every submission's records
-    equal those of a plain smhv_batch_run of the same frames, the slot hand-back is round robin, submit never loses a
-    batch when more than `depth` are pushed back to back."""
+    """smhv_pipeline_*: depth 1..4 with the batch-granular search, depth 3 / 4 / 8 with the frame-granular search service
+    (with and without the workgroup help desk, with one and three streaming streams), with idle streams the host created
+    beforehand; every submission's records equal those of a plain smhv_batch_run of the same frames, the slot hand-back is
+    round robin, submit never loses a batch when more than `depth` are pushed back to back."""
     import torch
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import synth
@@ -424,8 +424,9 @@ def test_pipeline_object_gives_the_records_of_plain_runs(vision):
     fb.close()
     assert len(set(want)) == 3
     idle = [torch.cuda.Stream() for _ in range(3)]                  # streams created before the pipeline: must not matter
-    for depth, cus in ((1, None), (2, None), (3, 0), (4, None), (2, 8), (3, 12), (4, 10), (1, 8)):
-        pipe = smh.Pipeline(vision, W, H, N, depth, stream_cus=cus)
+    for depth, cus in ((1, {}), (2, {}), (3, {}), (4, {}), (3, dict(search="frame")), (4, dict(search="frame", flags=smh._lib.PIPE_NO_TEAM_HELP)),
+                       (8, {}), (8, dict(streams=3, flags=smh._lib.PIPE_NO_PROLOGUE)), (5, dict(search="frame", streams=1, idle_close_us=2000))):
+        pipe = smh.Pipeline(vision, W, H, N, depth, **cus)
         order = [0, 1, 2, 2, 1, 0, 1, 1, 0, 2, 0, 1]
         slots = []
         for j, k in enumerate(order):
@@ -461,10 +462,12 @@ def _oracle_batch(frames, infos, stages=0xF):
 @pytest.mark.parametrize("W,H,N", [(1920, 1080, 256), (2560, 1440, 128)])
 def test_headline_configuration_pipelined_depth4(vision, W, H, N):
     """The EXACT configuration bench.py's `value` is measured on (BASELINE configs[2] / configs[3]): N resident frames,
-    smhv_pipeline with four batches in flight (k_lsd_tile, 512-thread workgroups, two per CU), twelve submissions back to
-    back.  Every slot's N records must equal, byte for byte, a plain smhv_batch_run of the same frames (k_lsd_tile with
-    1024-thread workgroups, nothing beside it), the depth-1 pipeline (k_lsd with helper workgroups at 1080p) must give them
-    too, and eight frames spread over the batch are checked against the oracle field by field."""
+    smhv_pipeline with twelve batches in flight (the frame-granular search service: one wave per frame, help desk), thirty
+    submissions back to back -- and the configuration it was measured on until round 3: four batches in flight, batch-granular
+    search (k_lsd_tile, 512-thread workgroups, occupancy policy), twelve submissions.  Every slot's N records must equal, byte
+    for byte, a plain smhv_batch_run of the same frames (k_lsd_tile with 1024-thread workgroups, nothing beside it), the
+    depth-1 pipeline (k_lsd with helper workgroups at 1080p) must give them too, and eight frames spread over the batch are
+    checked against the oracle field by field."""
     import torch
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import synth
@@ -477,13 +480,18 @@ def test_headline_configuration_pipelined_depth4(vision, W, H, N):
     want = bytes(want_raw)
     recs = smh.results_to_dicts(want_raw)
     fb.close()
-    pipe = smh.Pipeline(vision, W, H, N, 4)
-    for j in range(12):
-        assert pipe.submit(d.data_ptr(), N, anchors=anchors) == j % 4
-    pipe.wait()
-    for s_ in range(4):
-        assert bytes(pipe.slots[s_].read_results(0, N)) == want, "slot %d of the depth-4 pipeline differs from the plain run" % s_
-    pipe.close()
+    for depth, subs in ((12, 30), (4, 12)):
+        pipe = smh.Pipeline(vision, W, H, N, depth)
+        for j in range(subs):
+            assert pipe.submit(d.data_ptr(), N, anchors=anchors) == j % depth
+        pipe.wait()
+        for s_ in range(depth):
+            assert bytes(pipe.slots[s_].read_results(0, N)) == want, "slot %d of the depth-%d pipeline differs from the plain run" % (s_, depth)
+        st = pipe.search_stats()
+        assert (st is not None) == (depth >= 8)                     # which schedule the library picked
+        if st:
+            assert st["frames"] == subs * N and st["submissions"] == subs
+        pipe.close()
     pipe1 = smh.Pipeline(vision, W, H, N, 1)
     for _ in range(2):
         pipe1.submit(d.data_ptr(), N, anchors=anchors)
@@ -503,17 +511,17 @@ def test_headline_configuration_pipelined_depth4(vision, W, H, N):
 
 
 def test_pipeline_occupancy_policy_does_not_change_any_output(vision):
-    """A pipeline of depth >= 3 sets the occupancy of its own kernels (LDS reservation and capped, grid-stride grid of the
-    streaming pass; tile limit of the line search: DESIGN.md section 7).  None of that may change an output byte: records AND
-    images (ui_map, mask, ocr, scales) of a depth-4 pipeline equal a plain smhv_batch_run's -- on synthetic frames, and on
-    frames with MORE marker tiles than the policy's tile limit (dense scenes: those are searched on the mask in global
-    memory).  k_lsd_seq (one wave per frame) through a pipeline gives the same records too."""
-    import subprocess
-    import sys
+    """Whatever schedule a pipeline runs -- batch-granular search with the occupancy policy of depth >= 3 (LDS reservation and
+    capped, grid-stride grid of the streaming pass; tile limit of the line search) on, off or adaptive, late helpers always /
+    never, the frame-granular search service with and without its help desk, wave priority and prologue stream -- no output
+    byte may change: records AND images (ui_map, mask, ocr, scales) equal a plain smhv_batch_run's, on synthetic frames and on
+    frames with MORE marker tiles than the pipelines' tile limit (dense scenes: those are searched on the mask in global
+    memory)."""
     import torch
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import synth
     from fuzz_scenes import scene
+    L = smh._lib
     W, H, N = 1920, 1080, 40
     frames, infos = synth.make_batch(W, H, N, first_idx=2100, n_lines=3)
     rng = np.random.default_rng(77)
@@ -524,50 +532,22 @@ def test_pipeline_occupancy_policy_does_not_change_any_output(vision):
     fb = smh.FrameBatch(vision, W, H, N)
     fb.run(d.data_ptr(), N, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
     want = bytes(fb.read_results(0, N))
-    which = (smh._lib.IMAGE_UI_MAP, smh._lib.VIEW_LSD_INPUT, smh._lib.VIEW_OCR_INPUT, smh._lib.VIEW_FIND_SCALES_INPUT)
+    which = (L.IMAGE_UI_MAP, L.VIEW_LSD_INPUT, L.VIEW_OCR_INPUT, L.VIEW_FIND_SCALES_INPUT)
     pick = (0, 5, 17, N - 1)
     imgs = {(w, f): fb.read_image(w, f).copy() for w in which for f in pick}
     fb.close()
-    pipe = smh.Pipeline(vision, W, H, N, 4)
-    for j in range(6):
-        slot = pipe.submit(d.data_ptr(), N, anchors=anchors)
-    pipe.wait()
-    for s_ in range(4):
-        assert bytes(pipe.slots[s_].read_results(0, N)) == want, s_
-    for (w, f), img in imgs.items():
-        assert np.array_equal(pipe.slots[slot].read_image(w, f), img), (w, f)
-    pipe.close()
-    lib = smh._lib.load()
-    lib.smhv_debug_lsd_threads(64)
-    try:
-        pipe = smh.Pipeline(vision, W, H, N, 3)
-        for j in range(4):
-            pipe.submit(d.data_ptr(), N, anchors=anchors)
+    for depth, opts in ((4, {}), (4, dict(occupancy_policy=1)), (4, dict(occupancy_policy=2)), (4, dict(occupancy_policy=1, late_helpers=1)), (3, dict(late_helpers=2)),
+                        (8, {}), (4, dict(search="frame")), (8, dict(flags=L.PIPE_NO_TEAM_HELP)), (8, dict(flags=L.PIPE_NO_STREAM_PRIORITY | L.PIPE_NO_PROLOGUE, streams=3)),
+                        (16, dict(idle_close_us=500))):
+        pipe = smh.Pipeline(vision, W, H, N, depth, **opts)
+        for j in range(depth + 2):
+            slot = pipe.submit(d.data_ptr(), N, anchors=anchors)
         pipe.wait()
-        for s_ in range(3):
-            assert bytes(pipe.slots[s_].read_results(0, N)) == want, ("k_lsd_seq", s_)
+        for s_ in range(depth):
+            assert bytes(pipe.slots[s_].read_results(0, N)) == want, (depth, opts, s_)
+        for (w, f), img in imgs.items():
+            assert np.array_equal(pipe.slots[slot].read_image(w, f), img), (depth, opts, w, f)
         pipe.close()
-    finally:
-        lib.smhv_debug_lsd_threads(0)
-    # the policy switched off (its own process: the switch is read once) gives the same records
-    code = ("import sys; sys.path.insert(0, %r); import numpy as np, torch, squad_mortar_helper_amd as smh\n"
-            "from squad_mortar_helper_amd import synth\n"
-            "fr, inf = synth.make_batch(1920, 1080, 12, first_idx=2100, n_lines=3)\n"
-            "a = smh.make_anchors([(i['scales_start_y'], i['anchors']) for i in inf]); d = torch.from_numpy(fr).cuda(); v = smh.HipVision.init(0)\n"
-            "p = smh.Pipeline(v, 1920, 1080, 12, 4); [p.submit(d.data_ptr(), 12, anchors=a) for _ in range(5)]; p.wait()\n"
-            "import hashlib; print('SHA', hashlib.sha256(bytes(p.slots[0].read_results(0, 12))).hexdigest())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # ... and so does the opt-in lean form of the streaming pass (SMH_PIPE_LEAN=1: twelve 80-register waves per workgroup,
-    # three bands walking their own items, per-band LDS barriers, the quadrant masks in LDS)
-    shas = []
-    # ... and helper workgroups of the line search (SMH_LSD_FARM=50: one extra workgroup for each of the heavier half of the
-    # frames, casting whole candidates the owner posts through global memory)
-    # ... and workgroups that have finished their frame helping one that is still at work (SMH_LSD_LATE=<thousands of cycles>: 20 =
-    # every frame asks for help at once)
-    for env in (dict(SMH_PIPE_TUNING="1"), dict(SMH_PIPE_TUNING="0"), dict(SMH_PIPE_LEAN="1"), dict(SMH_LSD_FARM="50"), dict(SMH_LSD_LATE="20")):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
-        shas.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][-1])
-    assert len(set(shas)) == 1, shas
 
 
 def test_line_search_watchdog_becomes_an_error(vision):
@@ -606,8 +586,8 @@ def test_line_search_watchdog_becomes_an_error(vision):
                 assert recs[i].map_open == 1 and recs[i].n_mask_px == clean[i].n_mask_px and recs[i].mpx == clean[i].mpx
             else:
                 assert dd[i]["error"] is None and bytes(recs[i]) == bytes(clean[i])
-        # the pipeline reports it from wait()
-        pipe = smh.Pipeline(vision, W, H, N, 3)
+        # the pipeline reports it from wait() (the watchdog belongs to k_lsd_tile: the batch-granular search)
+        pipe = smh.Pipeline(vision, W, H, N, 3, search="batch")
         slot = pipe.submit(d.data_ptr(), N, anchors=anchors)
         with pytest.raises(smh.VisionError) as ei:
             pipe.wait(slot)

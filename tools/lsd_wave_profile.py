@@ -12,6 +12,7 @@ _, infos = synth.make_batch(W, H, N, out=host.numpy())
 d = host.cuda()
 v = smh.HipVision.init(0)
 smh._lib.load().smhv_debug_lsd_classic(0)
+smh._lib.load().smhv_debug_lsd_threads(int(os.environ.get('WPROF_THREADS', '1024')))   # (the library reads no environment: this tool's own knob)
 fb = smh.FrameBatch(v, W, H, N)
 fb.enable_timing(True)
 if COPY:
@@ -46,7 +47,7 @@ print("a local candidate's life: dispatch -> set up %.3g cycles, set up -> last 
 Y = np.array([[raw[i].angle[20 + k] for k in range(4)] for i in range(N)], dtype=np.float64)
 print("idle polls that found nothing to retire and nothing to dispatch: %.0f per frame -- speculation width full %.0f%%, no free window %.0f%%, list exhausted %.0f%%" % (
     Y[:, 3].mean(), 100 * Y[:, 0].sum() / max(Y[:, 3].sum(), 1), 100 * Y[:, 1].sum() / max(Y[:, 3].sum(), 1), 100 * Y[:, 2].sum() / max(Y[:, 3].sum(), 1)))
-NWV = int(os.environ.get('SMH_W_BS', '1024')) // 64
+NWV = int(os.environ.get('WPROF_THREADS', '1024')) // 64
 ft = P[:, 7] / NWV
 print("frame cycles (wave total / waves): mean %.3g median %.3g max %.3g (max/mean %.2f)" % (ft.mean(), np.median(ft), ft.max(), ft.max() / ft.mean()))
 mpx = np.array([raw[i].n_mask_px for i in range(N)])

@@ -24,7 +24,7 @@ names = ["claim", "unit", "finish", "lock-wait", "control", "setup", "idle", "to
 P = np.array([[raw[i].meters[20 + k] for k in range(8)] for i in range(N)])
 D = np.array([[raw[i].meters[28 + k] for k in range(4)] for i in range(N)])
 U = np.array([[raw[i].angle[16 + k] for k in range(4)] for i in range(N)], dtype=np.float64)
-NWV = int(os.environ.get('SMH_W_BS', '1024')) // 64
+NWV = int(os.environ.get('WPROF_THREADS', '1024')) // 64
 for i in np.argsort(-P[:, 7]):
     if raw[i].rounds == 0: continue
     print("farm on %d remote %3d | " % (raw[i].length_px[26], raw[i].length_px[27]), end="")

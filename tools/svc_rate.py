@@ -29,7 +29,12 @@ fb = smh.FrameBatch(vision, W, H, N)
 fb.run(d.data_ptr(), N, stages=stages, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
 want = bytes(fb.read_results(0, N))
 fb.close()
-pipe = smh.Pipeline(vision, W, H, N, depth)
+# experiment knobs (this tool's own; the library reads no environment): RATE_SEARCH=auto|batch|frame, RATE_STREAMS, RATE_IDLE_US,
+# RATE_WGS, RATE_FLAGS (1 no team help, 2 no streaming priority, 4 no prologue stream), RATE_POLICY, RATE_LATE
+_env = os.environ.get
+pipe = smh.Pipeline(vision, W, H, N, depth, search=_env("RATE_SEARCH", "auto"), streams=int(_env("RATE_STREAMS", "0")), idle_close_us=int(_env("RATE_IDLE_US", "0")),
+                    service_workgroups=int(_env("RATE_WGS", "0")), flags=int(_env("RATE_FLAGS", "0")), occupancy_policy=int(_env("RATE_POLICY", "0")),
+                    late_helpers=int(_env("RATE_LATE", "0")))
 
 
 def watchdog():
@@ -84,4 +89,4 @@ if os.environ.get("SVC_RATE_WPROF"):
     prof["rounds"] = float(np.mean([r.rounds for r in recs]))
 pipe.close()
 print(json.dumps({"frames_per_s": N * passes / dt, "ms_per_pass": dt / passes * 1e3, "N": N, "depth": depth, "stages": stages, "frame": [W, H],
-                  "slots_equal_plain_run": all(equal), "env": {k: v for k, v in os.environ.items() if k.startswith("SMH_")}, "search_service": st, "scan_profile_cycles_per_frame": prof, "stage_ms": stage_ms, "slow_submits": len(slow)}))
+                  "slots_equal_plain_run": all(equal), "env": {k: v for k, v in os.environ.items() if k.startswith(("SMH_", "RATE_"))}, "search_service": st, "scan_profile_cycles_per_frame": prof, "stage_ms": stage_ms, "slow_submits": len(slow)}))
