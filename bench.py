@@ -276,39 +276,45 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
 
 
 def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, H, n):
-    """PCIe-inclusive rate (never `value`): frames travel pinned host memory -> HBM through the ingest queue (async
-    copy, device CRC-32 duplicate test, slab append) and every full slab goes through the same pipeline; two queues
-    alternate so the uploads of one slab overlap the compute of the other.  The staging buffers are filled once; each
-    frame then gets a fresh counter in pixel (0,0) (outside every ROI) so that no CRC repeats."""
-    slots = 4
-    qs = [smh.IngestQueue(vision, W, H, slots=slots, capacity=n) for _ in range(2)]
-    for q in qs:                                               # prime the staging buffers (their content persists)
-        for i in range(slots):
-            q.acquire()[...] = src[i % len(src)]
-            q.commit()
-        q.batch()
-        q.reset()
-    slabs = max(2, (frames_total + n - 1) // n)
-    counter = 1
-    pending = [None, None]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in range(slabs):
-        q = qs[b % 2]
-        if pending[b % 2] is not None:
-            pipe.wait(pending[b % 2])                          # the previous run on this queue's slab has finished
-        q.reset()
-        for _ in range(n):
-            buf = q.acquire()
-            buf[0, 0, :] = (counter & 255, (counter >> 8) & 255, (counter >> 16) & 255, 255)
-            counter += 1
-            q.commit()
-        ptr, cnt, _ = q.batch()
-        assert cnt == n, "ingest dropped frames: %d of %d" % (cnt, n)
-        pending[b % 2] = pipe.submit(ptr, cnt, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
-    pipe.wait()
-    dt = time.perf_counter() - t0
-    frames = slabs * n
+    """PCIe-inclusive rate (never `value`): frames travel pinned host memory -> HBM through the ingest queue and every full
+    slab goes through the same pipeline; two queues alternate so the uploads of one slab overlap the compute of the other.
+    The staging buffers are filled once; each frame then gets a fresh counter in pixel (0,0) (outside every ROI) so that no
+    CRC repeats.  `frames_per_s`: region-of-interest upload (whole-frame CRC-32 on the host cores, one worker per staging
+    slot; only the map ROI's and the button's rows cross PCIe); `full_upload_frames_per_s`: the whole frame crosses and the
+    device computes the CRC (the mode a device-side producer or a decoded RGB image uses), on a quarter of the frames."""
+    def run(roi, slots, total):
+        qs = [smh.IngestQueue(vision, W, H, slots=slots, capacity=n, roi_upload=roi) for _ in range(2)]
+        for q in qs:                                           # prime the staging buffers (their content persists)
+            for i in range(slots):
+                q.acquire()[...] = src[i % len(src)]
+                q.commit()
+            q.batch()
+            q.reset()
+        slabs = max(2, (total + n - 1) // n)
+        counter = 1
+        pending = [None, None]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in range(slabs):
+            q = qs[b % 2]
+            if pending[b % 2] is not None:
+                pipe.wait(pending[b % 2])                      # the previous run on this queue's slab has finished
+            q.reset()
+            for _ in range(n):
+                buf = q.acquire()
+                buf[0, 0, :] = (counter & 255, (counter >> 8) & 255, (counter >> 16) & 255, 255)
+                counter += 1
+                q.commit()
+            ptr, cnt, _ = q.batch()
+            assert cnt == n, "ingest dropped frames: %d of %d" % (cnt, n)
+            pending[b % 2] = pipe.submit(ptr, cnt, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
+        pipe.wait()
+        dt = time.perf_counter() - t0
+        return qs, slabs * n, dt
+
+    cores = os.cpu_count() or 8
+    slots = max(4, min(16, cores // 2))
+    qs, frames, dt = run(True, slots, frames_total)
     q = qs[0]
     q.reset()
     k = min(64, n)
@@ -323,10 +329,18 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     _, dup = qs[0].counts()
     for q in qs:
         q.close()
-    return {"frames_per_s": frames / dt, "frames": frames, "h2d_GBps": frames * W * H * 4 / dt / 1e9,
+    qs, frames_full, dt_full = run(False, 4, max(2 * n, frames_total // 4))
+    for q in qs:
+        q.close()
+    (_, _, rw, rh), (_, _, bw, bh) = smh.map_bounds(W, H), smh.button_bounds(W, H)
+    return {"frames_per_s": frames / dt, "frames": frames, "mode": "roi_upload", "staging_slots": slots, "host_cores": cores,
+            "host_crc_GBps": frames * W * H * 4 / dt / 1e9, "uploaded_fraction": round((rw * rh + bw * bh) / float(W * H), 3),
+            "h2d_GBps": frames * (rw * rh + bw * bh) * 4 / dt / 1e9,
+            "full_upload_frames_per_s": frames_full / dt_full, "full_upload_h2d_GBps": frames_full * W * H * 4 / dt_full / 1e9,
             "push_frames_per_s": k / dt_push, "duplicates_dropped": dup,
-            "note": "PCIe-inclusive: pinned staging -> async H2D -> device CRC-32 dedupe (src/capture.rs:44-47) -> slab -> same "
-                    "pipeline, two slabs in flight; push_frames_per_s adds the host memcpy from pageable memory (one thread)"}
+            "note": "PCIe-inclusive: pinned staging -> whole-frame CRC-32 on the host workers (dedupe rule of src/capture.rs:44-47) -> "
+                    "packed ROI + button rows -> async H2D -> slab -> same pipeline, two slabs in flight; full_upload: whole frame H2D + "
+                    "device CRC-32; push_frames_per_s adds the host memcpy from pageable memory (one thread)"}
 
 
 def upload_synthetic(torch, synth, W, H, n, first, lines, distinct, device, keep_host):
@@ -831,6 +845,45 @@ def main():
                 del ca, cb
             except RuntimeError:
                 pass
+            # ... and a hand-written copy with the PASS'S OWN access pattern (smhv_debug_pattern_copy: every ROI quad loaded once
+            # out of the full-width frame rows, ui / mask / ocr / scales rows stored with the pass's widths and pitches, no
+            # arithmetic): what the memory system gives this pattern, alone and back to back on four streams like the pass
+            if (stages & 0xC) and (stages & 0x3):
+                lib = smh._lib.load()
+                pc = [smh.FrameBatch(vision, W, H, n) for _ in range(4)]
+                pst = [torch.cuda.Stream() for _ in pc]
+                pat_bytes = n * (2 * rw * rh * 4 + rw * rh + 2 * (rw // 2) * (rh // 2))       # algorithmic bytes of the copy (no halo rows)
+                try:
+                    for fbk, stk in zip(pc, pst):
+                        smh._lib.check(lib.smhv_debug_pattern_copy(fbk._b, fptr, n, stk.cuda_stream))
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    with torch.cuda.stream(pst[0]):
+                        e0.record()
+                        for _ in range(10):
+                            smh._lib.check(lib.smhv_debug_pattern_copy(pc[0]._b, fptr, n, pst[0].cuda_stream))
+                        e1.record()
+                    torch.cuda.synchronize()
+                    alone_ms = e0.elapsed_time(e1) / 10
+                    t0 = time.perf_counter()
+                    for _ in range(8):
+                        for fbk, stk in zip(pc, pst):
+                            smh._lib.check(lib.smhv_debug_pattern_copy(fbk._b, fptr, n, stk.cuda_stream))
+                    torch.cuda.synchronize()
+                    b2b = (time.perf_counter() - t0) * 1e3 / 32
+                    ri = out["roofline_isolated"]
+                    ri["pattern_copy_GBps"] = pat_bytes / (alone_ms * 1e-3) / 1e9
+                    ri["pattern_copy_ms"] = alone_ms
+                    ri["pattern_copy_back_to_back_GBps"] = pat_bytes / (b2b * 1e-3) / 1e9
+                    ri["pattern_copy_bytes"] = pat_bytes
+                    ri["frac_of_pattern_copy"] = (n * kernel_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9) / ri["pattern_copy_GBps"]
+                    if b2b_ms is not None:
+                        ri["back_to_back"]["frac_of_pattern_copy_back_to_back"] = (n * kernel_bytes / (b2b_ms * 1e-3) / 1e9) / ri["pattern_copy_back_to_back_GBps"]
+                    ri["pattern_copy_what"] = ("k_pattern_copy: one launch after the other on one stream (hipEvents) / four streams back to back (wall clock); "
+                                               "its bytes are the pass's algorithmic bytes (no halo rows)")
+                finally:
+                    for fbk in pc:
+                        fbk.close()
         out["stages_ms"] = stages_ms
         out["pipeline_algorithmic_GBps"] = value / world * full_bytes / 1e9
         out["pipeline_hbm_frac"] = value / world * full_bytes / 1e9 / HBM_PEAK_GBS

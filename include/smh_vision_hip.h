@@ -242,6 +242,11 @@ SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
 /* diagnostic (process-wide): threads per workgroup of every k_lsd_tile launch: 128..1024 (multiples of 64), 0 restores the
  * library's choice (1024 for a batch that runs alone, 512 inside pipelines). */
 SMHV_API int smhv_debug_lsd_threads(uint32_t threads);
+/* calibration: the fused streaming pass's memory traffic without its arithmetic -- every quad of the map ROI of n resident frames
+ * read once (16-byte loads out of the full-width frame rows), ui_map / mask / ocr / scales rows of the batch written with the
+ * pass's own store widths and pitches (their contents are garbage afterwards).  Asynchronous on `stream`.  Its rate is what the
+ * memory system gives this access pattern; bench.py reports it beside the pass (roofline_isolated.pattern_copy_GBps). */
+SMHV_API int smhv_debug_pattern_copy(smhv_batch *b, const void *d_frames, uint32_t n, void *stream);
 /* diagnostic (process-wide): batched runs launch everything but the line search, so that the streaming
  * pass can be timed back to back with itself (bench.py, roofline_isolated.back_to_back).  The records of such a run hold no
  * valid lines. */
@@ -285,6 +290,7 @@ SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t fram
 #define SMHV_PIPE_NO_TEAM_HELP 1u       /* flags, diagnostics (A/B): frame-granular search without waves helping the heavy frames of their workgroup */
 #define SMHV_PIPE_NO_STREAM_PRIORITY 2u /*   ... without wave priority for the streaming pass */
 #define SMHV_PIPE_NO_PROLOGUE 4u        /*   ... button test and anchor upload on the streaming streams instead of a stream of their own */
+#define SMHV_PIPE_NO_IN_PASS_PUBLISH 8u /*   ... the frames published by a kernel behind the streaming pass instead of by the pass itself */
 typedef struct {
 	uint32_t size;
 	uint32_t search;                    /* SMHV_SEARCH_* */
@@ -348,6 +354,13 @@ SMHV_API int smhv_debug_marker_table(smhv_ctx *ctx, uint32_t *bits);
  * smhv_batch_run (or smhv_load_frame_device) consumes.  One producer thread per queue. */
 typedef struct smhv_ingest smhv_ingest;
 SMHV_API int smhv_ingest_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t slots, uint32_t capacity, smhv_ingest **out);
+/* The same with flags.  SMHV_INGEST_ROI_UPLOAD: the CRC-32 of every committed frame is computed on the HOST (worker threads of the
+ * queue, carry-less-multiply folding: the whole frame, as the reference hashes it) and only what the pipeline reads -- the map
+ * ROI's rows and the button's rows, 39 % of a 1080p frame -- travels over PCIe, and nothing at all for a duplicate.  The slab
+ * frames then hold exactly those two rectangles (zero elsewhere), which is all smhv_batch_run / the pipelines read.  BGRA8
+ * commits only. */
+#define SMHV_INGEST_ROI_UPLOAD 1u
+SMHV_API int smhv_ingest_create_ex(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t slots, uint32_t capacity, uint32_t flags, smhv_ingest **out);
 SMHV_API void smhv_ingest_destroy(smhv_ingest *q);
 /* next pinned staging buffer (frame_w * frame_h * 4 bytes); blocks only when all `slots` uploads are in flight */
 SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra);
@@ -375,6 +388,8 @@ SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames, uint32_t *
  * with the last accepted frame; frames still queued are resolved into the new slab by the next acquire / batch */
 SMHV_API int smhv_ingest_reset(smhv_ingest *q);
 SMHV_API int smhv_ingest_counts(smhv_ingest *q, uint64_t *n_new, uint64_t *n_dup);
+/* CRC-32/IEEE of nbytes of HOST memory (any length, any alignment; PCLMULQDQ folding where the CPU has it); needs no device */
+SMHV_API uint32_t smhv_crc32_host(const void *data, uint64_t nbytes);
 /* CRC-32/IEEE of nbytes (multiple of 4) of device memory; == crc32fast::hash / zlib crc32 of the same bytes */
 SMHV_API int smhv_crc32_device(smhv_ctx *ctx, const void *d_data, uint64_t nbytes, uint32_t *crc);
 

@@ -115,8 +115,11 @@ SIGNATURES = {
     "smhv_debug_lsd_spin_limit": (C.c_int, [C.c_uint32]),
     "smhv_debug_lsd_threads": (C.c_int, [C.c_uint32]),
     "smhv_debug_skip_line_search": (C.c_int, [C.c_int]),
+    "smhv_debug_pattern_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "smhv_ingest_create_ex": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "smhv_crc32_host": (C.c_uint32, [C.c_void_p, C.c_uint64]),
     "smhv_ingest_destroy": (None, [C.c_void_p]),
     "smhv_ingest_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smhv_ingest_commit": (C.c_int, [C.c_void_p]),
@@ -137,7 +140,7 @@ class PipelineOptions(C.Structure):
 
 
 SEARCH_AUTO, SEARCH_BATCH, SEARCH_FRAME = 0, 1, 2
-PIPE_NO_TEAM_HELP, PIPE_NO_STREAM_PRIORITY, PIPE_NO_PROLOGUE = 1, 2, 4
+PIPE_NO_TEAM_HELP, PIPE_NO_STREAM_PRIORITY, PIPE_NO_PROLOGUE, PIPE_NO_IN_PASS_PUBLISH = 1, 2, 4, 8
 
 
 class VisionError(RuntimeError):

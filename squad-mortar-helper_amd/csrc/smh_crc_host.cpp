@@ -1,0 +1,144 @@
+// smh_crc_host.cpp -- CRC-32/IEEE of a captured frame on the HOST cores (x86-64, carry-less multiply), for the ingest queue's
+// region-of-interest upload mode (smh_runtime.cpp, SMHV_INGEST_ROI_UPLOAD): the reference's capture thread hashes the WHOLE
+// frame (crc32fast::hash, src/capture.rs:34,44-47) and drops it when the hash equals the previous capture's, while the vision
+// pipeline reads only the map ROI and the button rectangle (39 % of a 1080p frame).  Hashing on the device means uploading all
+// of it first; hashing where the bytes are lets the PCIe link carry the 39 % -- and nothing at all for a duplicate.
+//
+// The algorithm is the published one ("Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", Gopal et al., Intel 2009;
+// the same folding crc32fast 1.3.2 and zlib-ng use): four 128-bit lanes folded 512 bits at a time, folded into one, reduced to
+// 64 and then 32 bits (Barrett).  The folding constants are derived HERE from the polynomial (x^n mod P, bit-reflected) rather
+// than copied from a table, and tests/test_host_abi.py checks the result against zlib for ragged lengths and alignments.
+// Without PCLMULQDQ (or on another architecture) a slicing-by-8 table loop does the same job at a tenth of the speed.
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/smh_vision_hip.h"
+
+namespace {
+
+constexpr uint32_t POLY_REFLECTED = 0xEDB88320u;               // CRC-32/IEEE 802.3, reflected
+
+struct Tables {
+	uint32_t t[8][256];
+	Tables() {
+		for (uint32_t i = 0; i < 256; ++i) {
+			uint32_t c = i;
+			for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ POLY_REFLECTED : c >> 1;
+			t[0][i] = c;
+		}
+		for (uint32_t i = 0; i < 256; ++i)
+			for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 255u];
+	}
+};
+const Tables &tables() { static const Tables T; return T; }
+
+// state -> state over `n` bytes (state = ~crc convention: start with 0xFFFFFFFF, finish with ~state)
+uint32_t crc_table_update(uint32_t st, const uint8_t *p, size_t n) {
+	const Tables &T = tables();
+	while (n && ((uintptr_t)p & 7u)) { st = (st >> 8) ^ T.t[0][(st ^ *p++) & 255u]; --n; }
+	while (n >= 8) {
+		uint64_t v;
+		memcpy(&v, p, 8);
+		v ^= st;
+		st = T.t[7][v & 255u] ^ T.t[6][(v >> 8) & 255u] ^ T.t[5][(v >> 16) & 255u] ^ T.t[4][(v >> 24) & 255u] ^
+		     T.t[3][(v >> 32) & 255u] ^ T.t[2][(v >> 40) & 255u] ^ T.t[1][(v >> 48) & 255u] ^ T.t[0][(v >> 56) & 255u];
+		p += 8; n -= 8;
+	}
+	while (n--) st = (st >> 8) ^ T.t[0][(st ^ *p++) & 255u];
+	return st;
+}
+
+#if defined(__x86_64__)
+}  // namespace
+#include <immintrin.h>
+namespace {
+
+// x^n mod P as a bit-reflected 33-bit constant in the form the folding step wants: reflect(x^n mod P) << 1 (bit i of the result
+// = coefficient of x^(32 - i)): the reflected-domain carry-less products come out one bit short, the shift puts it back.
+uint64_t fold_constant(uint32_t n) {
+	// r = x^n mod P in the normal (non-reflected) representation, computed bit by bit; P = 0x104C11DB7
+	uint32_t r = 1u;                                            // x^0
+	for (uint32_t i = 0; i < n; ++i) r = (r & 0x80000000u) ? (r << 1) ^ 0x04C11DB7u : r << 1;
+	uint64_t refl = 0;
+	for (int b = 0; b < 32; ++b) if ((r >> b) & 1u) refl |= 1ull << (31 - b);
+	return refl << 1;
+}
+// floor(x^64 / P), reflected, 33 bits (Barrett constant)
+uint64_t barrett_mu() {
+	// polynomial long division of x^64 by P (33 bits)
+	uint64_t q = 0, rem_hi = 1;                                 // remainder register holds the current top 33 bits
+	unsigned __int128 num = (unsigned __int128)1 << 64, P = 0x104C11DB7ull;
+	for (int i = 64; i >= 32; --i) {
+		if ((num >> i) & 1) { q |= 1ull << (i - 32); num ^= P << (i - 32); }
+	}
+	(void)rem_hi;
+	uint64_t refl = 0;                                          // q has 33 bits (x^32 .. x^0): reflect over 33 bits
+	for (int b = 0; b <= 32; ++b) if ((q >> b) & 1ull) refl |= 1ull << (32 - b);
+	return refl;
+}
+struct Consts { uint64_t k1, k2, k3, k4, k5, px, mu; };
+const Consts &consts() {
+	// distances of the folds in bits: 512 + 64 / 512 (four lanes), 128 + 64 / 128 (one lane), 64 (the 96 -> 64 step)
+	static const Consts c = {fold_constant(4 * 128 + 32), fold_constant(4 * 128 - 32), fold_constant(128 + 32), fold_constant(128 - 32), fold_constant(64),
+	                         // P reflected over 33 bits
+	                         [] { uint64_t p = 0x104C11DB7ull, r = 0; for (int b = 0; b <= 32; ++b) if ((p >> b) & 1ull) r |= 1ull << (32 - b); return r; }(),
+	                         barrett_mu()};
+	return c;
+}
+
+__attribute__((target("pclmul,sse4.1"))) inline __m128i fold(__m128i a, __m128i b, __m128i k) {
+	return _mm_xor_si128(_mm_xor_si128(b, _mm_clmulepi64_si128(a, k, 0x00)), _mm_clmulepi64_si128(a, k, 0x11));
+}
+
+// state -> state over n bytes, n >= 64
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc_clmul_update(uint32_t st, const uint8_t *p, size_t n) {
+	const Consts &c = consts();
+	const __m128i *d = (const __m128i *)p;
+	__m128i x3 = _mm_loadu_si128(d), x2 = _mm_loadu_si128(d + 1), x1 = _mm_loadu_si128(d + 2), x0 = _mm_loadu_si128(d + 3);
+	d += 4; n -= 64;
+	x3 = _mm_xor_si128(x3, _mm_cvtsi32_si128((int)st));
+	const __m128i k1k2 = _mm_set_epi64x((long long)c.k2, (long long)c.k1);
+	while (n >= 64) {
+		x3 = fold(x3, _mm_loadu_si128(d), k1k2);
+		x2 = fold(x2, _mm_loadu_si128(d + 1), k1k2);
+		x1 = fold(x1, _mm_loadu_si128(d + 2), k1k2);
+		x0 = fold(x0, _mm_loadu_si128(d + 3), k1k2);
+		d += 4; n -= 64;
+	}
+	const __m128i k3k4 = _mm_set_epi64x((long long)c.k4, (long long)c.k3);
+	__m128i x = fold(x3, x2, k3k4);
+	x = fold(x, x1, k3k4);
+	x = fold(x, x0, k3k4);
+	while (n >= 16) { x = fold(x, _mm_loadu_si128(d), k3k4); ++d; n -= 16; }
+	// 128 -> 64 bits, then 64 -> 32 by Barrett reduction
+	const __m128i lo32 = _mm_set_epi32(0, 0, 0, -1);
+	x = _mm_xor_si128(_mm_clmulepi64_si128(x, k3k4, 0x10), _mm_srli_si128(x, 8));
+	x = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x, lo32), _mm_set_epi64x(0, (long long)c.k5), 0x00), _mm_srli_si128(x, 4));
+	const __m128i pu = _mm_set_epi64x((long long)c.mu, (long long)c.px);
+	const __m128i t1 = _mm_clmulepi64_si128(_mm_and_si128(x, lo32), pu, 0x10);
+	const __m128i t2 = _mm_clmulepi64_si128(_mm_and_si128(t1, lo32), pu, 0x00);
+	uint32_t out = (uint32_t)_mm_extract_epi32(_mm_xor_si128(x, t2), 1);
+	if (n) out = crc_table_update(out, (const uint8_t *)d, n);
+	return out;
+}
+bool have_clmul() {
+	static const bool v = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+	return v;
+}
+#else
+bool have_clmul() { return false; }
+uint32_t crc_clmul_update(uint32_t st, const uint8_t *, size_t) { return st; }
+#endif
+
+}  // namespace
+
+// CRC-32/IEEE of nbytes at data (== crc32fast::hash == zlib crc32(0, ..)); any length, any alignment.  Host only: needs no device.
+extern "C" SMHV_API uint32_t smhv_crc32_host(const void *data, uint64_t nbytes) {
+	const uint8_t *p = (const uint8_t *)data;
+	uint32_t st = 0xFFFFFFFFu;
+	if (!p || nbytes == 0) return 0u;
+	if (have_clmul() && nbytes >= 64) st = crc_clmul_update(st, p, (size_t)nbytes);
+	else st = crc_table_update(st, p, (size_t)nbytes);
+	return ~st;
+}

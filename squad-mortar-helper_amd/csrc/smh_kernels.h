@@ -113,7 +113,18 @@ struct FarmFrame {                  // one per frame of the launch
 	FarmEntry ring[SMH_FARM_RING];
 };
 
+struct SvcCtl;
+// Frame-granular pipelines, fused streaming pass: the pass publishes a frame to the search service itself, the moment the last
+// of the frame's row bands is done (smh_stream.hip, svc_push_tail) -- no publication kernel in the streaming chain, and the
+// search starts on the first frames while the pass is still working on the last.  One per pipeline slot, written once.
+struct SvcPushDesc {
+	SvcCtl *ctl;
+	unsigned long long *ring;
+	uint32_t *band_cnt;      // per frame of the slot: bands finished (the workgroup that brings it to the number of bands resets it)
+	uint32_t slot, ring_log2;
+};
 struct Buffers {
+	const SvcPushDesc *push; // null: nothing to publish (plain runs, batch-granular pipelines)
 	BatchError *err;         // device address of the batch's mailbox (null: none)
 	FarmFrame *farm;         // late-helper exchange of k_lsd_tile, one entry per frame (null: none)
 	// k_lsd_tile writes the frame's record itself (smh_record.inc: scale ratio + derived marker outputs) when SMH_REC_ON is set:
@@ -217,6 +228,8 @@ struct SvcParams {
 };
 // waves per service workgroup and LDS per workgroup for this frame size (0 waves: the frame size does not fit -> no service)
 uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes);
+// the slot's descriptor alone (the fused streaming pass then publishes the frames itself: SvcPushDesc)
+hipError_t launch_svc_open(SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, hipStream_t s);
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s);
 hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s);
 
@@ -243,6 +256,8 @@ uint32_t map_brq_lds_bytes(const Geom &g);
 uint32_t lsd_tile_lds_bytes(const Geom &g, uint32_t tile_limit);
 hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
                                const LaunchTuning *tune = nullptr);
+// the fused streaming pass's loads and stores without its arithmetic (calibration: smhv_debug_pattern_copy)
+hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s);
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
 // k_lsd is three kernels, one per mask residency mode, each over all frames (a workgroup whose frame needs another mode
 // exits at once).  When the whole ROI fits the LDS window (<= 1080p) every frame is a ROWS frame and only that kernel is
@@ -287,6 +302,8 @@ hipError_t set_ray_table(const float *dx, const float *dy);
 #define SMH_CRC_BS 1024
 // decoder layouts -> BGRA8 (n_px pixels; layout = SMHV_PIXELS_*)
 hipError_t launch_to_bgra(const void *d_src, void *d_bgra, uint64_t n_px, uint32_t layout, hipStream_t s);
+hipError_t launch_unpack_rows(const void *d_pack, void *d_frame, uint32_t pitch_px, uint32_t roi_x, uint32_t roi_y, uint32_t roi_w, uint32_t roi_h, uint32_t btn_x,
+                              uint32_t btn_y, uint32_t btn_w, uint32_t btn_h, hipStream_t s);
 hipError_t launch_crc32(const void *d_msg, uint64_t n_dwords, uint32_t wgs, uint32_t rounds, uint32_t x_skip, const uint32_t *d_x_local,
                         const uint32_t *d_x_wg, uint32_t *d_acc, hipStream_t s);
 uint32_t crc32_xpow(uint64_t n);                 // x^n mod P (reflected representation, x^0 = 0x80000000)

@@ -317,4 +317,26 @@ hipError_t launch_to_bgra(const void *d_src, void *d_bgra, uint64_t n_px, uint32
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_unpack_rows: the ingest queue's region-of-interest upload (smh_runtime.cpp): the packed rows of the map ROI followed by
+// the packed rows of the button rectangle go to their places in a frame of the slab.  One workgroup per row, dword copies
+// (the button's x is any pixel), 3.2 MB per 1080p frame.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_unpack_rows(const uint32_t *__restrict__ pack, uint32_t *__restrict__ frame, uint32_t pitch_px, uint32_t roi_x, uint32_t roi_y,
+                                                     uint32_t roi_w, uint32_t roi_h, uint32_t btn_x, uint32_t btn_y, uint32_t btn_w) {
+	const uint32_t r = blockIdx.x;
+	const bool roi = r < roi_h;
+	const uint32_t w = roi ? roi_w : btn_w;
+	const uint32_t *src = roi ? pack + (size_t)r * roi_w : pack + (size_t)roi_h * roi_w + (size_t)(r - roi_h) * btn_w;
+	uint32_t *dst = roi ? frame + (size_t)(roi_y + r) * pitch_px + roi_x : frame + (size_t)(btn_y + r - roi_h) * pitch_px + btn_x;
+	for (uint32_t i = threadIdx.x; i < w; i += 256u) dst[i] = src[i];
+}
+
+hipError_t launch_unpack_rows(const void *d_pack, void *d_frame, uint32_t pitch_px, uint32_t roi_x, uint32_t roi_y, uint32_t roi_w, uint32_t roi_h, uint32_t btn_x,
+                              uint32_t btn_y, uint32_t btn_w, uint32_t btn_h, hipStream_t s) {
+	hipLaunchKernelGGL(k_unpack_rows, dim3(roi_h + btn_h), dim3(256), 0, s, (const uint32_t *)d_pack, (uint32_t *)d_frame, pitch_px, roi_x, roi_y, roi_w, roi_h, btn_x, btn_y,
+	                   btn_w);
+	return hipGetLastError();
+}
+
 }  // namespace smh

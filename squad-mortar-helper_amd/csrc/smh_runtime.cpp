@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -286,6 +289,7 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
+	bf.push = nullptr;
 	bf.err = b->d_err;
 	bf.farm = b->d_farm; bf.rec_stages = 0u; bf.rec_bars = nullptr; bf.lsd_flags = 0u; bf.lsd_late_kc = 0u;
 	bf.cull_tab = nullptr;
@@ -575,7 +579,10 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 // s_pro: the pipeline's prologue stream -- the anchor upload and the button test of a submission run there, ahead of time, so
 // that the chain on a streaming stream is pass -> publication -> pass: the button test (45 us inside a busy pipeline, plus a
 // hand-over) is off it.
-struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro; };
+// push: the slot's SvcPushDesc (device) -- the fused streaming pass then publishes the frames itself and the descriptor is
+// written ahead of it (k_svc_open on the prologue stream); null: k_svc_publish behind the pass does both.
+struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro;
+                    const SvcPushDesc *push; };
 static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                           const smhv_anchors *anchors, hipStream_t s, hipStream_t sl, const SvcPublish *svc = nullptr) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
@@ -622,6 +629,17 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	STAGE_BEGIN(0, sb);
 	HIPCHK(launch_button(g, bf, n, 0, sb));
 	STAGE_END(0, sb);
+	// (stage flags of the run, needed here already when the pass publishes the frames itself)
+	const bool fused_pass = (stages & (SMHV_STAGE_MARKERS | SMHV_STAGE_UI_MAP)) && ((stages & SMHV_STAGE_OCR) || scales);
+	const bool in_pass_publish = svc && svc->push && fused_pass;
+	if (in_pass_publish) {
+		// the slot's descriptor ahead of the pass -- and the minimap kernel, whose output belongs to the record the service writes
+		if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sb));
+		bf.rec_stages = SMH_REC_ON | (scales ? stages : (stages & ~SMHV_STAGE_SCALES));
+		bf.rec_bars = b->d_bars;
+		bf.push = svc->push;
+		HIPCHK(launch_svc_open(svc->slots, svc->slot, bf, n, svc->seq, sb));
+	}
 	if (sb != s) {
 		HIPCHK(hipEventRecord(svc->ev_pro, sb));
 		HIPCHK(hipStreamWaitEvent(s, svc->ev_pro, 0));
@@ -642,10 +660,16 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	STAGE_BEGIN(2, s);
 	if (qflags && !mflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
 	STAGE_END(2, s);
-	HIPCHK(hipEventRecord(b->ev_map_done, s));
+	if (!svc) HIPCHK(hipEventRecord(b->ev_map_done, s));        // (every event recorded between two kernels of a chain lengthens their hand-over)
 	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[1], s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (smhv_debug_skip_line_search): the streaming pass with every output, no search
+	if (in_pass_publish) {                                      // the pass has published every frame as its last band finished
+		STAGE_BEGIN(3, s); STAGE_END(3, s);
+		STAGE_BEGIN(4, s); STAGE_END(4, s);
+		if (t) b->timed_runs++;
+		return SMHV_OK;
+	}
 	if (svc) {
 		// ---- frame-granular: publish the frames; the service searches them and writes the records (minimap first: its kernel
 		// needs nothing of the search and the record keeps what it wrote) ----
@@ -693,6 +717,15 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                                        const smhv_anchors *anchors, void *stream) {
 	return batch_run_impl(b, d_frames, n, stages, grayscale, max_gap, anchors, (hipStream_t)stream, (hipStream_t)stream);
+}
+
+extern "C" SMHV_API int smhv_debug_pattern_copy(smhv_batch *b, const void *d_frames, uint32_t n, void *stream) {
+	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+	CTX_OPEN(b->ctx);
+	HIPCHK(hipSetDevice(b->ctx->device));
+	const Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
+	HIPCHK(launch_pattern_copy(b->g, bf, n, (hipStream_t)stream));
+	return SMHV_OK;
 }
 
 extern "C" SMHV_API int smhv_batch_wait_map_pass(smhv_batch *b, void *stream) {
@@ -833,6 +866,8 @@ struct smhv_pipeline {
 	unsigned long long *d_svc_ring = nullptr;
 	SvcSlot *d_svc_slots = nullptr;
 	SvcHost *h_svc = nullptr, *d_svc_host = nullptr;
+	SvcPushDesc *d_svc_push = nullptr;  // per slot (in-pass publication of the fused streaming pass)
+	uint32_t *d_svc_cnt = nullptr;      // depth x max_frames band counters
 	hipStream_t s_search = nullptr, s_pro = nullptr;   // (s_pro: anchor uploads and button tests, ahead of the streaming streams)
 	std::vector<hipEvent_t> ev_pub;     // per slot: the slot's items have been published
 	std::vector<hipEvent_t> ev_pro;     // per slot: its button test has run
@@ -866,6 +901,8 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (p->d_svc_ring) (void)hipFree(p->d_svc_ring);
 	if (p->d_svc_slots) (void)hipFree(p->d_svc_slots);
 	if (p->h_svc) (void)hipHostFree(p->h_svc);
+	if (p->d_svc_push) (void)hipFree(p->d_svc_push);
+	if (p->d_svc_cnt) (void)hipFree(p->d_svc_cnt);
 	ctx_release(p->ctx);
 	delete p;
 }
@@ -968,6 +1005,14 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (e == hipSuccess) e = hipMemset(p->d_svc_slots, 0, sizeof(SvcSlot) * depth);
 		if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_svc, sizeof(SvcHost), hipHostMallocMapped | hipHostMallocCoherent);
 		if (e == hipSuccess) { memset(p->h_svc, 0, sizeof(SvcHost)); e = hipHostGetDevicePointer((void **)&p->d_svc_host, p->h_svc, 0); }
+		if (!(opt.flags & SMHV_PIPE_NO_IN_PASS_PUBLISH)) {
+			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_cnt, sizeof(uint32_t) * (size_t)depth * max_frames);
+			if (e == hipSuccess) e = hipMemset(p->d_svc_cnt, 0, sizeof(uint32_t) * (size_t)depth * max_frames);
+			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_push, sizeof(SvcPushDesc) * depth);
+			std::vector<SvcPushDesc> hp(depth);
+			for (uint32_t i = 0; i < depth; ++i) hp[i] = SvcPushDesc{p->d_svc_ctl, p->d_svc_ring, p->d_svc_cnt + (size_t)i * max_frames, i, lg};
+			if (e == hipSuccess) e = hipMemcpy(p->d_svc_push, hp.data(), sizeof(SvcPushDesc) * depth, hipMemcpyHostToDevice);
+		}
 	}
 	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline streams / events: %s", hipGetErrorString(e)); }
 	for (uint32_t i = 0; i < depth; ++i) {
@@ -1097,24 +1142,27 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	}
 	uint32_t seq = ++p->seq_counter;
 	if (seq == 0u) seq = ++p->seq_counter;
-	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot]};
+	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot],
+	               p->d_svc_push ? p->d_svc_push + slot : nullptr};
 	// The submission is counted BEFORE its kernels are enqueued: from here on the service does not regard itself as drained
 	// (were it counted afterwards, its items could be there -- and a wave at work on them -- while the count still said
 	// "everything complete", and the service would close under that wave).
 	__atomic_fetch_add(&p->h_svc->state, 1ull << 32, __ATOMIC_ACQ_REL);
 	rc = batch_run_impl(b, d_frames, n, stages, grayscale, max_gap, anchors, st, st, &pub);
-	hipError_t he = rc ? hipSuccess : hipEventRecord(p->ev_pub[slot], st);
-	if (rc || he != hipSuccess) {
-		// nothing of it may have been published: take the count back.  (If the publication did go out -- the event record failed
-		// behind it -- the service's count runs ahead by one and it simply never regards itself as drained early.)
-		if (rc) __atomic_fetch_sub(&p->h_svc->state, 1ull << 32, __ATOMIC_ACQ_REL);
-		return rc ? rc : fail(SMHV_E_HIP, "hipEventRecord: %s", hipGetErrorString(he));
+	if (rc) {
+		__atomic_fetch_sub(&p->h_svc->state, 1ull << 32, __ATOMIC_ACQ_REL);   // nothing of it was published: take the count back
+		return rc;
 	}
 	p->seq[slot] = seq;
 	p->slot_st[slot] = st;
 	p->last_sl[slot] = st;
-	// whoever finds no launch alive starts one (ordered behind this submission's items)
-	if (!svc_alive(p)) { rc = svc_launch(p, slot); if (rc) return rc; }
+	// whoever finds no launch alive starts one, ordered behind this submission's items (the event is recorded only then: a
+	// marker between two kernels of the streaming chain costs every submission a slower hand-over)
+	if (!svc_alive(p)) {
+		HIPCHK(hipEventRecord(p->ev_pub[slot], st));
+		rc = svc_launch(p, slot);
+		if (rc) return rc;
+	}
 	p->submitted++;
 	if (slot_out) *slot_out = slot;
 	return SMHV_OK;
@@ -1657,7 +1705,51 @@ struct smhv_ingest {
 	uint8_t *d_slab = nullptr;
 	uint32_t count = 0, last_crc = 0;                        // capture.rs:34 `let mut last_frame_crc32 = 0;`
 	uint64_t n_new = 0, n_dup = 0;
+	// ---- SMHV_INGEST_ROI_UPLOAD: hash on the host, upload only what the pipeline reads (smh_crc_host.cpp) ----
+	// A committed frame goes to a worker thread: CRC-32 of the whole staging buffer (what the reference's capture thread
+	// hashes), then the map-ROI rows and the button rows packed into a second pinned buffer.  Frames are resolved in order by
+	// the producer thread as before: a duplicate costs the PCIe link nothing, a new frame one contiguous upload of the packed
+	// rows (39 % of a 1080p frame) and two pitched device copies into its place in the slab.
+	bool roi = false;
+	Geom g{};
+	size_t roi_row_bytes = 0, btn_row_bytes = 0, pack_bytes = 0;
+	std::vector<uint8_t *> h_pack, d_pack;
+	std::vector<uint32_t> h_crc;
+	std::vector<int> crc_state;                              // 0 idle, 1 queued / being hashed, 2 done  (guarded by mu)
+	std::vector<std::thread> workers;
+	std::mutex mu;
+	std::condition_variable cv_job, cv_done;
+	std::deque<uint32_t> jobs;
+	bool stop = false;
 };
+extern "C" uint32_t smhv_crc32_host(const void *data, uint64_t nbytes);
+
+static void ingest_worker(smhv_ingest *q) {
+	for (;;) {
+		uint32_t slot;
+		{
+			std::unique_lock<std::mutex> lk(q->mu);
+			q->cv_job.wait(lk, [q] { return q->stop || !q->jobs.empty(); });
+			if (q->jobs.empty()) return;                         // (stop, nothing left)
+			slot = q->jobs.front();
+			q->jobs.pop_front();
+		}
+		const uint8_t *src = q->h_stage[slot];
+		const uint32_t crc = smhv_crc32_host(src, q->frame_bytes);
+		const Geom &g = q->g;
+		uint8_t *dst = q->h_pack[slot];
+		const size_t pitch = (size_t)g.W * 4;
+		for (uint32_t r = 0; r < g.rh; ++r) memcpy(dst + (size_t)r * q->roi_row_bytes, src + (size_t)(g.ry + r) * pitch + (size_t)g.m_ax * 4, q->roi_row_bytes);
+		dst += (size_t)g.rh * q->roi_row_bytes;
+		for (uint32_t r = 0; r < g.bh; ++r) memcpy(dst + (size_t)r * q->btn_row_bytes, src + (size_t)(g.by + r) * pitch + (size_t)g.bx * 4, q->btn_row_bytes);
+		{
+			std::lock_guard<std::mutex> lk(q->mu);
+			q->h_crc[slot] = crc;
+			q->crc_state[slot] = 2;
+		}
+		q->cv_done.notify_all();
+	}
+}
 
 // crc = raw remainder ^ (init 0xFFFFFFFF carried over the whole message) ^ final xor
 static uint32_t crc32_len_term(uint64_t n_dwords) { return crc32_mul(crc32_xpow(32u * n_dwords), 0xFFFFFFFFu) ^ 0xFFFFFFFFu; }
@@ -1709,11 +1801,18 @@ extern "C" SMHV_API int smhv_crc32_device(smhv_ctx *c, const void *d_data, uint6
 
 extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
 	if (!q) return;
+	if (!q->workers.empty()) {
+		{ std::lock_guard<std::mutex> lk(q->mu); q->stop = true; q->jobs.clear(); }
+		q->cv_job.notify_all();
+		for (auto &t : q->workers) t.join();
+	}
 	if (q->ctx) (void)hipSetDevice(q->ctx->device);
 	if (q->s) (void)hipStreamSynchronize(q->s);
 	for (auto p : q->h_stage) if (p) (void)hipHostFree(p);
 	for (auto p : q->d_stage) if (p) (void)hipFree(p);
 	for (auto p : q->d_raw) if (p) (void)hipFree(p);
+	for (auto p : q->h_pack) if (p) (void)hipHostFree(p);
+	for (auto p : q->d_pack) if (p) (void)hipFree(p);
 	for (auto ev : q->done) if (ev) (void)hipEventDestroy(ev);
 	if (q->d_acc) (void)hipFree(q->d_acc);
 	if (q->h_acc) (void)hipHostFree(q->h_acc);
@@ -1730,7 +1829,7 @@ static int ingest_setup(smhv_ingest *q) {
 	q->h_stage.assign(q->slots, nullptr); q->d_stage.assign(q->slots, nullptr); q->d_raw.assign(q->slots, nullptr); q->done.assign(q->slots, nullptr);
 	for (uint32_t i = 0; i < q->slots; ++i) {
 		HIPCHK(hipHostMalloc((void **)&q->h_stage[i], q->frame_bytes, hipHostMallocDefault));
-		HIPCHK(hipMalloc((void **)&q->d_stage[i], q->frame_bytes));
+		if (!q->roi) HIPCHK(hipMalloc((void **)&q->d_stage[i], q->frame_bytes));
 		HIPCHK(hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming));
 	}
 	HIPCHK(hipMalloc((void **)&q->d_acc, sizeof(uint32_t) * q->slots));
@@ -1743,11 +1842,31 @@ static int ingest_setup(smhv_ingest *q) {
 	HIPCHK(hipMemcpy(q->d_x_local, p.x_local.data(), sizeof(uint32_t) * SMH_CRC_BS, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(q->d_x_wg, p.x_wg.data(), sizeof(uint32_t) * p.wgs, hipMemcpyHostToDevice));
 	HIPCHK(hipMalloc((void **)&q->d_slab, q->frame_bytes * q->capacity));
+	if (q->roi) {
+		const Geom &g = q->g;
+		// the columns the streaming pass loads: whole quads from the ROI's quad-aligned x on (clipped to the frame)
+		const uint32_t roi_px = std::min<uint32_t>(g.m_quads * 4u, g.W - g.m_ax);
+		q->roi_row_bytes = (size_t)roi_px * 4; q->btn_row_bytes = (size_t)g.bw * 4;
+		q->pack_bytes = q->roi_row_bytes * g.rh + q->btn_row_bytes * g.bh;
+		q->h_pack.assign(q->slots, nullptr); q->d_pack.assign(q->slots, nullptr); q->h_crc.assign(q->slots, 0u); q->crc_state.assign(q->slots, 0);
+		for (uint32_t i = 0; i < q->slots; ++i) {
+			HIPCHK(hipHostMalloc((void **)&q->h_pack[i], q->pack_bytes, hipHostMallocDefault));
+			HIPCHK(hipMalloc((void **)&q->d_pack[i], q->pack_bytes));
+		}
+		// (frames outside the copied rectangles are never read by any kernel; zero them once so that the slab is deterministic)
+		HIPCHK(hipMemset(q->d_slab, 0, q->frame_bytes * q->capacity));
+		const uint32_t nthreads = std::min<uint32_t>(q->slots, std::max(2u, std::thread::hardware_concurrency() / 2u));
+		for (uint32_t i = 0; i < nthreads; ++i) q->workers.emplace_back(ingest_worker, q);
+	}
 	return SMHV_OK;
 }
 
 extern "C" SMHV_API int smhv_ingest_create(smhv_ctx *c, uint32_t w, uint32_t h, uint32_t slots, uint32_t capacity, smhv_ingest **out) {
-	if (!c || !out || w == 0 || h == 0 || slots < 2 || slots > 64 || capacity == 0) return fail(SMHV_E_INVALID, "ingest_create: bad arguments");
+	return smhv_ingest_create_ex(c, w, h, slots, capacity, 0u, out);
+}
+
+extern "C" SMHV_API int smhv_ingest_create_ex(smhv_ctx *c, uint32_t w, uint32_t h, uint32_t slots, uint32_t capacity, uint32_t flags, smhv_ingest **out) {
+	if (!c || !out || w == 0 || h == 0 || slots < 2 || slots > 64 || capacity == 0 || (flags & ~SMHV_INGEST_ROI_UPLOAD)) return fail(SMHV_E_INVALID, "ingest_create: bad arguments");
 	*out = nullptr;
 	CTX_OPEN(c);
 	Geom g;
@@ -1758,6 +1877,7 @@ extern "C" SMHV_API int smhv_ingest_create(smhv_ctx *c, uint32_t w, uint32_t h, 
 	if (!q) return fail(SMHV_E_INVALID, "out of memory");
 	c->refs.fetch_add(1, std::memory_order_relaxed);
 	q->ctx = c; q->W = w; q->H = h; q->slots = slots; q->capacity = capacity; q->frame_bytes = (size_t)w * h * 4;
+	q->roi = (flags & SMHV_INGEST_ROI_UPLOAD) != 0u; q->g = g;
 	rc = ingest_setup(q);
 	if (rc) { smhv_ingest_destroy(q); return rc; }
 	*out = q;
@@ -1770,6 +1890,25 @@ extern "C" SMHV_API int smhv_ingest_create(smhv_ctx *c, uint32_t w, uint32_t h, 
 enum { INGEST_FULL = 1 };
 static int ingest_resolve_one(smhv_ingest *q) {
 	const uint32_t slot = (uint32_t)(q->tail % q->slots);
+	if (q->roi) {
+		uint32_t crc;
+		{
+			std::unique_lock<std::mutex> lk(q->mu);
+			q->cv_done.wait(lk, [q, slot] { return q->crc_state[slot] == 2; });
+			crc = q->h_crc[slot];
+		}
+		if (crc == q->last_crc) { q->crc_state[slot] = 0; q->tail++; q->n_dup++; return SMHV_OK; }   // nothing was uploaded
+		if (q->count == q->capacity) return INGEST_FULL;
+		q->last_crc = crc;
+		const Geom &g = q->g;
+		uint8_t *dst = q->d_slab + (size_t)q->count * q->frame_bytes;
+		HIPCHK(hipMemcpyAsync(q->d_pack[slot], q->h_pack[slot], q->pack_bytes, hipMemcpyHostToDevice, q->s));
+		HIPCHK(launch_unpack_rows(q->d_pack[slot], dst, g.W, g.m_ax, g.ry, (uint32_t)(q->roi_row_bytes / 4), g.rh, g.bx, g.by, g.bw, g.bh, q->s));
+		HIPCHK(hipEventRecord(q->done[slot], q->s));             // the slot's pack buffers are free again when this has passed
+		q->crc_state[slot] = 0;
+		q->tail++; q->count++; q->n_new++;
+		return SMHV_OK;
+	}
 	HIPCHK(hipEventSynchronize(q->done[slot]));
 	const uint32_t crc = q->h_acc[slot] ^ q->len_term;
 	if (crc == q->last_crc) { q->tail++; q->n_dup++; return SMHV_OK; }
@@ -1793,6 +1932,7 @@ extern "C" SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra)
 	}
 	const uint32_t slot = (uint32_t)(q->head % q->slots);
 	// the slot's previous device copy may still be the source of a slab append on q->s: stream order covers it
+	if (q->roi) HIPCHK(hipEventSynchronize(q->done[slot]));   // (its packed rows may still be on their way: the next frame's worker overwrites them)
 	*host_bgra = q->h_stage[slot];
 	q->acquired = true;
 	return SMHV_OK;
@@ -1818,6 +1958,18 @@ extern "C" SMHV_API int smhv_ingest_commit_pixels(smhv_ingest *q, uint32_t layou
 	if (!bpp) return fail(SMHV_E_INVALID, "ingest_commit_pixels: unknown pixel layout %u", layout);
 	HIPCHK(hipSetDevice(q->ctx->device));
 	const uint32_t slot = (uint32_t)(q->head % q->slots);
+	if (q->roi) {
+		if (layout != SMHV_PIXELS_BGRA8) return fail(SMHV_E_INVALID, "ingest_commit_pixels: a queue created with SMHV_INGEST_ROI_UPLOAD takes BGRA8 frames only");
+		{
+			std::lock_guard<std::mutex> lk(q->mu);
+			q->crc_state[slot] = 1;
+			q->jobs.push_back(slot);
+		}
+		q->cv_job.notify_one();
+		q->head++;
+		q->acquired = false;
+		return SMHV_OK;
+	}
 	if (layout == SMHV_PIXELS_BGRA8) {
 		HIPCHK(hipMemcpyAsync(q->d_stage[slot], q->h_stage[slot], q->frame_bytes, hipMemcpyHostToDevice, q->s));
 	} else {

@@ -798,6 +798,27 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	}
 }
 
+// Frame-granular pipelines (Buffers::push): the workgroup that finishes the LAST band of a frame hands the frame to the search
+// service -- a ring entry and one count on the service's semaphore (smh_kernels.h, SvcCtl; smh_service.inc pops it).  Every
+// workgroup first makes its own outputs visible to the other XCDs: its waves have passed the barrier with their stores
+// acknowledged, then one thread writes the L2 back (agent-scope release) and counts the band.  All threads of the workgroup.
+__device__ __forceinline__ void svc_push_tail(MapKernelArgsPtr ka, uint32_t f) {
+	const SvcPushDesc *pd = ka->b.push;
+	if (!pd) return;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (__hip_atomic_fetch_add(&pd->band_cnt[f], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == ka->nbands) {
+			__hip_atomic_store(&pd->band_cnt[f], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			SvcCtl *ctl = pd->ctl;
+			const uint32_t t = __hip_atomic_fetch_add(&ctl->reserve, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(pd->ring + (t & ((1u << pd->ring_log2) - 1u)), ((unsigned long long)((t >> pd->ring_log2) + 1u) << 32) | (pd->slot << 24) | f,
+			                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_fetch_add(&ctl->avail, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
 // LOOP: the grid is capped (launch_map_brq_pass) and a workgroup walks the (frame, band) items with a grid stride.  Beyond
 // the number of workgroups that saturates HBM, more resident streaming workgroups only wait on each other in the memory
 // queues while holding wave slots and registers the other batches' line searches need.  The loop's
@@ -821,6 +842,7 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 		}
 	} else {
 		map_brq_item<GRAY>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
+		svc_push_tail(ka, blockIdx.y);
 	}
 }
 
@@ -877,6 +899,53 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 		if (grayscale) hipLaunchKernelGGL((k_map_brq_pass<true, false>), dim3(nbands, n), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
 		else hipLaunchKernelGGL((k_map_brq_pass<false, false>), dim3(nbands, n), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
 	}
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pattern_copy: the streaming pass's memory traffic without its arithmetic -- the calibration of what the memory system
+// gives THIS access pattern (smhv_debug_pattern_copy; bench.py: roofline_isolated.pattern_copy_GBps).  Same decomposition as
+// k_map_brq_pass (one workgroup per (frame, band of MAPQ_RB_MAX rows), one thread per quad across the ROI width): every ROI
+// quad is read once with a 16-byte load out of the 1920-px-pitch frame (986 of 1920 pixels of a row at 1080p), 16 bytes go to
+// the ui_map row, 4 to the mask row, and inside the bottom-right quadrant 4 each to the ocr and scales rows: per 256 1080p
+// frames 0.83 GB read and 1.14 GB written (the pass reads 0.95 GB: two halo rows per band on top).  What is stored is a
+// cheap function of what was loaded, so that no load can be dropped.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b) {
+	const uint32_t f = blockIdx.y, q = threadIdx.x;
+	const int r0 = (int)(blockIdx.x * MAPQ_RB_MAX), r1 = min(r0 + MAPQ_RB_MAX, (int)g.rh);
+	if (q >= g.m_quads) return;
+	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax) * 4 + (size_t)q * 16;
+	uint8_t *up = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
+	uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
+	const int qy0 = (int)(g.qy - g.ry);
+	const int qq = (int)q - (int)((g.q_ax - g.m_ax) >> 2);
+	const bool in_q = qq >= 0 && (uint32_t)qq < g.q_quads;
+	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
+	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
+	const size_t row_bytes = (size_t)g.W * 4;
+	for (int r = r0; r < r1; r += 4) {
+		uint4 v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) v[k] = *(const uint4 *)(fp + (size_t)min(r + k, r1 - 1) * row_bytes);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int row = r + k;
+			if (row >= r1) break;
+			*(uint4 *)(up + (size_t)row * g.ui_pitch) = v[k];
+			const uint32_t m = v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+			*(uint32_t *)(mp + (size_t)row * g.mask_pitch) = m;
+			const int qrow = row - qy0;
+			if (in_q && qrow >= 0 && qrow < (int)g.qh) {
+				*(uint32_t *)(op + (size_t)qrow * g.ocr_pitch) = ~m;
+				*(uint32_t *)(sp + (size_t)qrow * g.ocr_pitch) = m + 1u;
+			}
+		}
+	}
+}
+
+hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s) {
+	hipLaunchKernelGGL(k_pattern_copy, dim3((g.rh + MAPQ_RB_MAX - 1) / MAPQ_RB_MAX, n), dim3(g.m_block), 0, s, g, b);
 	return hipGetLastError();
 }
 

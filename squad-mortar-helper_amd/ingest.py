@@ -12,6 +12,12 @@ from . import _lib
 from ._lib import check
 
 
+def crc32_host(data):
+    """CRC-32/IEEE of a bytes-like / contiguous uint8 array on the host cores (the library's own routine); equals zlib.crc32."""
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else data, dtype=np.uint8)
+    return int(_lib.load().smhv_crc32_host(a.ctypes.data_as(C.c_void_p), C.c_uint64(a.size)))
+
+
 def crc32_device(vision, device_ptr, nbytes):
     """CRC-32/IEEE of `nbytes` (multiple of 4) of device memory; equals zlib.crc32 of the same bytes."""
     out = C.c_uint32(0)
@@ -26,13 +32,14 @@ PIXEL_LAYOUTS = {"bgra": (0, 4), "rgba": (1, 4), "rgb": (2, 3), "l": (3, 1), "la
 class IngestQueue:
     """`slots` pinned staging buffers + one device slab of `capacity` frames of w x h BGRA."""
 
-    def __init__(self, vision, w, h, slots=4, capacity=256):
+    def __init__(self, vision, w, h, slots=4, capacity=256, roi_upload=False):
+        """roi_upload: hash on the host, upload only the map ROI's and the button's rows (SMHV_INGEST_ROI_UPLOAD)."""
         self._lib = _lib.load()
         self._q = C.c_void_p()
         self.w, self.h, self.capacity = int(w), int(h), int(capacity)
         self.frame_bytes = self.w * self.h * 4
         self._vision = vision                                   # keeps the context alive
-        check(self._lib.smhv_ingest_create(vision._ctx, self.w, self.h, int(slots), self.capacity, C.byref(self._q)))
+        check(self._lib.smhv_ingest_create_ex(vision._ctx, self.w, self.h, int(slots), self.capacity, 1 if roi_upload else 0, C.byref(self._q)))
 
     def close(self):
         if self._q:

@@ -740,6 +740,74 @@ def test_ingest_queue_dedupes_like_the_capture_thread_and_feeds_the_batch(vision
     q.close()
 
 
+def test_ingest_roi_upload_hashes_on_the_host_and_uploads_only_what_is_read(vision):
+    """SMHV_INGEST_ROI_UPLOAD: the CRC-32 of the WHOLE frame is computed by the queue's host threads (so the duplicate rule
+    of src/capture.rs:44-47 sees the bytes the reference hashes), only the map ROI's and the button's rows travel; the
+    records, the images and the dedupe decisions equal the full-upload queue's and the oracle's."""
+    import zlib
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    for (W, H) in ((1280, 1024), (1366, 768)):                   # (1366: the ROI's x is not quad aligned)
+        fr = [synth.make_frame(W, H, 40 + i, n_lines=1 + i % 3)[0] for i in range(5)]
+        outside = fr[1].copy()
+        outside[0, 0, 0] ^= 1                                      # differs from fr[1] only OUTSIDE everything the pipeline reads
+        seq = [fr[0], fr[0], fr[1], outside, outside, fr[2], fr[2], fr[3], fr[4], fr[4], fr[0]]
+        crcs = [zlib.crc32(f.tobytes()) for f in seq]
+        keep, last = o.capture_dedupe(crcs)
+        want = [f for f, k in zip(seq, keep) if k]
+        assert len(want) == 7                                      # `outside` is a new capture for the reference, and for the queue
+        q = smh.IngestQueue(vision, W, H, slots=4, capacity=8, roi_upload=True)
+        for k, f in enumerate(seq):
+            if k % 2:
+                q.push(f)
+            else:
+                q.acquire()[...] = f
+                q.commit()
+        ptr, n, crc = q.batch()
+        assert n == len(want) and crc == last and q.counts() == (len(want), len(seq) - len(want))
+        fb = smh.FrameBatch(vision, W, H, n)
+        fb.run(ptr, n, stages=0x3)
+        recs = fb.read_results(0, n)
+        for r, f in zip(recs, want):
+            ref = o.process_frame(f, stages=0x3)
+            lines = np.array([[l.x0, l.y0, l.x1, l.y1] for l in r.lines[:r.n_lines]], np.float32).reshape(-1, 4)
+            assert r.map_open == ref["map_open"] == 1 and np.array_equal(lines, ref["lines"])
+        # the slab frames hold the two rectangles and zeros elsewhere
+        import ctypes as C
+        nb = W * H * 4
+        x, y, rw, rh = o.map_bounds(W, H)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        for i, f in enumerate(want):
+            fr_dev = np.empty((H, W, 4), np.uint8)
+            assert hip.hipMemcpy(fr_dev.ctypes.data, ptr + i * nb, nb, 2) == 0            # hipMemcpyDeviceToHost
+            assert np.array_equal(fr_dev[y:y + rh, x:x + rw], f[y:y + rh, x:x + rw])
+            assert not fr_dev[:min(y, 8), :8].any() and fr_dev.sum() < f.sum()
+        # a slab frame also feeds the per-call path
+        vision.load_frame_device(ptr + 2 * nb, W, H)
+        ui, roi = vision.crop_to_map(True)
+        vision.isolate_map_markers(); vision.mask_marker_lines()
+        refb = o.process_frame(want[2], stages=0x3, want_images=True)
+        assert np.array_equal(ui, refb["ui_map"]) and np.array_equal(vision.find_marker_lines(15), refb["lines"])
+        # full slab: the surplus stays queued, nothing is lost
+        q.reset()
+        more = [synth.make_frame(W, H, 70 + i, n_lines=1)[0] for i in range(8 + 4)]
+        for f in more:
+            q.push(f)
+        with pytest.raises(smh.VisionError) as ei:
+            q.push(fr[0])
+        assert ei.value.code == smh._lib.E_STATE
+        assert q.batch()[1] == 8
+        q.reset()
+        ptr, n, crc = q.batch()
+        assert n == 4 and crc == zlib.crc32(more[-1].tobytes())
+        q.acquire()
+        with pytest.raises(smh.VisionError):                       # decoded pixel layouts need the device path
+            q.commit_pixels("rgb")
+        q.commit()
+        q.close()
+
+
 def test_stress_4k_sparse_candidates_exceed_the_row_cache(vision):
     """3840x2160: the mask does not fit LDS, k_lsd keeps a sliding cache of 434 rows.  Isolated marker pixels every
     ~90 rows make a speculative group of 8 candidates span more rows than the cache (the group is cut short and

@@ -85,6 +85,23 @@ def test_record_layout_matches_header(built):
     assert "#define SMHV_FRAME_OK 0u" in hdr and "#define SMHV_FRAME_LSD_STUCK 1u" in hdr and "uint32_t status;" in hdr
 
 
+def test_host_crc32_equals_zlib_for_ragged_lengths_and_alignments(built):
+    """smhv_crc32_host (smh_crc_host.cpp: carry-less-multiply folding with constants derived from the polynomial, table loop
+    for the head / tail and short messages) == zlib.crc32 == crc32fast::hash (src/capture.rs:44): the ingest queue's
+    region-of-interest mode decides duplicates with it.  Needs no device."""
+    import zlib
+    from squad_mortar_helper_amd import ingest
+    rng = np.random.default_rng(7)
+    buf = rng.integers(0, 256, size=(1 << 20) + 64, dtype=np.uint8)
+    for n in list(range(0, 200)) + [255, 256, 257, 1023, 4096, 65537, (1 << 20) - 3, 1 << 20]:
+        for off in (0, 1, 5, 8, 15):
+            a = buf[off:off + n]
+            assert ingest.crc32_host(a) == zlib.crc32(a.tobytes()), (n, off)
+    assert ingest.crc32_host(b"123456789") == 0xCBF43926           # the CRC-32/IEEE check value
+    assert ingest.crc32_host(bytes(1 << 16)) == zlib.crc32(bytes(1 << 16))
+    assert ingest.crc32_host(b"\xff" * 100000) == zlib.crc32(b"\xff" * 100000)
+
+
 def test_shard_range_partitions_exactly(built):
     from squad_mortar_helper_amd.dist import shard_range
     for n in (1, 7, 8, 255, 256, 8192):
