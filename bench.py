@@ -98,7 +98,7 @@ def parse_args():
     ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="testing only (no GPU needed): the ranks meet, reduce one number over the process group, rank 0 prints a JSON line")
-    ap.add_argument("--ingest-frames", type=int, default=512,
+    ap.add_argument("--ingest-frames", type=int, default=2048,
                     help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1, config 2 only)")
     return ap.parse_args()
 
@@ -313,7 +313,7 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
         return qs, slabs * n, dt
 
     cores = os.cpu_count() or 8
-    slots = max(4, min(16, cores // 2))
+    slots = max(4, min(32, cores // 4))
     qs, frames, dt = run(True, slots, frames_total)
     q = qs[0]
     q.reset()

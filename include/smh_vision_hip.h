@@ -290,7 +290,6 @@ SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t fram
 #define SMHV_PIPE_NO_TEAM_HELP 1u       /* flags, diagnostics (A/B): frame-granular search without waves helping the heavy frames of their workgroup */
 #define SMHV_PIPE_NO_STREAM_PRIORITY 2u /*   ... without wave priority for the streaming pass */
 #define SMHV_PIPE_NO_PROLOGUE 4u        /*   ... button test and anchor upload on the streaming streams instead of a stream of their own */
-#define SMHV_PIPE_NO_IN_PASS_PUBLISH 8u /*   ... the frames published by a kernel behind the streaming pass instead of by the pass itself */
 typedef struct {
 	uint32_t size;
 	uint32_t search;                    /* SMHV_SEARCH_* */

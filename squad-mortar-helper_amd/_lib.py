@@ -140,7 +140,7 @@ class PipelineOptions(C.Structure):
 
 
 SEARCH_AUTO, SEARCH_BATCH, SEARCH_FRAME = 0, 1, 2
-PIPE_NO_TEAM_HELP, PIPE_NO_STREAM_PRIORITY, PIPE_NO_PROLOGUE, PIPE_NO_IN_PASS_PUBLISH = 1, 2, 4, 8
+PIPE_NO_TEAM_HELP, PIPE_NO_STREAM_PRIORITY, PIPE_NO_PROLOGUE = 1, 2, 4
 
 
 class VisionError(RuntimeError):

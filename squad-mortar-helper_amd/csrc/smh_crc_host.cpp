@@ -133,12 +133,17 @@ uint32_t crc_clmul_update(uint32_t st, const uint8_t *, size_t) { return st; }
 
 }  // namespace
 
+// Incremental form for the ingest workers (smh_runtime.cpp), which hash a frame row by row and copy the rows the pipeline
+// reads while they are still in the cache: state in, state out; start with 0xFFFFFFFF, the CRC is ~state.
+namespace smh {
+uint32_t crc32_host_update(uint32_t st, const uint8_t *p, size_t n) {
+	if (n == 0) return st;
+	return have_clmul() && n >= 64 ? crc_clmul_update(st, p, n) : crc_table_update(st, p, n);
+}
+}  // namespace smh
+
 // CRC-32/IEEE of nbytes at data (== crc32fast::hash == zlib crc32(0, ..)); any length, any alignment.  Host only: needs no device.
 extern "C" SMHV_API uint32_t smhv_crc32_host(const void *data, uint64_t nbytes) {
-	const uint8_t *p = (const uint8_t *)data;
-	uint32_t st = 0xFFFFFFFFu;
-	if (!p || nbytes == 0) return 0u;
-	if (have_clmul() && nbytes >= 64) st = crc_clmul_update(st, p, (size_t)nbytes);
-	else st = crc_table_update(st, p, (size_t)nbytes);
-	return ~st;
+	if (!data || nbytes == 0) return 0u;
+	return ~smh::crc32_host_update(0xFFFFFFFFu, (const uint8_t *)data, (size_t)nbytes);
 }

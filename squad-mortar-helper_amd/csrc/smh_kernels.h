@@ -113,18 +113,7 @@ struct FarmFrame {                  // one per frame of the launch
 	FarmEntry ring[SMH_FARM_RING];
 };
 
-struct SvcCtl;
-// Frame-granular pipelines, fused streaming pass: the pass publishes a frame to the search service itself, the moment the last
-// of the frame's row bands is done (smh_stream.hip, svc_push_tail) -- no publication kernel in the streaming chain, and the
-// search starts on the first frames while the pass is still working on the last.  One per pipeline slot, written once.
-struct SvcPushDesc {
-	SvcCtl *ctl;
-	unsigned long long *ring;
-	uint32_t *band_cnt;      // per frame of the slot: bands finished (the workgroup that brings it to the number of bands resets it)
-	uint32_t slot, ring_log2;
-};
 struct Buffers {
-	const SvcPushDesc *push; // null: nothing to publish (plain runs, batch-granular pipelines)
 	BatchError *err;         // device address of the batch's mailbox (null: none)
 	FarmFrame *farm;         // late-helper exchange of k_lsd_tile, one entry per frame (null: none)
 	// k_lsd_tile writes the frame's record itself (smh_record.inc: scale ratio + derived marker outputs) when SMH_REC_ON is set:
@@ -228,8 +217,6 @@ struct SvcParams {
 };
 // waves per service workgroup and LDS per workgroup for this frame size (0 waves: the frame size does not fit -> no service)
 uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes);
-// the slot's descriptor alone (the fused streaming pass then publishes the frames itself: SvcPushDesc)
-hipError_t launch_svc_open(SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, hipStream_t s);
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s);
 hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s);
 

@@ -1464,11 +1464,6 @@ uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words,
 	return w;
 }
 
-hipError_t launch_svc_open(SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, hipStream_t s) {
-	hipLaunchKernelGGL(k_svc_open, dim3(1), dim3(64), 0, s, slots, slot, b, n, seq);
-	return hipGetLastError();
-}
-
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s) {
 	hipLaunchKernelGGL(k_svc_publish, dim3(1), dim3(256), 0, s, ctl, ring, slots, slot, b, n, seq, ring_log2);
 	return hipGetLastError();

@@ -289,7 +289,6 @@ static int sector_table_for(smhv_ctx *c, uint32_t max_gap, hipStream_t s, Buffer
 
 static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t result_slot) {
 	Buffers bf;
-	bf.push = nullptr;
 	bf.err = b->d_err;
 	bf.farm = b->d_farm; bf.rec_stages = 0u; bf.rec_bars = nullptr; bf.lsd_flags = 0u; bf.lsd_late_kc = 0u;
 	bf.cull_tab = nullptr;
@@ -579,10 +578,7 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 // s_pro: the pipeline's prologue stream -- the anchor upload and the button test of a submission run there, ahead of time, so
 // that the chain on a streaming stream is pass -> publication -> pass: the button test (45 us inside a busy pipeline, plus a
 // hand-over) is off it.
-// push: the slot's SvcPushDesc (device) -- the fused streaming pass then publishes the frames itself and the descriptor is
-// written ahead of it (k_svc_open on the prologue stream); null: k_svc_publish behind the pass does both.
-struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro;
-                    const SvcPushDesc *push; };
+struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro; };
 static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                           const smhv_anchors *anchors, hipStream_t s, hipStream_t sl, const SvcPublish *svc = nullptr) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
@@ -629,17 +625,6 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	STAGE_BEGIN(0, sb);
 	HIPCHK(launch_button(g, bf, n, 0, sb));
 	STAGE_END(0, sb);
-	// (stage flags of the run, needed here already when the pass publishes the frames itself)
-	const bool fused_pass = (stages & (SMHV_STAGE_MARKERS | SMHV_STAGE_UI_MAP)) && ((stages & SMHV_STAGE_OCR) || scales);
-	const bool in_pass_publish = svc && svc->push && fused_pass;
-	if (in_pass_publish) {
-		// the slot's descriptor ahead of the pass -- and the minimap kernel, whose output belongs to the record the service writes
-		if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, sb));
-		bf.rec_stages = SMH_REC_ON | (scales ? stages : (stages & ~SMHV_STAGE_SCALES));
-		bf.rec_bars = b->d_bars;
-		bf.push = svc->push;
-		HIPCHK(launch_svc_open(svc->slots, svc->slot, bf, n, svc->seq, sb));
-	}
 	if (sb != s) {
 		HIPCHK(hipEventRecord(svc->ev_pro, sb));
 		HIPCHK(hipStreamWaitEvent(s, svc->ev_pro, 0));
@@ -664,12 +649,6 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[1], s));
 	if (sl != s) HIPCHK(hipStreamWaitEvent(sl, b->ev_map_done, 0));
 	const bool skip_lsd = g_skip_lsd.load(std::memory_order_relaxed);   // diagnostic (smhv_debug_skip_line_search): the streaming pass with every output, no search
-	if (in_pass_publish) {                                      // the pass has published every frame as its last band finished
-		STAGE_BEGIN(3, s); STAGE_END(3, s);
-		STAGE_BEGIN(4, s); STAGE_END(4, s);
-		if (t) b->timed_runs++;
-		return SMHV_OK;
-	}
 	if (svc) {
 		// ---- frame-granular: publish the frames; the service searches them and writes the records (minimap first: its kernel
 		// needs nothing of the search and the record keeps what it wrote) ----
@@ -866,8 +845,6 @@ struct smhv_pipeline {
 	unsigned long long *d_svc_ring = nullptr;
 	SvcSlot *d_svc_slots = nullptr;
 	SvcHost *h_svc = nullptr, *d_svc_host = nullptr;
-	SvcPushDesc *d_svc_push = nullptr;  // per slot (in-pass publication of the fused streaming pass)
-	uint32_t *d_svc_cnt = nullptr;      // depth x max_frames band counters
 	hipStream_t s_search = nullptr, s_pro = nullptr;   // (s_pro: anchor uploads and button tests, ahead of the streaming streams)
 	std::vector<hipEvent_t> ev_pub;     // per slot: the slot's items have been published
 	std::vector<hipEvent_t> ev_pro;     // per slot: its button test has run
@@ -901,8 +878,6 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (p->d_svc_ring) (void)hipFree(p->d_svc_ring);
 	if (p->d_svc_slots) (void)hipFree(p->d_svc_slots);
 	if (p->h_svc) (void)hipHostFree(p->h_svc);
-	if (p->d_svc_push) (void)hipFree(p->d_svc_push);
-	if (p->d_svc_cnt) (void)hipFree(p->d_svc_cnt);
 	ctx_release(p->ctx);
 	delete p;
 }
@@ -1005,14 +980,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (e == hipSuccess) e = hipMemset(p->d_svc_slots, 0, sizeof(SvcSlot) * depth);
 		if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_svc, sizeof(SvcHost), hipHostMallocMapped | hipHostMallocCoherent);
 		if (e == hipSuccess) { memset(p->h_svc, 0, sizeof(SvcHost)); e = hipHostGetDevicePointer((void **)&p->d_svc_host, p->h_svc, 0); }
-		if (!(opt.flags & SMHV_PIPE_NO_IN_PASS_PUBLISH)) {
-			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_cnt, sizeof(uint32_t) * (size_t)depth * max_frames);
-			if (e == hipSuccess) e = hipMemset(p->d_svc_cnt, 0, sizeof(uint32_t) * (size_t)depth * max_frames);
-			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_push, sizeof(SvcPushDesc) * depth);
-			std::vector<SvcPushDesc> hp(depth);
-			for (uint32_t i = 0; i < depth; ++i) hp[i] = SvcPushDesc{p->d_svc_ctl, p->d_svc_ring, p->d_svc_cnt + (size_t)i * max_frames, i, lg};
-			if (e == hipSuccess) e = hipMemcpy(p->d_svc_push, hp.data(), sizeof(SvcPushDesc) * depth, hipMemcpyHostToDevice);
-		}
+
 	}
 	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline streams / events: %s", hipGetErrorString(e)); }
 	for (uint32_t i = 0; i < depth; ++i) {
@@ -1142,8 +1110,7 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	}
 	uint32_t seq = ++p->seq_counter;
 	if (seq == 0u) seq = ++p->seq_counter;
-	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot],
-	               p->d_svc_push ? p->d_svc_push + slot : nullptr};
+	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot]};
 	// The submission is counted BEFORE its kernels are enqueued: from here on the service does not regard itself as drained
 	// (were it counted afterwards, its items could be there -- and a wave at work on them -- while the count still said
 	// "everything complete", and the service would close under that wave).
@@ -1722,7 +1689,7 @@ struct smhv_ingest {
 	std::deque<uint32_t> jobs;
 	bool stop = false;
 };
-extern "C" uint32_t smhv_crc32_host(const void *data, uint64_t nbytes);
+namespace smh { uint32_t crc32_host_update(uint32_t st, const uint8_t *p, size_t n); }   // smh_crc_host.cpp
 
 static void ingest_worker(smhv_ingest *q) {
 	for (;;) {
@@ -1734,14 +1701,22 @@ static void ingest_worker(smhv_ingest *q) {
 			slot = q->jobs.front();
 			q->jobs.pop_front();
 		}
+		// one pass over the frame: a few rows are hashed, then what the pipeline reads of them is copied while it is in the cache
 		const uint8_t *src = q->h_stage[slot];
-		const uint32_t crc = smhv_crc32_host(src, q->frame_bytes);
 		const Geom &g = q->g;
-		uint8_t *dst = q->h_pack[slot];
+		uint8_t *roi_dst = q->h_pack[slot], *btn_dst = roi_dst + (size_t)g.rh * q->roi_row_bytes;
 		const size_t pitch = (size_t)g.W * 4;
-		for (uint32_t r = 0; r < g.rh; ++r) memcpy(dst + (size_t)r * q->roi_row_bytes, src + (size_t)(g.ry + r) * pitch + (size_t)g.m_ax * 4, q->roi_row_bytes);
-		dst += (size_t)g.rh * q->roi_row_bytes;
-		for (uint32_t r = 0; r < g.bh; ++r) memcpy(dst + (size_t)r * q->btn_row_bytes, src + (size_t)(g.by + r) * pitch + (size_t)g.bx * 4, q->btn_row_bytes);
+		uint32_t st = 0xFFFFFFFFu;
+		constexpr uint32_t ROWS = 8;                             // 61 KB of a 1080p frame at a time
+		for (uint32_t y0 = 0; y0 < g.H; y0 += ROWS) {
+			const uint32_t y1 = std::min(g.H, y0 + ROWS);
+			st = smh::crc32_host_update(st, src + (size_t)y0 * pitch, (size_t)(y1 - y0) * pitch);
+			for (uint32_t y = y0; y < y1; ++y) {
+				if (y >= g.ry && y < g.ry + g.rh) memcpy(roi_dst + (size_t)(y - g.ry) * q->roi_row_bytes, src + (size_t)y * pitch + (size_t)g.m_ax * 4, q->roi_row_bytes);
+				if (y >= g.by && y < g.by + g.bh) memcpy(btn_dst + (size_t)(y - g.by) * q->btn_row_bytes, src + (size_t)y * pitch + (size_t)g.bx * 4, q->btn_row_bytes);
+			}
+		}
+		const uint32_t crc = ~st;
 		{
 			std::lock_guard<std::mutex> lk(q->mu);
 			q->h_crc[slot] = crc;

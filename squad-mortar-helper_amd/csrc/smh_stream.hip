@@ -798,27 +798,6 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	}
 }
 
-// Frame-granular pipelines (Buffers::push): the workgroup that finishes the LAST band of a frame hands the frame to the search
-// service -- a ring entry and one count on the service's semaphore (smh_kernels.h, SvcCtl; smh_service.inc pops it).  Every
-// workgroup first makes its own outputs visible to the other XCDs: its waves have passed the barrier with their stores
-// acknowledged, then one thread writes the L2 back (agent-scope release) and counts the band.  All threads of the workgroup.
-__device__ __forceinline__ void svc_push_tail(MapKernelArgsPtr ka, uint32_t f) {
-	const SvcPushDesc *pd = ka->b.push;
-	if (!pd) return;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		if (__hip_atomic_fetch_add(&pd->band_cnt[f], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == ka->nbands) {
-			__hip_atomic_store(&pd->band_cnt[f], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			SvcCtl *ctl = pd->ctl;
-			const uint32_t t = __hip_atomic_fetch_add(&ctl->reserve, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(pd->ring + (t & ((1u << pd->ring_log2) - 1u)), ((unsigned long long)((t >> pd->ring_log2) + 1u) << 32) | (pd->slot << 24) | f,
-			                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_fetch_add(&ctl->avail, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-		}
-	}
-}
-
 // LOOP: the grid is capped (launch_map_brq_pass) and a workgroup walks the (frame, band) items with a grid stride.  Beyond
 // the number of workgroups that saturates HBM, more resident streaming workgroups only wait on each other in the memory
 // queues while holding wave slots and registers the other batches' line searches need.  The loop's
@@ -842,7 +821,6 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 		}
 	} else {
 		map_brq_item<GRAY>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
-		svc_push_tail(ka, blockIdx.y);
 	}
 }
 

@@ -17,5 +17,7 @@ run d16 $R 256 16 400
 run c3_d12 $R 128 12 300 0xF 2560 1440
 run c4_d8 $R 1024 8 100
 run batch_d4 RATE_SEARCH=batch $R 256 4 400
-timeout -s KILL 600 python -m pytest tests/test_gpu_configs.py -x -q -m gpu -o faulthandler_timeout=200 -k "headline or pipeline_object or occupancy_policy or both_line or watchdog" > gpurun_out/r04m/pytest.log 2>&1
+timeout -s KILL 600 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -x -q -m gpu -o faulthandler_timeout=200 -k "headline or pipeline_object or occupancy_policy or both_line or watchdog or ingest" > gpurun_out/r04m/pytest.log 2>&1
 echo "pytest rc=$?"; tail -6 gpurun_out/r04m/pytest.log | cut -c1-300
+timeout -s KILL 500 python bench.py --steps 20 --warmup 3 --no-real-samples > gpurun_out/r04m/bench.json 2> gpurun_out/r04m/bench.err
+echo "bench rc=$?"; tail -1 gpurun_out/r04m/bench.json | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d.get('ingest'))"
