@@ -666,7 +666,8 @@ def main():
     regions = timed(pipe, args.steps)
     stages_ms = None
     if not args.no_stage_timing:
-        per = [b.stage_ms() for b in pipe.slots[:min(depth, args.steps * rounds)]]
+        first = args.warmup * rounds                             # submissions before the timed region: slot = submission % depth
+        per = [pipe.slots[(first + i) % depth].stage_ms() for i in range(min(depth, args.steps * rounds))]
         stages_ms = {k: float(np.mean([p[k] for p in per])) for k in per[0]}
         for b in pipe.slots:
             b.enable_timing(False)
