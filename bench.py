@@ -73,8 +73,8 @@ def parse_args():
     ap.add_argument("--stages", type=lambda s: int(s, 0), default=None)
     ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
-    ap.add_argument("--pipeline-depth", type=int, default=12,
-                    help="batches in flight (smhv_pipeline_create depth; 12 x 256 frames resident outputs = 16 GB of the 288: what the frame-granular search needs to hide its one-wave-per-frame latency)")
+    ap.add_argument("--pipeline-depth", type=int, default=0,
+                    help="batches in flight (smhv_pipeline_create depth; 0 = default: 12, or 8 for 1024-frame shards; 12 x 256 frames resident outputs = 16 GB of the 288: what the frame-granular search needs to hide its one-wave-per-frame latency)")
     ap.add_argument("--distinct", type=int, default=None,
                     help="distinct synthetic frames per GPU (0 = every frame distinct); fewer are tiled on the device.  Default: every "
                          "frame distinct, except config 4 (1024 frames per GPU): 256 distinct frames per GPU, tiled four times -- "
@@ -246,20 +246,33 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
             stems.append(stem)
     k = len(frames)
     d = torch.from_numpy(np.stack([frames[i % k] for i in range(batch)])).cuda()
-    pipe = smh.Pipeline(vision, 2560, 1440, batch, depth=depth)
     stages = 0x3
-    for _ in range(2 * depth):
-        pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
-    pipe.wait()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        slot = pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
-    pipe.wait()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    got = smh.results_to_dicts(pipe.slots[slot].read_results(0, batch))
-    pipe.close()
+
+    def rate(dep):
+        pipe = smh.Pipeline(vision, 2560, 1440, batch, depth=dep)
+        for _ in range(2 * dep):
+            pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
+        pipe.wait()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            slot = pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
+        pipe.wait()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        got_ = smh.results_to_dicts(pipe.slots[slot].read_results(0, batch))
+        pipe.close()
+        return dt_, got_
+
+    dt, got = rate(depth)
+    by_depth = {str(depth): batch * steps / dt}
+    for dep in (4, 8):                                     # (depth 4: the batch-granular search; 8 and up: the search service)
+        if dep != depth:
+            dt2, got2 = rate(dep)
+            by_depth[str(dep)] = batch * steps / dt2
+            same = all(a["n_lines"] == b["n_lines"] and np.array_equal(a["lines"], b["lines"]) and a["rounds"] == b["rounds"] for a, b in zip(got, got2))
+            if not same:
+                raise SystemExit("bench.py: the sample screenshots' records differ between pipeline depths %d and %d" % (depth, dep))
     ref = orc.process_batch(np.stack(frames), cpu_threads(k), stages=stages, max_gap=15)
     ok = True
     for i in range(batch):
@@ -269,7 +282,7 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
     rounds = [int(r.rounds) for r in ref]
     return {"frames_per_s": batch * steps / dt, "ms_per_pass": dt / steps * 1e3,
             "workload": "%d distinct 2560x1440 open-map screenshots of vision-common/samples (committed fixtures), cycled through a batch of %d; ui_map + markers" % (k, batch),
-            "batch": batch, "pipeline_depth": depth, "stages": stages, "passes": steps,
+            "batch": batch, "pipeline_depth": depth, "stages": stages, "passes": steps, "frames_per_s_by_depth": by_depth,
             "rounds_per_frame": {"min": min(rounds), "max": max(rounds), "mean": float(np.mean(rounds)), "all": rounds},
             "lines_per_frame_mean": float(np.mean([int(r.n_lines) for r in ref])),
             "records_equal_oracle": bool(ok), "note": "outside the timed region of `value`; the headline stays the synthetic configs[2] scene"}
@@ -586,7 +599,9 @@ def main():
     frames, infos, frames_host, h2d_s = upload_synthetic(torch, synth, W, H, n, first, args.lines, args.distinct, torch.device("cuda", local_rank), keep)
 
     vision = smh.HipVision.init(local_rank)
-    depth = max(1, args.pipeline_depth)
+    # default: 12 batches in flight (the frame-granular search service); 1024-frame shards (config 4): 8 -- each slot
+    # holds the output images of a whole batch, 8 MB per 1080p frame
+    depth = args.pipeline_depth if args.pipeline_depth > 0 else (8 if n >= 1024 else 12)
     idle_streams = [torch.cuda.Stream() for _ in range(max(0, args.idle_streams))]   # noqa: F841 (kept alive on purpose)
     if args.tile_cap > 0:
         smh._lib.load().smhv_debug_lsd_tile_cap(args.tile_cap)
@@ -781,7 +796,8 @@ def main():
                    "distinct_frames_per_gpu": (n if args.distinct <= 0 else min(args.distinct, n)),
                    "passes_per_step": rounds, "frames_per_step": frames_per_step,
                    "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world,
-                   "pipeline_depth": depth, "schedule": "smhv_pipeline (library-owned streams, staggered start)"},
+                   "pipeline_depth": depth, "schedule": ("smhv_pipeline, frame-granular line search (k_lsd_service: one long-lived kernel pulls (slot, frame) items from a device ring)"
+                                if svc_stats else "smhv_pipeline, batch-granular line search (one launch per batch)")},
         "value_is": "median of %d sub-regions of the %d timed steps (each bracketed by barrier + synchronize)" % (len(regions), args.steps),
         "value_min": min(rates), "value_max": max(rates), "value_whole_region": frames_per_step * args.steps / dt_total,
         "timed_seconds": dt_total,

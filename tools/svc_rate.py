@@ -50,8 +50,12 @@ def watchdog():
 
 import threading
 threading.Thread(target=watchdog, daemon=True).start()
+SYNC = bool(_env("RATE_SYNC"))                          # one submission at a time: every kernel runs alone (for --pmc runs)
 for _ in range(2 * depth):
-    pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
+    s_ = pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
+    if SYNC:
+        pipe.wait(s_)
+        torch.cuda.synchronize()
 pipe.wait()
 torch.cuda.synchronize()
 timing = os.environ.get("SVC_RATE_STAGE_MS")
@@ -63,8 +67,11 @@ slow = []
 for k in range(passes):
     t1 = time.perf_counter()
     slot = pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
+    if SYNC:
+        pipe.wait(slot)                                    # (counter profiling: rocprofv3 --pmc runs one kernel at a time)
+        torch.cuda.synchronize()
     t2 = time.perf_counter()
-    if t2 - t1 > 0.03:
+    if t2 - t1 > 0.03 and not SYNC:
         slow.append((k, round((t2 - t1) * 1e3, 1), pipe.peek()))
 pipe.wait()
 torch.cuda.synchronize()
