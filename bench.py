@@ -229,7 +229,7 @@ def records_equal_oracle(np, rec, ref):
             and np.array_equal(rec["lines"], lines) and rec["mpx"] == (ref.mpx if ref.has_mpx else None))
 
 
-def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
+def real_samples_leg(smh, torch, vision, depth, batch=128, steps=200):
     """The reference's own screenshots beside the synthetic scene (never `value`): the 2560x1440 open-map fixtures of
     tests/golden (crops of vision-common/samples/*, the images the reference's one GPU test runs on, vision-gpu/src/lib.rs:571)
     rebuilt into full frames and cycled through a batch of `batch` frames, ui_map + markers, through the same smhv_pipeline.
@@ -250,9 +250,10 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
 
     def rate(dep):
         pipe = smh.Pipeline(vision, 2560, 1440, batch, depth=dep)
-        for _ in range(2 * dep):
+        for _ in range(26 * dep if dep >= 8 else 2 * dep):     # (from depth 8 on the pipeline first measures both of its searches: 24 x depth submissions)
             pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
         pipe.wait()
+        modes[str(dep)] = (pipe.search_stats() or {}).get("mode", "batch-granular")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -264,6 +265,7 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
         pipe.close()
         return dt_, got_
 
+    modes = {}
     dt, got = rate(depth)
     by_depth = {str(depth): batch * steps / dt}
     for dep in (4, 8):                                     # (depth 4: the batch-granular search; 8 and up: the search service)
@@ -282,7 +284,7 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=40):
     rounds = [int(r.rounds) for r in ref]
     return {"frames_per_s": batch * steps / dt, "ms_per_pass": dt / steps * 1e3,
             "workload": "%d distinct 2560x1440 open-map screenshots of vision-common/samples (committed fixtures), cycled through a batch of %d; ui_map + markers" % (k, batch),
-            "batch": batch, "pipeline_depth": depth, "stages": stages, "passes": steps, "frames_per_s_by_depth": by_depth,
+            "batch": batch, "pipeline_depth": depth, "stages": stages, "passes": steps, "frames_per_s_by_depth": by_depth, "search_by_depth": modes,
             "rounds_per_frame": {"min": min(rounds), "max": max(rounds), "mean": float(np.mean(rounds)), "all": rounds},
             "lines_per_frame_mean": float(np.mean([int(r.n_lines) for r in ref])),
             "records_equal_oracle": bool(ok), "note": "outside the timed region of `value`; the headline stays the synthetic configs[2] scene"}
@@ -674,6 +676,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # a pipeline with SMHV_SEARCH_AUTO at depth >= 8 times both of its line searches on the workload before it settles on one
+    # (24 x depth submissions, smh_runtime.cpp mode_control): that belongs to the warm-up, whatever --warmup says.  The number
+    # of extra steps is computed, not polled: every rank must run the same number of passes (each gathers).
+    extra_warmup = 0
+    if depth >= 8 and args.search == "auto":
+        extra_warmup = max(0, -(-(26 * depth - args.warmup * rounds) // rounds))
+        for _ in range(extra_warmup):
+            step()
+        if extra_warmup and rank == 0:
+            print("bench.py: %d extra warm-up step(s): the pipeline measures both line searches on the workload before it settles" % extra_warmup, file=sys.stderr)
     barrier()
     if not args.no_stage_timing:
         for b in pipe.slots:
@@ -681,7 +693,7 @@ def main():
     regions = timed(pipe, args.steps)
     stages_ms = None
     if not args.no_stage_timing:
-        first = args.warmup * rounds                             # submissions before the timed region: slot = submission % depth
+        first = (args.warmup + extra_warmup) * rounds            # submissions before the timed region: slot = submission % depth
         per = [pipe.slots[(first + i) % depth].stage_ms() for i in range(min(depth, args.steps * rounds))]
         stages_ms = {k: float(np.mean([p[k] for p in per])) for k in per[0]}
         for b in pipe.slots:
@@ -797,7 +809,8 @@ def main():
                    "passes_per_step": rounds, "frames_per_step": frames_per_step,
                    "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world,
                    "pipeline_depth": depth, "schedule": ("smhv_pipeline, frame-granular line search (k_lsd_service: one long-lived kernel pulls (slot, frame) items from a device ring)"
-                                if svc_stats else "smhv_pipeline, batch-granular line search (one launch per batch)")},
+                                if svc_stats and svc_stats.get("mode") == "frame-granular" else "smhv_pipeline, batch-granular line search (one launch per batch)") +
+                               ("; chosen by the pipeline's own measurement of both on this workload" if svc_stats and svc_stats.get("adaptive") else "")},
         "value_is": "median of %d sub-regions of the %d timed steps (each bracketed by barrier + synchronize)" % (len(regions), args.steps),
         "value_min": min(rates), "value_max": max(rates), "value_whole_region": frames_per_step * args.steps / dt_total,
         "timed_seconds": dt_total,

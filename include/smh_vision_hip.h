@@ -268,23 +268,29 @@ SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
  *            is a counter the search's waves count down, not a point on a stream.
  *   hold   : a consumer reads the slot's outputs on `stream` (work already enqueued there): the slot's next submission
  *            is ordered behind it.
- * depth: 1..16.  Two line-search schedules, chosen by the library from the depth (smhv_pipeline_options::search overrides):
- *   batch-granular (depth < 8): one search launch per submission on the slot's own stream (k_lsd with helper workgroups at
- *     depth 1, k_lsd at depth 2 up to 1080p, k_lsd_tile otherwise), staggered starts, and from depth 3 on an occupancy policy
- *     for the streaming pass that adapts to the workload.  Tuned for depth 4; 5 and 6 measure 20-25 % lower (HIP deals the
- *     slots' streams onto four hardware queues).
- *   frame-granular (depth >= 8, frame sizes up to ~4K): ONE long-lived search kernel per pipeline whose waves pull (slot,
+ * depth: 1..16.  Two line-search schedules (smhv_pipeline_options::search pins one):
+ *   batch-granular: one search launch per submission on the slot's own stream (k_lsd with helper workgroups at depth 1, k_lsd
+ *     at depth 2 up to 1080p, k_lsd_tile -- eight waves per frame -- otherwise), staggered starts, and from depth 3 on an
+ *     occupancy policy for the streaming pass and late helpers for heavy frames, both adapting to the workload.  Every slot's
+ *     stream has a hardware queue of its own.
+ *   frame-granular (depth >= 3, frame sizes up to ~4K): ONE long-lived search kernel per pipeline whose waves pull (slot,
  *     frame) items from a device-side ring -- one wave per frame, the reference's sequential scan, with the other waves of its
  *     workgroup casting a heavy frame's upcoming candidates -- write the frame's record and count it off against its
  *     submission; the submissions' streaming sides take two library-owned streams in turn.  A slot is done when its slowest
  *     frame is, nothing else waits for that frame.  The kernel closes by itself when nothing is outstanding (a device-wide
- *     synchronize by anybody still returns) and is launched again by the next submission.  Needs ~2000 frames in flight to
- *     hide the one-wave latency: 455 k frames/s at depth 8, 510 k at depth 12 (256 x 1080p; batch-granular at depth 4: 435 k). */
+ *     synchronize by anybody still returns) and is launched again by the next submission.  A third of the wave-time per frame,
+ *     but a frame is one wave's work from start to end: it needs ~2000 light frames in flight.
+ *   SMHV_SEARCH_AUTO (the default): below depth 8 batch-granular.  From depth 8 on the pipeline has both and MEASURES which is
+ *     faster on the workload it is given -- a window of 8 x depth submissions in each, after warm-ups, ~24 x depth submissions in
+ *     all; again every 16384 submissions and when the submissions change shape -- keeping the faster one (both write
+ *     byte-identical records).  Measured at depth 12: the synthetic 256 x 1080p scene 519 k frames/s on the frame-granular
+ *     search (419 k batch-granular); the reference's own 1440p screenshots in batches of 128 (0-372 search rounds per frame)
+ *     289 k batch-granular (163 k frame-granular). */
 typedef struct smhv_pipeline smhv_pipeline;
 SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth, smhv_pipeline **out);
 /* The same with explicit choices: zero-initialise, set `size` = sizeof(smhv_pipeline_options), change what you need (every 0 is
  * the library's default; there are no environment variables). */
-#define SMHV_SEARCH_AUTO 0u             /* frame-granular from depth 8 on where the frame size allows it, else batch-granular */
+#define SMHV_SEARCH_AUTO 0u             /* batch-granular below depth 8; from 8 on whichever of the two the pipeline measures faster on its workload */
 #define SMHV_SEARCH_BATCH 1u
 #define SMHV_SEARCH_FRAME 2u            /* SMHV_E_INVALID when depth < 3 or the frame's mask tiles do not fit the LDS beside the streaming pass (8K) */
 #define SMHV_PIPE_NO_TEAM_HELP 1u       /* flags, diagnostics (A/B): frame-granular search without waves helping the heavy frames of their workgroup */

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <sched.h>
 #include <mutex>
 #include <vector>
 #include <new>
@@ -61,6 +62,46 @@ extern "C" int smhv_internal_fail(int code, const char *fmt, ...) {
 		hipError_t _e = (expr);                                                                               \
 		if (_e != hipSuccess) return fail(SMHV_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
 	} while (0)
+
+// Waits of the pipelined paths.  hipEventSynchronize / hipStreamSynchronize may put the thread to sleep on an interrupt --
+// whether they do depends on process-wide state the library does not own (measured: a pipeline created before anything else
+// had used the device waited that way and ran the sample screenshots at 107 k frames/s; the same pipeline created after one
+// unrelated 16-byte torch copy ran at 203 k, depth 4, batch-granular search).  A slot of a pipeline is due within a
+// millisecond, so these waits poll first (hipEventQuery / hipStreamQuery, ~1 us per look, yielding the core between looks)
+// and fall back to the blocking call only after SMH_SPIN_WAIT_US.
+#define SMH_SPIN_WAIT_US 20000
+static hipError_t wait_event(hipEvent_t ev) {
+	hipError_t e = hipEventQuery(ev);
+	if (e != hipErrorNotReady) return e;
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (uint32_t k = 0;; ++k) {
+		e = hipEventQuery(ev);
+		if (e != hipErrorNotReady) return e;
+		if ((k & 15u) == 15u) {
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			if ((t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 > SMH_SPIN_WAIT_US) break;
+			sched_yield();
+		}
+	}
+	return hipEventSynchronize(ev);
+}
+static hipError_t wait_stream(hipStream_t st) {
+	hipError_t e = hipStreamQuery(st);
+	if (e != hipErrorNotReady) return e;
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (uint32_t k = 0;; ++k) {
+		e = hipStreamQuery(st);
+		if (e != hipErrorNotReady) return e;
+		if ((k & 15u) == 15u) {
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			if ((t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 > SMH_SPIN_WAIT_US) break;
+			sched_yield();
+		}
+	}
+	return hipStreamSynchronize(st);
+}
 
 extern "C" SMHV_API const char *smhv_last_error(void) { return t_last_error.c_str(); }
 
@@ -854,8 +895,32 @@ struct smhv_pipeline {
 	bool svc_key_valid = false;         // the running / next service's sector table and gap threshold
 	const uint32_t *svc_cull = nullptr;
 	uint32_t svc_max_gap = 0;
+	// ---- SMHV_SEARCH_AUTO at depth >= SMH_SVC_AUTO_DEPTH: both searches, and the pipeline MEASURES which one this workload
+	// runs faster on.  The frame-granular service costs a third of the wave-time per frame but a frame is one wave's work from
+	// start to end; a batch whose heaviest frame takes longer than the pipeline has slots for is faster on the batch-granular
+	// search, eight waves per frame (measured, depth 12: synthetic 1080p scene 519 k against 419 k frames/s for the service;
+	// the reference's 1440p screenshots, 0-372 rounds per frame, 163 k against 288 k for the batch-granular search).  Both
+	// write byte-identical records, so the choice is a matter of speed only: the pipeline times a window of submissions in
+	// each mode (host clock over 2 x depth submissions, after a warm-up), keeps the faster one, and looks again every
+	// SMH_MODE_RECHECK submissions or when the shape of the submissions changes.  Submissions of both kinds may be in flight
+	// at once (a slot remembers which kind its last submission was).
+	std::vector<hipStream_t> svc_stream;   // the streaming streams of frame-granular submissions (stream[]: one per slot, batch-granular)
+	std::vector<uint8_t> slot_frame;       // per slot: its most recent submission went to the service
+	bool adaptive = false, mode_frame = false;
+	struct ModeCtl {
+		uint32_t phase = 0, count = 0, settle = 0, key_n = 0, key_stages = 0, key_gap = 0, decisions = 0;
+		uint64_t frames = 0;
+		struct timespec t0{};
+		double rate[2] = {0.0, 0.0};       // frames/s measured in the last window of [0] batch-granular, [1] frame-granular
+	} mc;
 };
 static int svc_wait_slot(smhv_pipeline *p, uint32_t slot);
+// wait for the slot's most recent submission, whichever search it went to
+static int slot_wait(smhv_pipeline *p, uint32_t slot) {
+	if (p->svc && p->slot_frame[slot]) return svc_wait_slot(p, slot);
+	HIPCHK(wait_event(p->done[slot]));
+	return SMHV_OK;
+}
 static int svc_launch(smhv_pipeline *p, uint32_t slot);
 static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                       const smhv_anchors *anchors, void *after_stream, uint32_t *slot_out);
@@ -863,13 +928,14 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (!p) return;
 	if (p->ctx) (void)hipSetDevice(p->ctx->device);
-	if (p->svc) for (uint32_t i = 0; i < p->depth; ++i) (void)svc_wait_slot(p, i);   // (a stalled service is relaunched by the wait)
+	if (p->svc) for (uint32_t i = 0; i < p->depth && i < p->slot_frame.size(); ++i) if (p->slot_frame[i]) (void)svc_wait_slot(p, i);   // (a stalled service is relaunched by the wait)
 	(void)hipDeviceSynchronize();                             // the service closes by itself once every submission is complete
 	for (auto b : p->batch) if (b) smhv_batch_destroy(b);
 	for (auto e : p->done) if (e) (void)hipEventDestroy(e);
 	for (auto e : p->hold) if (e) (void)hipEventDestroy(e);
 	if (p->ev_after) (void)hipEventDestroy(p->ev_after);
 	for (auto st : p->stream) if (st) (void)hipStreamDestroy(st);
+	for (auto st : p->svc_stream) if (st) (void)hipStreamDestroy(st);
 	if (p->s_search) (void)hipStreamDestroy(p->s_search);
 	if (p->s_pro) (void)hipStreamDestroy(p->s_pro);
 	for (auto e : p->ev_pub) if (e) (void)hipEventDestroy(e);
@@ -913,6 +979,7 @@ static LaunchTuning pipeline_tuning(const Geom &g) {
 // batches: 455 k frames/s at depth 8 and 510 k at depth 12, against 435 k for the batch-granular search at depth 4), below
 // that the batch-granular search with its occupancy policy is ahead (depth 4: 435 k against 275 k).
 #define SMH_SVC_AUTO_DEPTH 8u
+#define SMH_OWN_QUEUES 16u
 static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, const smhv_pipeline_options *opt_in, smhv_pipeline **out) {
 	if (!c || !out || max_frames == 0 || depth == 0 || depth > SVC_MAX_SLOTS) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..%u)", SVC_MAX_SLOTS);
 	*out = nullptr;
@@ -945,18 +1012,30 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 	p->batch.assign(depth, nullptr); p->done.assign(depth, nullptr); p->hold.assign(depth, nullptr); p->held.assign(depth, 0); p->last_sl.assign(depth, nullptr);
 	hipError_t e = hipSuccess;
 	{
-		// The streams are created back to back, before any other object of the pipeline: HIP deals streams onto the
-		// hardware queues in creation order, so consecutive streams never share one, whatever the host created earlier.
+		// Every stream of the pipeline gets a hardware queue of its own: a stream created with a CU mask (here: all CUs) does,
+		// the mask being a property of the queue.  Ordinary streams are dealt onto the process's four hardware queues when they
+		// are first USED, in an order that depends on what else the process has done with the device by then -- measured: a
+		// depth-4 pipeline created before the process's first other use of the device had two of its four chains on one
+		// queue (kernel trace: 1111 / 555 / 555 kernels on three queues) and ran the sample screenshots at 104 k frames/s, the
+		// same pipeline created after one unrelated 16-byte copy had four queues and 203 k.  (The first streams of a pipeline, within a budget:
+		// below.)  The search service's kernel lives as
+		// long as the pipeline is busy: whatever shared its queue would wait that long.
 		p->svc_streams = p->svc ? std::min<uint32_t>(depth, opt.streams ? opt.streams : 2u) : 0u;
-		const uint32_t ns = p->svc ? p->svc_streams : depth;
+		p->adaptive = p->svc && opt.search == SMHV_SEARCH_AUTO;
+		p->mode_frame = p->svc;
+		p->slot_frame.assign(depth, 0);
+		const uint32_t ns = (!p->svc || p->adaptive) ? depth : 0u;   // one stream per slot for batch-granular submissions
+		const uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
 		p->stream.assign(ns, nullptr);
-		for (uint32_t i = 0; i < ns && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking);
+		// (a budget of SMH_OWN_QUEUES queues per pipeline, the service's four included: with 21 queues of one process the
+		// hardware scheduler started to time-slice them -- stalls of 80 ms in the kernel trace of a depth-16 pipeline)
+		const uint32_t own = SMH_OWN_QUEUES - (p->svc ? p->svc_streams + 2u : 0u);
+		for (uint32_t i = 0; i < ns && e == hipSuccess; ++i) e = create_stream(&p->stream[i], i < own ? full : nullptr);
 		if (p->svc && e == hipSuccess) {
-			// a stream with a CU mask gets a hardware queue of its own (the mask is a property of the queue): the service kernel
-			// lives as long as the pipeline is busy, and whatever shared its queue would wait that long
-			const uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
-			e = create_stream(&p->s_search, full);
-			if (e == hipSuccess && !(opt.flags & SMHV_PIPE_NO_PROLOGUE)) e = hipStreamCreateWithFlags(&p->s_pro, hipStreamNonBlocking);
+			p->svc_stream.assign(p->svc_streams, nullptr);
+			for (uint32_t i = 0; i < p->svc_streams && e == hipSuccess; ++i) e = create_stream(&p->svc_stream[i], full);
+			if (e == hipSuccess) e = create_stream(&p->s_search, full);
+			if (e == hipSuccess && !(opt.flags & SMHV_PIPE_NO_PROLOGUE)) e = create_stream(&p->s_pro, full);
 		}
 	}
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
@@ -991,11 +1070,11 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		// k_lsd_tile always.
 		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
-		if (p->svc) {
+		if (p->svc && !p->adaptive) {
 			// no occupancy policy: the service's resident waves (one per SIMD, most of a CU's LDS) are what caps the streaming
 			// pass at three workgroups per CU; the streaming waves go first on their SIMD
 			p->batch[i]->tune.map_prio = (opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u;
-		} else if (depth >= 3) {
+		} else if (depth >= 3) {                                  // (an adaptive pipeline sets the tuning of a slot per submission)
 			if (opt.occupancy_policy != 2u) p->tuning = pipeline_tuning(p->batch[i]->g);
 			p->batch[i]->tune = p->tuning;
 			if (opt.late_helpers == 1u) p->batch[i]->lsd_late_kc = 20u;           // every frame asks at once
@@ -1083,10 +1162,11 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	smhv_batch *b = p->batch[slot];
 	if (!d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b->max_frames);
 	// the slot's previous submission owns its buffers until its last frame has been counted off
-	int rc = svc_wait_slot(p, slot);
+	int rc = slot_wait(p, slot);
 	if (rc) return rc;
 	if (batch_check_errors(b, "pipeline_submit (the slot's previous submission, never waited for)") != SMHV_OK) logf(p->ctx, 2, "%s", t_last_error.c_str());
-	hipStream_t st = p->stream[p->submitted % p->svc_streams];
+	hipStream_t st = p->svc_stream[p->submitted % p->svc_streams];
+	if (p->adaptive) { b->tune = LaunchTuning{0u, 0u, 0u, (p->opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u}; b->probe = false; b->lsd_late_kc = 0u; }
 	// the sector table of this gap threshold is a launch parameter of the service: a submission with another one waits for
 	// the service to finish what it has and close (a host that alternates thresholds pays a drain per change)
 	Buffers probe{};
@@ -1123,6 +1203,7 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	p->seq[slot] = seq;
 	p->slot_st[slot] = st;
 	p->last_sl[slot] = st;
+	p->slot_frame[slot] = 1;
 	// whoever finds no launch alive starts one, ordered behind this submission's items (the event is recorded only then: a
 	// marker between two kernels of the streaming chain costs every submission a slower hand-over)
 	if (!svc_alive(p)) {
@@ -1135,16 +1216,74 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	return SMHV_OK;
 }
 
+
+// The mode controller of an adaptive pipeline (smhv_pipeline::ModeCtl): called at the top of every submission.
+//   phase 0  warm-up in the current mode (2 depth submissions)
+//   phase 1  measure the current mode: frames submitted / host-clock time over W = 8 depth submissions -> rate[mode].  A full
+//            pipeline lets a submission in when its slot's previous one has completed, so over a long window the cadence of
+//            the calls IS the throughput; over a short one it is not (the calls return in bursts: 65 to 2343 k frames/s over
+//            windows of 16 submissions of a pipeline that runs at 420 k).  Draining the pipeline around the window instead
+//            measures the ramps: a batch-granular pipeline restarts staggered, one streaming pass after the other.
+//   phase 2  the other mode, warm-up (6 depth submissions: the other search's submissions drain, and a batch-granular pipeline
+//            also has to find its occupancy policy)
+//   phase 3  measure it the same way -> rate[other]; keep the faster mode (the service has to be 3 % ahead: it occupies the
+//            device while idle, so a tie -- a host that submits slower than either search runs -- goes to the batch-granular search)
+//   phase 4  settled for SMH_MODE_RECHECK submissions, or until the submissions change shape (frames, stages, gap threshold)
+#define SMH_MODE_RECHECK 16384u
+static int mode_control(smhv_pipeline *p, uint32_t n, uint32_t stages, uint32_t max_gap) {
+	smhv_pipeline::ModeCtl &m = p->mc;
+	const uint32_t W = 8u * p->depth;
+	if (m.phase == 4 && (m.key_n != n || m.key_stages != stages || m.key_gap != max_gap)) { m.phase = 0; m.count = 0; }
+	m.key_n = n; m.key_stages = stages; m.key_gap = max_gap;
+	auto begin = [&m]() { m.count = 0; m.frames = 0; clock_gettime(CLOCK_MONOTONIC, &m.t0); };
+	auto rate = [&m]() {
+		struct timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		const double dt = (double)(t1.tv_sec - m.t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - m.t0.tv_nsec);
+		return dt > 0.0 ? (double)m.frames / dt : 0.0;
+	};
+	int rc = SMHV_OK;
+	switch (m.phase) {
+	case 0:
+		if (m.count >= 2u * p->depth) { m.phase = 1; begin(); }
+		break;
+	case 1:
+		if (m.count >= W) { m.rate[p->mode_frame ? 1 : 0] = rate(); p->mode_frame = !p->mode_frame; m.phase = 2; m.count = 0; }
+		break;
+	case 2:
+		if (m.count >= 6u * p->depth) { m.phase = 3; begin(); }
+		break;
+	case 3:
+		if (m.count >= W) {
+			m.rate[p->mode_frame ? 1 : 0] = rate();
+			p->mode_frame = m.rate[1] > 1.03 * m.rate[0];
+			m.decisions++;
+			m.phase = 4; m.count = 0; m.settle = SMH_MODE_RECHECK;
+			logf(p->ctx, 3, "pipeline: frame-granular search %.0f frames/s, batch-granular %.0f -> %s", m.rate[1], m.rate[0], p->mode_frame ? "frame-granular" : "batch-granular");
+		}
+		break;
+	default:
+		if (m.count >= m.settle) { m.phase = 1; begin(); }
+		break;
+	}
+	return rc;
+}
+
 extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                                              const smhv_anchors *anchors, void *after_stream, uint32_t *slot_out) {
 	if (!p) return fail(SMHV_E_INVALID, "null pipeline");
 	CTX_OPEN(p->ctx);
 	HIPCHK(hipSetDevice(p->ctx->device));
 	const uint32_t slot = (uint32_t)(p->submitted % p->depth);
-	if (p->svc) return svc_submit(p, slot, d_frames, n, stages, grayscale, max_gap, anchors, after_stream, slot_out);
+	if (p->adaptive) { int rc = mode_control(p, n, stages, max_gap); if (rc) return rc; }
+	if (p->svc && p->mode_frame) {
+		int rc = svc_submit(p, slot, d_frames, n, stages, grayscale, max_gap, anchors, after_stream, slot_out);
+		if (!rc && p->adaptive) { p->mc.count++; p->mc.frames += n; }
+		return rc;
+	}
 	// the slot's previous submission (depth submissions ago) owns its output buffers until it has finished: this is the
 	// only place the call can wait, and only when more than `depth` submissions would be in flight
-	HIPCHK(hipEventSynchronize(p->done[slot]));
+	{ int rc = slot_wait(p, slot); if (rc) return rc; }
 	// frames the slot's previous submission gave up, if nobody waited for it: reported (logged) now, with that submission,
 	// not by some later wait with the wrong run's frame index
 	if (batch_check_errors(p->batch[slot], "pipeline_submit (the slot's previous submission, never waited for)") != SMHV_OK)
@@ -1169,7 +1308,11 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 		bb->lsd_late_kc = p->opt.late_helpers == 2u ? 0u : (p->opt.late_helpers == 1u ? 20u : (p->tune_on ? 0u : SMH_LATE_KC_SEARCH_BOUND));
 		// a sample every fourth round of the slots is plenty for a running average, and the three timed events sit in the batch's
 		// chain on its hardware queue (the hand-over before the search: 33 us with them, 14 without)
-		bb->probe = (p->submitted / p->depth) % 4u == 0u;
+		bb->probe = (p->submitted / p->depth) % 4u == 0u || (p->adaptive && p->mc.phase != 4u);
+	}
+	if (p->adaptive && !p->adapt) {                           // (a fixed policy: what the slot's last frame-granular submission changed)
+		p->batch[slot]->tune = p->tuning;
+		p->batch[slot]->lsd_late_kc = p->opt.late_helpers == 1u ? 20u : 0u;
 	}
 	hipStream_t st, sl;
 	{
@@ -1202,7 +1345,9 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(p->done[slot], sl));
 	p->last_sl[slot] = sl;
+	p->slot_frame[slot] = 0;
 	p->submitted++;
+	if (p->adaptive) { p->mc.count++; p->mc.frames += n; }
 	if (slot_out) *slot_out = slot;
 	return SMHV_OK;
 }
@@ -1210,18 +1355,14 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 extern "C" SMHV_API int smhv_pipeline_wait(smhv_pipeline *p, uint32_t slot) {
 	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_wait: bad arguments");
 	HIPCHK(hipSetDevice(p->ctx->device));
-	if (p->svc) { int rc = svc_wait_slot(p, slot); if (rc) return rc; }
-	else HIPCHK(hipEventSynchronize(p->done[slot]));
+	{ int rc = slot_wait(p, slot); if (rc) return rc; }
 	return batch_check_errors(p->batch[slot], "pipeline_wait");
 }
 
 extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
 	if (!p) return fail(SMHV_E_INVALID, "null pipeline");
 	HIPCHK(hipSetDevice(p->ctx->device));
-	for (uint32_t i = 0; i < p->depth; ++i) {
-		if (p->svc) { int r = svc_wait_slot(p, i); if (r) return r; }
-		else HIPCHK(hipEventSynchronize(p->done[i]));
-	}
+	for (uint32_t i = 0; i < p->depth; ++i) { int r = slot_wait(p, i); if (r) return r; }
 	int rc = SMHV_OK;
 	for (uint32_t i = 0; i < p->depth; ++i) {                 // every slot is checked (and cleared); the first failure is the one returned
 		std::string keep = t_last_error;
@@ -1244,6 +1385,7 @@ extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out
 	out[6] = (uint64_t)p->svc_wgs * p->svc_waves; out[7] = c.completed;
 	for (int k = 0; k < 4; ++k) out[8 + k] = c.stat_phase[k];
 	out[12] = c.stat_help;
+	out[13] = (p->adaptive ? 2u : 0u) | (p->mode_frame ? 1u : 0u) | (p->mc.phase == 4u ? 4u : 0u); out[14] = (uint64_t)p->mc.rate[1]; out[15] = (uint64_t)p->mc.rate[0];
 	return SMHV_OK;
 }
 
@@ -1277,13 +1419,13 @@ extern "C" SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void
 extern "C" SMHV_API int smhv_pipeline_slot(smhv_pipeline *p, uint32_t slot, smhv_batch **batch, void **stream) {
 	if (!p || slot >= p->depth) return fail(SMHV_E_INVALID, "pipeline_slot: bad arguments");
 	if (batch) *batch = p->batch[slot];
-	if (stream && p->svc) {
+	if (stream && p->svc && (p->slot_frame[slot] || p->stream.empty())) {
 		// frame-granular search: a submission's completion is not a point on a stream; the call waits for the slot's records
 		// on the host, after which any stream will do
 		HIPCHK(hipSetDevice(p->ctx->device));
 		int rc = svc_wait_slot(p, slot);
 		if (rc) return rc;
-		*stream = (void *)(p->slot_st[slot] ? p->slot_st[slot] : p->stream[0]);
+		*stream = (void *)(p->slot_st[slot] ? p->slot_st[slot] : p->svc_stream[0]);
 		return SMHV_OK;
 	}
 	// the stream on which the slot's most recent record kernel runs (what a consumer has to order itself after)
@@ -1884,7 +2026,7 @@ static int ingest_resolve_one(smhv_ingest *q) {
 		q->tail++; q->count++; q->n_new++;
 		return SMHV_OK;
 	}
-	HIPCHK(hipEventSynchronize(q->done[slot]));
+	HIPCHK(wait_event(q->done[slot]));
 	const uint32_t crc = q->h_acc[slot] ^ q->len_term;
 	if (crc == q->last_crc) { q->tail++; q->n_dup++; return SMHV_OK; }
 	if (q->count == q->capacity) return INGEST_FULL;
@@ -1907,7 +2049,7 @@ extern "C" SMHV_API int smhv_ingest_acquire(smhv_ingest *q, uint8_t **host_bgra)
 	}
 	const uint32_t slot = (uint32_t)(q->head % q->slots);
 	// the slot's previous device copy may still be the source of a slab append on q->s: stream order covers it
-	if (q->roi) HIPCHK(hipEventSynchronize(q->done[slot]));   // (its packed rows may still be on their way: the next frame's worker overwrites them)
+	if (q->roi) HIPCHK(wait_event(q->done[slot]));   // (its packed rows may still be on their way: the next frame's worker overwrites them)
 	*host_bgra = q->h_stage[slot];
 	q->acquired = true;
 	return SMHV_OK;
@@ -1985,7 +2127,7 @@ extern "C" SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames,
 		if (rc == INGEST_FULL) break;                         // later frames stay queued for the next slab (after reset)
 		if (rc) return rc;
 	}
-	HIPCHK(hipStreamSynchronize(q->s));                       // slab appends done: any stream may read it now
+	HIPCHK(wait_stream(q->s));                                // slab appends done: any stream may read it now
 	*d_frames = q->d_slab; *n = q->count;
 	if (last_crc) *last_crc = q->last_crc;
 	return SMHV_OK;

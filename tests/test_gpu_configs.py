@@ -452,6 +452,64 @@ def test_pipeline_object_gives_the_records_of_plain_runs(vision):
     del idle
 
 
+def test_adaptive_pipeline_measures_both_searches_and_never_changes_a_record(vision):
+    """SMHV_SEARCH_AUTO at depth 8: the pipeline runs its submissions through the frame-granular search service first, then
+    through the batch-granular search, times a window of each and keeps the faster; submissions of both kinds are in flight
+    together around every switch.  260 submissions of three alternating frame sets: every one's records equal those of a
+    plain smhv_batch_run, whatever search it went to; afterwards the pipeline has settled and has a rate for both.  A change
+    of the submissions' shape (stages) starts the measurement again."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H, N, depth = 1920, 1080, 16, 8
+    sets = []
+    for k in range(3):
+        fr, inf = synth.make_batch(W, H, N, first_idx=9500 + 100 * k, n_lines=1 + 2 * k)
+        sets.append((torch.from_numpy(fr).cuda(), smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in inf])))
+    fb = smh.FrameBatch(vision, W, H, N)
+    want, want3 = [], []
+    for d, a in sets:
+        fb.run(d.data_ptr(), N, anchors=a, stream=torch.cuda.current_stream().cuda_stream)
+        want.append(bytes(fb.read_results(0, N)))
+        fb.run(d.data_ptr(), N, stages=0x3, stream=torch.cuda.current_stream().cuda_stream)
+        want3.append(bytes(fb.read_results(0, N)))
+    fb.close()
+    pipe = smh.Pipeline(vision, W, H, N, depth)
+    st0 = pipe.search_stats()
+    assert st0["adaptive"] and not st0["settled"] and st0["mode"] == "frame-granular"
+    inflight = []
+
+    def push(k, stages, expect):
+        slot = pipe.submit(sets[k][0].data_ptr(), N, stages=stages, anchors=sets[k][1] if stages & 8 else None)
+        inflight.append((slot, expect[k]))
+        if len(inflight) == depth:                                  # the oldest submission still in flight: check it before its slot is reused
+            s_old, w_old = inflight.pop(0)
+            pipe.wait(s_old)
+            assert bytes(pipe.slots[s_old].read_results(0, N)) == w_old
+
+    for j in range(26 * depth + 52):
+        push((j * 7 + j // 5) % 3, 0xF, want)
+    st = pipe.search_stats()
+    assert st["settled"] and st["launches"] >= 1 and min(st["measured_frames_per_s"].values()) > 0, st
+    for j in range(3 * depth):                                      # another shape: the measurement starts again
+        push(j % 3, 0x3, want3)
+    assert not pipe.search_stats()["settled"]
+    while inflight:
+        s_old, w_old = inflight.pop(0)
+        pipe.wait(s_old)
+        assert bytes(pipe.slots[s_old].read_results(0, N)) == w_old
+    pipe.close()
+    # a pinned schedule does not measure anything
+    for mode in ("batch", "frame"):
+        pipe = smh.Pipeline(vision, W, H, N, depth, search=mode)
+        for j in range(2 * depth):
+            pipe.submit(sets[0][0].data_ptr(), N, anchors=sets[0][1])
+        pipe.wait()
+        st = pipe.search_stats()
+        assert (st is None) if mode == "batch" else (not st["adaptive"] and st["mode"] == "frame-granular")
+        pipe.close()
+
+
 def _oracle_batch(frames, infos, stages=0xF):
     k = len(frames)
     a9 = np.zeros((k, 3, 3), np.uint32)

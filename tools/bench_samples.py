@@ -30,19 +30,38 @@ def main():
     batch = np.stack([frames[i % k] for i in range(n)])
     vision = smh.HipVision.init(0)
     depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth)
-    d = torch.from_numpy(batch).cuda()
+    search = os.environ.get("SAMPLES_SEARCH", "auto")
+    if os.environ.get("SAMPLES_TOUCH_FIRST"):
+        torch.zeros(int(os.environ["SAMPLES_TOUCH_FIRST"]), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+    if os.environ.get("SAMPLES_FRAMES_FIRST"):
+        d = torch.from_numpy(batch).cuda()
+    pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth, search=search)
+    if not os.environ.get("SAMPLES_FRAMES_FIRST"):
+        d = torch.from_numpy(batch).cuda()
     torch.cuda.synchronize()
-    for i in range(2 * depth):
-        pipe.submit(d.data_ptr(), n, stages=STAGES, max_gap=15)
-    pipe.wait()
-    steps = 40
+    # warm: a GPU that comes out of idle needs a few hundred milliseconds to reach its clocks (40 cold steps measured 107 k
+    # frames/s where the same pipeline runs at 190 k once warm)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < float(os.environ.get("SAMPLES_WARM_S", "1.0")):
+        for i in range(2 * depth):
+            pipe.submit(d.data_ptr(), n, stages=STAGES, max_gap=15)
+        pipe.wait()
+    steps = int(os.environ.get("SAMPLES_STEPS", "400"))
     t0 = time.perf_counter()
+    stamps = []
     for i in range(steps):
         slot = pipe.submit(d.data_ptr(), n, stages=STAGES, max_gap=15)
+        stamps.append(time.perf_counter())
     pipe.wait()
     dt = time.perf_counter() - t0
+    if os.environ.get("RATE_TIMELINE"):
+        w = depth
+        print("[timeline] k frames/s per %d submissions: %s" % (w, " ".join("%d" % (n * w / 1e3 / (stamps[i + w] - stamps[i])) for i in range(0, len(stamps) - w, w))), file=sys.stderr, flush=True)
     got = smh.results_to_dicts(pipe.slots[slot].read_results(0, n))
+    pipe_stats = pipe.search_stats()
+    if pipe_stats:
+        pipe_stats = {k: pipe_stats[k] for k in ("launches", "frames", "busy_fraction", "cycles_per_frame", "help_cycles_per_frame", "adaptive", "mode", "measured_frames_per_s") if k in pipe_stats}
     t1 = time.perf_counter()
     ref = orc.process_batch(np.stack(frames), min(os.cpu_count() or 1, k), stages=STAGES, max_gap=15)
     cdt = time.perf_counter() - t1
@@ -58,7 +77,7 @@ def main():
     import json
     print(json.dumps({"metric": "map frames/sec (2560x1440 sample screenshots, stages 0x%x), one GPU" % STAGES, "value": n * steps / dt, "unit": "frames/s",
                       "ms_per_step": dt / steps * 1e3, "config": {"workload": "%d distinct 2560x1440 frames rebuilt from tests/golden, cycled through a batch of %d" % (k, n),
-                                                                "batch": n, "pipeline_depth": depth, "stages": STAGES},
+                                                                "batch": n, "pipeline_depth": depth, "search": search, "search_service": pipe_stats, "stages": STAGES},
                       "rounds_per_frame": [int(r.rounds) for r in ref], "records_equal_oracle": bool(ok),
                       "cpu_oracle_frames_per_s": k / cdt, "cpu_threads": min(os.cpu_count() or 1, k), "data": "the reference's sample screenshots"}))
     sys.exit(0 if ok else 1)

@@ -64,6 +64,7 @@ if timing:
         b.enable_timing(True)
 t0 = time.perf_counter()
 slow = []
+stamps = []
 for k in range(passes):
     t1 = time.perf_counter()
     slot = pipe.submit(d.data_ptr(), N, stages=stages, anchors=anchors)
@@ -71,11 +72,15 @@ for k in range(passes):
         pipe.wait(slot)                                    # (counter profiling: rocprofv3 --pmc runs one kernel at a time)
         torch.cuda.synchronize()
     t2 = time.perf_counter()
+    stamps.append(t2)
     if t2 - t1 > 0.03 and not SYNC:
         slow.append((k, round((t2 - t1) * 1e3, 1), pipe.peek()))
 pipe.wait()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if _env("RATE_TIMELINE"):
+    w = depth
+    print("[timeline] k frames/s per %d submissions: %s" % (w, " ".join("%d" % (N * w / 1e3 / (stamps[i + w] - stamps[i])) for i in range(0, len(stamps) - w, w))), file=sys.stderr, flush=True)
 for k, ms, pk in slow[:6]:
     print("[slow submit %d: %.1f ms] %s" % (k, ms, pk), file=sys.stderr, flush=True)
 stage_ms = None
