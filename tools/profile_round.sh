@@ -12,11 +12,11 @@ R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back"   # profiled runs: only warm-up, timed and isolated passes
+B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back --no-real-samples"   # profiled runs: only warm-up, timed and isolated passes
 for C in 2 3; do
   P=""; [ $C = 3 ] && P="c3_"
   for D in 1 4 12; do
-    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${P}d$D -- $B --config $C --steps 3 --warmup 1 --pipeline-depth $D > $OUT/${TAG}_${P}bench_profiled_d$D.json 2>/dev/null
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${P}d$D -- $B --config $C --steps 20 --warmup 1 --pipeline-depth $D > $OUT/${TAG}_${P}bench_profiled_d$D.json 2>/dev/null
   done
   # (the counter passes run at depth 1: with --pmc the profiler runs one kernel at a time, which a long-lived service kernel
   #  beside the streaming passes cannot live with -- it would idle out between any two passes)

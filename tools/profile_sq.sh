@@ -5,7 +5,7 @@ set -u
 TAG=${1:-rXX}
 R=$(pwd); OUT=$R/gpurun_out; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back --steps 1 --warmup 1 --rounds-per-step 2 --pipeline-depth ${PDEPTH:-1}"
+B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back --no-real-samples --steps 1 --warmup 1 --rounds-per-step 2 --pipeline-depth ${PDEPTH:-1}"
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/prof_${TAG}_sq1 -- $B > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/prof_${TAG}_sq2 -- $B > /dev/null 2>&1
 cd $R
