@@ -931,10 +931,11 @@ def main():
                       "ray_steps_per_s": (n * ray_steps / t_lsd) if t_lsd > 0 else None,
                       "time_share": stages_ms["lsd"] / max(sum(stages_ms.values()), 1e-9)}
 
-    if not args.no_real_samples and world == 1 and args.config == 2 and not custom:
-        out["real_samples"] = real_samples_leg(smh, torch, vision, depth)
     if args.ingest_frames > 0 and world == 1 and args.config == 2 and not custom:
         out["ingest"] = ingest_leg(smh, torch, vision, pipe, frames_host, anchors, stages, args.ingest_frames, W, H, n)
+    pipe.close()                                           # (its streams hold hardware queues the next leg's pipelines should get)
+    if not args.no_real_samples and world == 1 and args.config == 2 and not custom:
+        out["real_samples"] = real_samples_leg(smh, torch, vision, depth)
 
     if args.cpu_sample > 0 and world == 1:
         from oracle import oracle as orc   # CPU baseline leg only (checker, never the product path)
@@ -965,7 +966,6 @@ def main():
         if not same:
             emit(out)
             raise SystemExit("bench.py: GPU records differ from the CPU oracle on the sampled frames")
-    pipe.close()
     if world > 1:
         dist.destroy_process_group()
     emit(out)

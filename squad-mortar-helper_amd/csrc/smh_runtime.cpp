@@ -856,6 +856,7 @@ extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t
 // ------------------------------------------------------------------------------------------------
 // pipeline: `depth` batches in flight, each on its own stream; the library owns the schedule
 // ------------------------------------------------------------------------------------------------
+static std::atomic<int> g_own_queues{0};   // streams with a hardware queue of their own, all pipelines of the process (pipeline_create_impl)
 struct smhv_pipeline {
 	smhv_ctx *ctx = nullptr;
 	uint32_t depth = 0;
@@ -907,6 +908,7 @@ struct smhv_pipeline {
 	std::vector<hipStream_t> svc_stream;   // the streaming streams of frame-granular submissions (stream[]: one per slot, batch-granular)
 	std::vector<uint8_t> slot_frame;       // per slot: its most recent submission went to the service
 	bool adaptive = false, mode_frame = false;
+	uint32_t own_queues = 0;               // streams of this pipeline that were given a hardware queue of their own
 	struct ModeCtl {
 		uint32_t phase = 0, count = 0, settle = 0, key_n = 0, key_stages = 0, key_gap = 0, decisions = 0;
 		uint64_t frames = 0;
@@ -936,6 +938,7 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (p->ev_after) (void)hipEventDestroy(p->ev_after);
 	for (auto st : p->stream) if (st) (void)hipStreamDestroy(st);
 	for (auto st : p->svc_stream) if (st) (void)hipStreamDestroy(st);
+	g_own_queues.fetch_sub((int)p->own_queues, std::memory_order_relaxed);
 	if (p->s_search) (void)hipStreamDestroy(p->s_search);
 	if (p->s_pro) (void)hipStreamDestroy(p->s_pro);
 	for (auto e : p->ev_pub) if (e) (void)hipEventDestroy(e);
@@ -980,6 +983,7 @@ static LaunchTuning pipeline_tuning(const Geom &g) {
 // that the batch-granular search with its occupancy policy is ahead (depth 4: 435 k against 275 k).
 #define SMH_SVC_AUTO_DEPTH 8u
 #define SMH_OWN_QUEUES 16u
+#define SMH_OWN_QUEUES_PROCESS 20u
 static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, const smhv_pipeline_options *opt_in, smhv_pipeline **out) {
 	if (!c || !out || max_frames == 0 || depth == 0 || depth > SVC_MAX_SLOTS) return fail(SMHV_E_INVALID, "pipeline_create: bad arguments (depth 1..%u)", SVC_MAX_SLOTS);
 	*out = nullptr;
@@ -1027,16 +1031,24 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		const uint32_t ns = (!p->svc || p->adaptive) ? depth : 0u;   // one stream per slot for batch-granular submissions
 		const uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
 		p->stream.assign(ns, nullptr);
-		// (a budget of SMH_OWN_QUEUES queues per pipeline, the service's four included: with 21 queues of one process the
-		// hardware scheduler started to time-slice them -- stalls of 80 ms in the kernel trace of a depth-16 pipeline)
-		const uint32_t own = SMH_OWN_QUEUES - (p->svc ? p->svc_streams + 2u : 0u);
-		for (uint32_t i = 0; i < ns && e == hipSuccess; ++i) e = create_stream(&p->stream[i], i < own ? full : nullptr);
-		if (p->svc && e == hipSuccess) {
+		// (a budget: SMH_OWN_QUEUES queues per pipeline, the service's included, and SMH_OWN_QUEUES_PROCESS for all pipelines
+		// of the process that are alive -- with 21 queues the hardware scheduler started to time-slice them: stalls of 80 ms
+		// in the kernel trace of a depth-16 pipeline, and a second 16-queue pipeline beside the first ran at half its rate.
+		// Streams beyond the budget are ordinary ones; the search kernel's stream always has its own queue.)
+		auto own_queue = [p]() {
+			if (p->own_queues >= SMH_OWN_QUEUES) return false;
+			if (g_own_queues.fetch_add(1, std::memory_order_relaxed) >= (int)SMH_OWN_QUEUES_PROCESS) { g_own_queues.fetch_sub(1, std::memory_order_relaxed); return false; }
+			p->own_queues++;
+			return true;
+		};
+		if (p->svc) {
 			p->svc_stream.assign(p->svc_streams, nullptr);
-			for (uint32_t i = 0; i < p->svc_streams && e == hipSuccess; ++i) e = create_stream(&p->svc_stream[i], full);
-			if (e == hipSuccess) e = create_stream(&p->s_search, full);
-			if (e == hipSuccess && !(opt.flags & SMHV_PIPE_NO_PROLOGUE)) e = create_stream(&p->s_pro, full);
+			(void)own_queue();
+			e = create_stream(&p->s_search, full);
+			for (uint32_t i = 0; i < p->svc_streams && e == hipSuccess; ++i) e = create_stream(&p->svc_stream[i], own_queue() ? full : nullptr);
+			if (e == hipSuccess && !(opt.flags & SMHV_PIPE_NO_PROLOGUE)) e = create_stream(&p->s_pro, own_queue() ? full : nullptr);
 		}
+		for (uint32_t i = 0; i < ns && e == hipSuccess; ++i) e = create_stream(&p->stream[i], own_queue() ? full : nullptr);
 	}
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming);
 	for (uint32_t i = 0; i < depth && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
@@ -1226,8 +1238,9 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 //            measures the ramps: a batch-granular pipeline restarts staggered, one streaming pass after the other.
 //   phase 2  the other mode, warm-up (6 depth submissions: the other search's submissions drain, and a batch-granular pipeline
 //            also has to find its occupancy policy)
-//   phase 3  measure it the same way -> rate[other]; keep the faster mode (the service has to be 3 % ahead: it occupies the
-//            device while idle, so a tie -- a host that submits slower than either search runs -- goes to the batch-granular search)
+//   phase 3  measure it the same way -> rate[other]; keep the faster mode (the batch-granular search has to be 3 % ahead: on a
+//            tie -- a host that submits slower than either search runs, batches of one frame -- the service is the cheaper
+//            one for the host, one small publication kernel per submission instead of a search launch)
 //   phase 4  settled for SMH_MODE_RECHECK submissions, or until the submissions change shape (frames, stages, gap threshold)
 #define SMH_MODE_RECHECK 16384u
 static int mode_control(smhv_pipeline *p, uint32_t n, uint32_t stages, uint32_t max_gap) {
@@ -1256,7 +1269,7 @@ static int mode_control(smhv_pipeline *p, uint32_t n, uint32_t stages, uint32_t 
 	case 3:
 		if (m.count >= W) {
 			m.rate[p->mode_frame ? 1 : 0] = rate();
-			p->mode_frame = m.rate[1] > 1.03 * m.rate[0];
+			p->mode_frame = !(m.rate[0] > 1.03 * m.rate[1]);
 			m.decisions++;
 			m.phase = 4; m.count = 0; m.settle = SMH_MODE_RECHECK;
 			logf(p->ctx, 3, "pipeline: frame-granular search %.0f frames/s, batch-granular %.0f -> %s", m.rate[1], m.rate[0], p->mode_frame ? "frame-granular" : "batch-granular");
