@@ -884,33 +884,43 @@ def main():
                 pst = [torch.cuda.Stream() for _ in pc]
                 pat_bytes = n * (2 * rw * rh * 4 + rw * rh + 2 * (rw // 2) * (rh // 2))       # algorithmic bytes of the copy (no halo rows)
                 try:
-                    for fbk, stk in zip(pc, pst):
-                        smh._lib.check(lib.smhv_debug_pattern_copy(fbk._b, fptr, n, stk.cuda_stream))
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    with torch.cuda.stream(pst[0]):
-                        e0.record()
-                        for _ in range(10):
-                            smh._lib.check(lib.smhv_debug_pattern_copy(pc[0]._b, fptr, n, pst[0].cuda_stream))
-                        e1.record()
-                    torch.cuda.synchronize()
-                    alone_ms = e0.elapsed_time(e1) / 10
-                    t0 = time.perf_counter()
-                    for _ in range(8):
+                    best = None
+                    variants = {}
+                    for rows in (4, 8, 12):                          # loads in flight per thread (the pass itself: 12)
                         for fbk, stk in zip(pc, pst):
-                            smh._lib.check(lib.smhv_debug_pattern_copy(fbk._b, fptr, n, stk.cuda_stream))
-                    torch.cuda.synchronize()
-                    b2b = (time.perf_counter() - t0) * 1e3 / 32
+                            smh._lib.check(lib.smhv_debug_pattern_copy(fbk._b, fptr, n, rows, stk.cuda_stream))
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        with torch.cuda.stream(pst[0]):
+                            e0.record()
+                            for _ in range(10):
+                                smh._lib.check(lib.smhv_debug_pattern_copy(pc[0]._b, fptr, n, rows, pst[0].cuda_stream))
+                            e1.record()
+                        torch.cuda.synchronize()
+                        a_ms = e0.elapsed_time(e1) / 10
+                        t0 = time.perf_counter()
+                        for _ in range(8):
+                            for fbk, stk in zip(pc, pst):
+                                smh._lib.check(lib.smhv_debug_pattern_copy(fbk._b, fptr, n, rows, stk.cuda_stream))
+                        torch.cuda.synchronize()
+                        bb = (time.perf_counter() - t0) * 1e3 / 32
+                        variants[str(rows)] = {"alone_GBps": pat_bytes / (a_ms * 1e-3) / 1e9, "back_to_back_GBps": pat_bytes / (bb * 1e-3) / 1e9}
+                        if best is None or a_ms < best[0]:
+                            best = (a_ms, rows)
+                    alone_ms = best[0]
+                    b2b = pat_bytes / max(v["back_to_back_GBps"] for v in variants.values()) / 1e9 * 1e3
                     ri = out["roofline_isolated"]
                     ri["pattern_copy_GBps"] = pat_bytes / (alone_ms * 1e-3) / 1e9
                     ri["pattern_copy_ms"] = alone_ms
                     ri["pattern_copy_back_to_back_GBps"] = pat_bytes / (b2b * 1e-3) / 1e9
                     ri["pattern_copy_bytes"] = pat_bytes
+                    ri["pattern_copy_variants"] = variants
                     ri["frac_of_pattern_copy"] = (n * kernel_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9) / ri["pattern_copy_GBps"]
                     if b2b_ms is not None:
                         ri["back_to_back"]["frac_of_pattern_copy_back_to_back"] = (n * kernel_bytes / (b2b_ms * 1e-3) / 1e9) / ri["pattern_copy_back_to_back_GBps"]
-                    ri["pattern_copy_what"] = ("k_pattern_copy: one launch after the other on one stream (hipEvents) / four streams back to back (wall clock); "
-                                               "its bytes are the pass's algorithmic bytes (no halo rows)")
+                    ri["pattern_copy_what"] = ("k_pattern_copy, the best of 4 / 8 / 12 rows in flight per thread (pattern_copy_variants; the pass holds 12): one launch "
+                                               "after the other on one stream (hipEvents) / four streams back to back (wall clock); its bytes are the pass's "
+                                               "algorithmic bytes (no halo rows)")
                 finally:
                     for fbk in pc:
                         fbk.close()

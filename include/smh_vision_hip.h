@@ -244,9 +244,10 @@ SMHV_API int smhv_debug_lsd_tile_cap(uint32_t cap);
 SMHV_API int smhv_debug_lsd_threads(uint32_t threads);
 /* calibration: the fused streaming pass's memory traffic without its arithmetic -- every quad of the map ROI of n resident frames
  * read once (16-byte loads out of the full-width frame rows), ui_map / mask / ocr / scales rows of the batch written with the
- * pass's own store widths and pitches (their contents are garbage afterwards).  Asynchronous on `stream`.  Its rate is what the
- * memory system gives this access pattern; bench.py reports it beside the pass (roofline_isolated.pattern_copy_GBps). */
-SMHV_API int smhv_debug_pattern_copy(smhv_batch *b, const void *d_frames, uint32_t n, void *stream);
+ * pass's own store widths and pitches (their contents are garbage afterwards).  Asynchronous on `stream`.  rows_in_flight: loads
+ * a thread issues before it stores (0 = 4, 4, 8, 12; the pass itself: 12).  Its rate is what the memory system gives this
+ * access pattern; bench.py reports the best variant beside the pass (roofline_isolated.pattern_copy_GBps). */
+SMHV_API int smhv_debug_pattern_copy(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t rows_in_flight, void *stream);
 /* diagnostic (process-wide): batched runs launch everything but the line search, so that the streaming
  * pass can be timed back to back with itself (bench.py, roofline_isolated.back_to_back).  The records of such a run hold no
  * valid lines. */

@@ -115,7 +115,7 @@ SIGNATURES = {
     "smhv_debug_lsd_spin_limit": (C.c_int, [C.c_uint32]),
     "smhv_debug_lsd_threads": (C.c_int, [C.c_uint32]),
     "smhv_debug_skip_line_search": (C.c_int, [C.c_int]),
-    "smhv_debug_pattern_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "smhv_debug_pattern_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "smhv_ingest_create_ex": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),

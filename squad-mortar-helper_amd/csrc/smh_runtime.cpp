@@ -739,12 +739,13 @@ extern "C" SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint
 	return batch_run_impl(b, d_frames, n, stages, grayscale, max_gap, anchors, (hipStream_t)stream, (hipStream_t)stream);
 }
 
-extern "C" SMHV_API int smhv_debug_pattern_copy(smhv_batch *b, const void *d_frames, uint32_t n, void *stream) {
-	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+extern "C" SMHV_API int smhv_debug_pattern_copy(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t rows_in_flight, void *stream) {
+	if (!b || !d_frames || n == 0 || n > b->max_frames || (rows_in_flight != 0u && rows_in_flight != 4u && rows_in_flight != 8u && rows_in_flight != 12u))
+		return fail(SMHV_E_INVALID, "bad arguments (rows in flight: 0 = 4, 4, 8, 12)");
 	CTX_OPEN(b->ctx);
 	HIPCHK(hipSetDevice(b->ctx->device));
 	const Buffers bf = make_buffers(b, (const uint8_t *)d_frames, 0);
-	HIPCHK(launch_pattern_copy(b->g, bf, n, (hipStream_t)stream));
+	HIPCHK(launch_pattern_copy(b->g, bf, n, rows_in_flight, (hipStream_t)stream));
 	return SMHV_OK;
 }
 

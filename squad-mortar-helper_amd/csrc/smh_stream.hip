@@ -887,8 +887,10 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 // quad is read once with a 16-byte load out of the 1920-px-pitch frame (986 of 1920 pixels of a row at 1080p), 16 bytes go to
 // the ui_map row, 4 to the mask row, and inside the bottom-right quadrant 4 each to the ocr and scales rows: per 256 1080p
 // frames 0.83 GB read and 1.14 GB written (the pass reads 0.95 GB: two halo rows per band on top).  What is stored is a
-// cheap function of what was loaded, so that no load can be dropped.
+// cheap function of what was loaded, so that no load can be dropped.  NR = rows a thread has in flight (the pass: three sets of
+// four = 12); the bench line quotes the best of 4 / 8 / 12.
 // ------------------------------------------------------------------------------------------------
+template <int NR>
 __global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b) {
 	const uint32_t f = blockIdx.y, q = threadIdx.x;
 	const int r0 = (int)(blockIdx.x * MAPQ_RB_MAX), r1 = min(r0 + MAPQ_RB_MAX, (int)g.rh);
@@ -902,12 +904,12 @@ __global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b) {
 	uint8_t *op = b.ocr + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
 	uint8_t *sp = b.scales + (size_t)f * g.ocr_stride + (size_t)(in_q ? qq : 0) * 4;
 	const size_t row_bytes = (size_t)g.W * 4;
-	for (int r = r0; r < r1; r += 4) {
-		uint4 v[4];
+	for (int r = r0; r < r1; r += NR) {
+		uint4 v[NR];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) v[k] = *(const uint4 *)(fp + (size_t)min(r + k, r1 - 1) * row_bytes);
+		for (int k = 0; k < NR; ++k) v[k] = *(const uint4 *)(fp + (size_t)min(r + k, r1 - 1) * row_bytes);
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
+		for (int k = 0; k < NR; ++k) {
 			const int row = r + k;
 			if (row >= r1) break;
 			*(uint4 *)(up + (size_t)row * g.ui_pitch) = v[k];
@@ -922,8 +924,14 @@ __global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b) {
 	}
 }
 
-hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, hipStream_t s) {
-	hipLaunchKernelGGL(k_pattern_copy, dim3((g.rh + MAPQ_RB_MAX - 1) / MAPQ_RB_MAX, n), dim3(g.m_block), 0, s, g, b);
+hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, uint32_t rows_in_flight, hipStream_t s) {
+	const dim3 grid((g.rh + MAPQ_RB_MAX - 1) / MAPQ_RB_MAX, n), block(g.m_block);
+	switch (rows_in_flight) {
+	case 0: case 4: hipLaunchKernelGGL(k_pattern_copy<4>, grid, block, 0, s, g, b); break;
+	case 8: hipLaunchKernelGGL(k_pattern_copy<8>, grid, block, 0, s, g, b); break;
+	case 12: hipLaunchKernelGGL(k_pattern_copy<12>, grid, block, 0, s, g, b); break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }
 

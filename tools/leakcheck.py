@@ -1,7 +1,7 @@
 """Leak check (diagnostic): init / trait path / batch path with many gap thresholds / ingest queue / shutdown, six times over;
 prints the change in free device memory after each cycle (it must level off)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import squad_mortar_helper_amd as smh
 from squad_mortar_helper_amd import synth
@@ -23,7 +23,19 @@ for cycle in range(6):
         for i in range(8):
             b = q.acquire(); b[...] = frame; b[0, 0, 0] = i; q.commit()
         q.batch(); q.close()
+        q = smh.IngestQueue(v, W, H, slots=4, capacity=8, roi_upload=True)   # worker threads, packed staging buffers
+        for i in range(12):
+            b = q.acquire(); b[...] = frame; b[0, 0, 0] = i // 2; q.commit()
+        assert q.batch()[1] == 6
+        q.close()
+        for depth, kw in ((4, {}), (12, {}), (8, dict(search="frame")), (16, dict(search="batch"))):   # streams with queues of their own, both searches
+            pipe = smh.Pipeline(v, W, H, 16, depth, **kw)
+            for i in range(3 * depth):
+                pipe.submit(d.data_ptr(), 16)
+            pipe.wait(); pipe.close()
         del fb, d, q
     v.shutdown()
     torch.cuda.synchronize(); torch.cuda.empty_cache()
-    print("cycle %d: free memory delta %.1f MB" % (cycle, (free0 - torch.cuda.mem_get_info()[0]) / 1e6), flush=True)
+    import threading
+    fds = len(os.listdir("/proc/self/fd"))
+    print("cycle %d: free memory delta %.1f MB, %d threads, %d file descriptors" % (cycle, (free0 - torch.cuda.mem_get_info()[0]) / 1e6, len(os.listdir("/proc/self/task")), fds), flush=True)
