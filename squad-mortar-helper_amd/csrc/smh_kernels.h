@@ -272,7 +272,7 @@ hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
 hipError_t launch_build_ray_offsets(float *d_off, hipStream_t s);   // 3600 x (SMH_RAY_OFF_BATCHES + 1) float2
 size_t lsd_lds_bytes();
-// diagnostic: find_lines on the workgroup-synchronous k_lsd for every frame instead of k_lsd_tile (also SMH_LSD_KERNEL=classic)
+// diagnostic: find_lines on the workgroup-synchronous k_lsd for every frame instead of k_lsd_tile 
 void lsd_set_classic(bool on);
 // diagnostic: cap the tile store of k_lsd_tile (0 = what fits), to exercise the path of frames with more tiles than that
 void lsd_set_tile_cap(uint32_t cap);

@@ -1390,7 +1390,7 @@ hipError_t launch_lsd(const Geom &g, const Buffers &b, uint32_t n, float max_gap
 	const bool coop = mode == 0 && b.co.ctl != nullptr;
 	// find_lines has two implementations: the task-based k_lsd_tile (default: any frame size, two frames per CU) and the
 	// workgroup-synchronous k_lsd (with helper workgroups when the batch asks for them, for Vision::find_longest_line, and
-	// on request: smhv_debug_lsd_classic / SMH_LSD_KERNEL=classic).
+	// on request: smhv_debug_lsd_classic).
 	if (mode == 0 && !coop && !prefer_classic && !lsd_classic_flag().load(std::memory_order_relaxed)) {
 		const uint32_t bs_o = g_bs_override.load(std::memory_order_relaxed);
 		const uint32_t bs = std::max<uint32_t>(128u, bs_o ? bs_o : (tile_bs ? std::min<uint32_t>(tile_bs, LSD_TILE_BS) : 512u));

@@ -613,7 +613,7 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 }
 
 // s: the streaming kernels (button test, the fused map / quadrant pass); sl: the line-segment search and the record kernel.
-// sl == s for a plain smhv_batch_run; a pipeline with partitioned CUs passes two streams (sl waits for the streaming pass).
+// sl == s for a plain smhv_batch_run and for every pipeline (sl != s: the line search on a stream of its own, waiting for the streaming pass).
 // svc != null: the batch belongs to a pipeline with a frame-granular search service (smh_kernels.h): the streaming side ends
 // with the publication of the frames, and the service's waves search them and write their records.
 // s_pro: the pipeline's prologue stream -- the anchor upload and the button test of a submission run there, ahead of time, so
@@ -2028,7 +2028,11 @@ static int ingest_resolve_one(smhv_ingest *q) {
 			q->cv_done.wait(lk, [q, slot] { return q->crc_state[slot] == 2; });
 			crc = q->h_crc[slot];
 		}
-		if (crc == q->last_crc) { q->crc_state[slot] = 0; q->tail++; q->n_dup++; return SMHV_OK; }   // nothing was uploaded
+		if (crc == q->last_crc) {                                // nothing was uploaded
+			{ std::lock_guard<std::mutex> lk(q->mu); q->crc_state[slot] = 0; }
+			q->tail++; q->n_dup++;
+			return SMHV_OK;
+		}
 		if (q->count == q->capacity) return INGEST_FULL;
 		q->last_crc = crc;
 		const Geom &g = q->g;
@@ -2036,7 +2040,7 @@ static int ingest_resolve_one(smhv_ingest *q) {
 		HIPCHK(hipMemcpyAsync(q->d_pack[slot], q->h_pack[slot], q->pack_bytes, hipMemcpyHostToDevice, q->s));
 		HIPCHK(launch_unpack_rows(q->d_pack[slot], dst, g.W, g.m_ax, g.ry, (uint32_t)(q->roi_row_bytes / 4), g.rh, g.bx, g.by, g.bw, g.bh, q->s));
 		HIPCHK(hipEventRecord(q->done[slot], q->s));             // the slot's pack buffers are free again when this has passed
-		q->crc_state[slot] = 0;
+		{ std::lock_guard<std::mutex> lk(q->mu); q->crc_state[slot] = 0; }
 		q->tail++; q->count++; q->n_new++;
 		return SMHV_OK;
 	}
