@@ -2,13 +2,14 @@
 # tools/profile_sq_service.sh <tag> -- run ON THE GPU BOX: SQ counters of the frame-granular search service's kernel.  rocprofv3
 # --pmc runs one kernel at a time, and k_lsd_service lives beside the streaming passes: the driver (tools/svc_rate.py,
 # RATE_SYNC=1) therefore waits for every submission before the next, so that each launch of the service searches one batch
-# ALONE and closes (what the counters then show is the scan itself, without the streaming pass on the same CUs).
+# ALONE and closes (what the counters then show is the scan itself, without the streaming pass on the same CUs).  1024 frames per
+# submission = one per resident wave of the service (256 workgroups x 4): with fewer, most waves only sleep between polls.
 set -u
 TAG=${1:-rXX}
 R=$(pwd); OUT=$R/gpurun_out; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export RATE_SYNC=1 RATE_SEARCH=frame
-B="python3 $R/tools/svc_rate.py 256 3 6"
+B="python3 $R/tools/svc_rate.py 1024 3 4"
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/prof_${TAG}_svc_sq1 -- $B > $OUT/${TAG}_svc_sq1.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/prof_${TAG}_svc_sq2 -- $B > $OUT/${TAG}_svc_sq2.log 2>&1
 cd $R
@@ -22,7 +23,7 @@ for sub in ("svc_sq1", "svc_sq2"):
     for f in glob.glob(os.path.join("gpurun_out", "prof_%s_%s" % (tag, sub), "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f, newline="")):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-lines = ["%s: tools/svc_rate.py 256 3 6, RATE_SEARCH=frame RATE_SYNC=1 (one submission at a time), 256 x 1080p; rocprofv3 --pmc (two passes), mean per dispatch" % tag]
+lines = ["%s: tools/svc_rate.py 1024 3 4, RATE_SEARCH=frame RATE_SYNC=1 (one submission at a time, one frame per resident wave), 1024 x 1080p; rocprofv3 --pmc (two passes), mean per dispatch" % tag]
 for k in sorted(acc):
     if "smh::" not in k:
         continue
