@@ -34,10 +34,23 @@ def main():
         t1 = time.time()
         fb = smh.FrameBatch(vision, W, H, n)
         d = torch.from_numpy(frames).cuda()
+        # FUZZ_SERVICE=1: through the frame-granular search service of a pipeline (one wave per frame + the workgroup help desk;
+        # several submissions in flight so that waves are helping while others start) instead of the plain batch path
+        service = bool(os.environ.get("FUZZ_SERVICE"))
+        pipe = smh.Pipeline(vision, W, H, n, 3, search="frame") if service else None
         for exact in (0, smh.STAGE_EXACT_STATS):
-            fb.run(d.data_ptr(), n, stages=0x1 | exact, max_gap=max_gap)
-            torch.cuda.synchronize()
-            got = smh.results_to_dicts(fb.read_results(0, n))
+            if service:
+                slots = [pipe.submit(d.data_ptr(), n, stages=0x1 | exact, max_gap=max_gap) for _ in range(3)]
+                pipe.wait()
+                recs = [bytes(pipe.slots[s_].read_results(0, n)) for s_ in slots]
+                if len(set(recs)) != 1:
+                    bad += 1
+                    print("MISMATCH iter %d: the three submissions of the same frames hold different records" % it)
+                got = smh.results_to_dicts(pipe.slots[slots[0]].read_results(0, n))
+            else:
+                fb.run(d.data_ptr(), n, stages=0x1 | exact, max_gap=max_gap)
+                torch.cuda.synchronize()
+                got = smh.results_to_dicts(fb.read_results(0, n))
             for i in range(n):
                 rl = np.array([[ref[i].lines[k][j] for j in range(4)] for k in range(ref[i].n_lines)], np.float32).reshape(-1, 4)
                 same = got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], rl) and got[i]["rounds"] == ref[i].rounds
@@ -50,6 +63,8 @@ def main():
                     np.save("gpurun_out/fuzz_bad_%d_%d.npy" % (it, i), frames[i])
         print("iter %d: %d frames %dx%d max_gap %d, oracle %.1f s, rounds/frame %.1f, lines/frame %.1f, mismatches so far %d" % (
             it, n, W, H, max_gap, t1 - t0, np.mean([r.rounds for r in ref]), np.mean([r.n_lines for r in ref]), bad), flush=True)
+        if pipe is not None:
+            pipe.close()
         del fb, d
     print("FUZZ %s" % ("OK" if bad == 0 else "FAILED (%d)" % bad))
     sys.exit(1 if bad else 0)
