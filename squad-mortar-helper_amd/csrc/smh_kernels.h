@@ -95,6 +95,7 @@ struct BatchError {
 #define SMH_FARM_RING 4u
 #define SMH_REC_ON 0x80000000u
 #define SMH_LSD_LATE_HELP 1u
+#define SMH_LSD_NO_TEAM_HELP 2u         // frame-granular search: the frames of this submission do not ask their workgroup for help
 struct FarmEntry {                  // 64 bytes
 	unsigned long long post;        // owner -> helper: epoch16 << 48 | (k + 1)24 << 24 | py12 << 12 | px12   (k = posts so far)
 	unsigned long long best;        // helper -> owner: max over rays of (len^2 bits << 32 | ray index)
@@ -164,7 +165,7 @@ struct Buffers {
 // batch is complete and nothing has arrived for `idle_short` cycles -- atomically with respect to the host's next submission
 // (compare-and-swap on SvcHost::state, which names the launch that is alive), so a device-wide synchronize by anybody still
 // returns.
-#define SVC_MAX_SLOTS 16u
+#define SVC_MAX_SLOTS 32u
 struct SvcSlot {
 	Buffers b;                          // the submission's buffers, record stages, anchors, ... (as the batch kernels get them)
 	uint32_t n;                         // frames of the submission

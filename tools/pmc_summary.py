@@ -49,7 +49,7 @@ def main():
     FRAMES, W, H, rw, rh = CFG[cfg]
     # ROI read as BGRA + ui_map RGBA + u8 mask + ocr_out + scales
     MAP_ALGO_BYTES_PER_FRAME = rw * rh * 4 * 2 + rw * rh + 2 * (rw // 2) * (rh // 2)
-    for d in ("d1", "d4", "d12"):
+    for d in ("d1", "d4", "d12", "d16"):
         src = find(tag, d if cfg == "c2" else f"{cfg}_{d}", "*kernel_stats.csv")
         if src:
             shutil.copy(src, os.path.join(OUT, f"{tag}_kernel_stats_depth{d[1:]}.csv" if cfg == "c2" else f"{tag}_{cfg}_kernel_stats_depth{d[1:]}.csv"))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/profile_final.sh <tag> -- run ON THE GPU BOX: everything profiles/<tag>_* is made of, one box for all of it:
-# the GPU test suite, profile_round.sh (kernel stats depth 1 / 4 / 12, PMC traffic, bench configs 1-3, depth 1), SQ counters at depth 1
+# the GPU test suite, profile_round.sh (kernel stats depth 1 / 4 / 12 / 16, PMC traffic, bench configs 1-3, depth 1), SQ counters at depth 1
 # and 4 and of the search service's kernel, bench configs 0 and 4, the sample-screenshot bench at depth 4 and 12, the kernel-trace overlap.
 set -u
 TAG=${1:-rXX}
@@ -15,7 +15,7 @@ for D in 4 12; do
   timeout 600 python tools/bench_samples.py 128 $D 2>&1 | grep -v amdgpu.ids | tail -5 > gpurun_out/${TAG}_samples_d$D.txt
   tail -1 gpurun_out/${TAG}_samples_d$D.txt > gpurun_out/${TAG}_samples_d$D.json
 done
-for D in 4 12; do
+for D in 4 12 16; do
   T=$(find gpurun_out/prof_${TAG}_d$D -name "*kernel_trace.csv" | head -1)
   [ -n "$T" ] && python tools/trace_overlap.py $T > gpurun_out/${TAG}_trace_overlap_depth$D.txt 2>&1
 done

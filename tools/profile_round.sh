@@ -2,8 +2,8 @@
 # tools/profile_round.sh <tag> -- run ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence
 # behind bench.py's roofline object for the current build and writes the summaries that get
 # committed under profiles/ into gpurun_out/<tag>_*.
-#   kernel stats  : rocprofv3 --kernel-trace --stats   (depth 1, depth 4 = batch-granular search, and the default depth 12 =
-#                   frame-granular search service; config 2 and config 3)
+#   kernel stats  : rocprofv3 --kernel-trace --stats   (depth 1, depth 4 = batch-granular search, depth 12 and 16 = what
+#                   SMHV_SEARCH_AUTO measures and picks: 16 is bench.py's default for config 2, 12 for config 3)
 #   HBM traffic   : rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes, never combined
 #                   with any other trace domain (MI355X_MICROARCH.md, HBM section)
 set -u
@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back --no-real-samples"   # profiled runs: only warm-up, timed and isolated passes
 for C in 2 3; do
   P=""; [ $C = 3 ] && P="c3_"
-  for D in 1 4 12; do
+  for D in 1 4 12 16; do
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_${P}d$D -- $B --config $C --steps 20 --warmup 1 --pipeline-depth $D > $OUT/${TAG}_${P}bench_profiled_d$D.json 2>/dev/null
   done
   # (the counter passes run at depth 1: with --pmc the profiler runs one kernel at a time, which a long-lived service kernel
