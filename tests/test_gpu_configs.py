@@ -243,7 +243,7 @@ def test_both_line_segment_kernels_agree_with_the_oracle(vision):
 
     try:
         for seed, (W, H), max_gap in ((31, (1920, 1080), 15), (32, (2560, 1440), 15), (33, (1280, 1024), 30), (34, (1024, 768), 0), (35, (1600, 1024), 50)):
-            n = 24
+            n = 16
             rng = np.random.default_rng(seed)
             frames = np.stack([scene(rng, W, H, 100 * seed + i, max_gap) if i % 3 else synth.make_frame(W, H, 100 * seed + i, n_lines=3)[0] for i in range(n)])
             ref = o.process_batch(frames, min(os.cpu_count() or 1, n), stages=0x1, max_gap=max_gap)
