@@ -273,7 +273,7 @@ SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
  *   batch-granular: one search launch per submission on the slot's own stream (k_lsd with helper workgroups at depth 1, k_lsd
  *     at depth 2 up to 1080p, k_lsd_tile -- eight waves per frame -- otherwise), staggered starts, and from depth 3 on an
  *     occupancy policy for the streaming pass and late helpers for heavy frames, both adapting to the workload.  Every slot's
- *     stream has a hardware queue of its own (up to 16 per pipeline, 20 for all live pipelines of the process).
+ *     stream has a hardware queue of its own (up to 16 per pipeline, 20 for all live pipelines of the process on one device).
  *   frame-granular (depth >= 3, frame sizes up to ~4K): ONE long-lived search kernel per pipeline whose waves pull (slot,
  *     frame) items from a device-side ring -- one wave per frame, the reference's sequential scan, with the other waves of its
  *     workgroup casting a heavy frame's upcoming candidates -- write the frame's record and count it off against its

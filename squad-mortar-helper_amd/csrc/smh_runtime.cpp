@@ -858,7 +858,7 @@ extern "C" SMHV_API int smhv_batch_read_image(smhv_batch *b, int which, uint32_t
 // ------------------------------------------------------------------------------------------------
 // pipeline: `depth` batches in flight, each on its own stream; the library owns the schedule
 // ------------------------------------------------------------------------------------------------
-static std::atomic<int> g_own_queues{0};   // streams with a hardware queue of their own, all pipelines of the process (pipeline_create_impl)
+static std::atomic<int> g_own_queues[64];  // per device: streams with a hardware queue of their own, all live pipelines of the process (pipeline_create_impl)
 struct smhv_pipeline {
 	smhv_ctx *ctx = nullptr;
 	uint32_t depth = 0;
@@ -940,7 +940,7 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (p->ev_after) (void)hipEventDestroy(p->ev_after);
 	for (auto st : p->stream) if (st) (void)hipStreamDestroy(st);
 	for (auto st : p->svc_stream) if (st) (void)hipStreamDestroy(st);
-	g_own_queues.fetch_sub((int)p->own_queues, std::memory_order_relaxed);
+	if (p->ctx) g_own_queues[(uint32_t)p->ctx->device & 63u].fetch_sub((int)p->own_queues, std::memory_order_relaxed);
 	if (p->s_search) (void)hipStreamDestroy(p->s_search);
 	if (p->s_pro) (void)hipStreamDestroy(p->s_pro);
 	for (auto e : p->ev_pub) if (e) (void)hipEventDestroy(e);
@@ -1033,13 +1033,14 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		const uint32_t ns = (!p->svc || p->adaptive) ? depth : 0u;   // one stream per slot for batch-granular submissions
 		const uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
 		p->stream.assign(ns, nullptr);
-		// (a budget: SMH_OWN_QUEUES queues per pipeline, the service's included, and SMH_OWN_QUEUES_PROCESS for all pipelines
-		// of the process that are alive -- with 21 queues the hardware scheduler started to time-slice them: stalls of 80 ms
+		// (a budget: SMH_OWN_QUEUES queues per pipeline, the service's included, and SMH_OWN_QUEUES_PROCESS for all live pipelines
+		// of the process on the same device -- with 21 queues the hardware scheduler started to time-slice them: stalls of 80 ms
 		// in the kernel trace of a depth-16 pipeline, and a second 16-queue pipeline beside the first ran at half its rate.
 		// Streams beyond the budget are ordinary ones; the search kernel's stream always has its own queue.)
 		auto own_queue = [p]() {
 			if (p->own_queues >= SMH_OWN_QUEUES) return false;
-			if (g_own_queues.fetch_add(1, std::memory_order_relaxed) >= (int)SMH_OWN_QUEUES_PROCESS) { g_own_queues.fetch_sub(1, std::memory_order_relaxed); return false; }
+			std::atomic<int> &cnt = g_own_queues[(uint32_t)p->ctx->device & 63u];
+			if (cnt.fetch_add(1, std::memory_order_relaxed) >= (int)SMH_OWN_QUEUES_PROCESS) { cnt.fetch_sub(1, std::memory_order_relaxed); return false; }
 			p->own_queues++;
 			return true;
 		};
