@@ -74,7 +74,7 @@ def parse_args():
     ap.add_argument("--rounds-per-step", type=int, default=None, help="passes over the resident batch per step")
     ap.add_argument("--lines", type=int, default=2, help="marker lines per synthetic frame")
     ap.add_argument("--pipeline-depth", type=int, default=0,
-                    help="batches in flight (smhv_pipeline_create depth; 0 = default: 16 for 256-frame batches, 12 below, 8 for 1024-frame shards; 16 x 256 frames resident outputs = 16 GB of the 288: what the frame-granular search needs to hide its one-wave-per-frame latency)")
+                    help="batches in flight (smhv_pipeline_create depth; 0 = default: 12, or 8 for 1024-frame shards; 12 x 256 frames resident outputs = 16 GB of the 288: what the frame-granular search needs to hide its one-wave-per-frame latency)")
     ap.add_argument("--distinct", type=int, default=None,
                     help="distinct synthetic frames per GPU (0 = every frame distinct); fewer are tiled on the device.  Default: every "
                          "frame distinct, except config 4 (1024 frames per GPU): 256 distinct frames per GPU, tiled four times -- "
@@ -601,11 +601,11 @@ def main():
     frames, infos, frames_host, h2d_s = upload_synthetic(torch, synth, W, H, n, first, args.lines, args.distinct, torch.device("cuda", local_rank), keep)
 
     vision = smh.HipVision.init(local_rank)
-    # default: 16 batches in flight for the 256-frame headline (4096 frames = four per resident wave of the search service:
-    # every wave always finds a frame of its own and nobody spends wave-time helping), 12 for the 128-frame
-    # 1440p batches (that pipeline picks the batch-granular search, whose slot streams have twelve hardware queues of their
-    # own), 8 for 1024-frame shards (config 4) -- each slot holds the output images of a whole batch, 5 MB per 1080p frame
-    depth = args.pipeline_depth if args.pipeline_depth > 0 else (8 if n >= 1024 else 16 if n * 16 >= 4096 else 12)
+    # default: 12 batches in flight (3072 frames at 256 per batch = three per resident wave of the search service, from where on
+    # its rate no longer grows; a pipeline that picks the batch-granular search has twelve hardware queues
+    # for its slot streams), 8 for 1024-frame shards (config 4) -- each slot holds the output images of a whole batch, 5 MB
+    # per 1080p frame
+    depth = args.pipeline_depth if args.pipeline_depth > 0 else (8 if n >= 1024 else 12)
     idle_streams = [torch.cuda.Stream() for _ in range(max(0, args.idle_streams))]   # noqa: F841 (kept alive on purpose)
     if args.tile_cap > 0:
         smh._lib.load().smhv_debug_lsd_tile_cap(args.tile_cap)

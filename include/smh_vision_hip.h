@@ -280,9 +280,8 @@ SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
  *     submission; the submissions' streaming sides take two library-owned streams in turn.  A slot is done when its slowest
  *     frame is, nothing else waits for that frame.  The kernel closes by itself when nothing is outstanding (a device-wide
  *     synchronize by anybody still returns) and is launched again by the next submission.  A third of the wave-time per frame,
- *     but a frame is one wave's work from start to end: it needs ~2000 light frames in flight, and runs best with four or more
- *     per resident wave (depth x frames >= 3840 at 1080p: nobody runs dry, nobody spends wave-time helping: 16 x 256 frames
- *     533-550 k frames/s against 503-522 k for 12 x 256).
+ *     but a frame is one wave's work from start to end: it needs ~3000 light frames in flight (three per resident wave: 12 x
+ *     256 frames at 1080p, 526-538 k frames/s; more changes nothing).
  *   SMHV_SEARCH_AUTO (the default): below depth 8 batch-granular.  From depth 8 on the pipeline has both and MEASURES which is
  *     faster on the workload it is given -- a window of 8 x depth submissions in each, after warm-ups, ~24 x depth submissions in
  *     all; again every 16384 submissions and when the submissions change shape -- keeping the faster one (both write

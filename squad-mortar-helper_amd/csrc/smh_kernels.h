@@ -95,7 +95,6 @@ struct BatchError {
 #define SMH_FARM_RING 4u
 #define SMH_REC_ON 0x80000000u
 #define SMH_LSD_LATE_HELP 1u
-#define SMH_LSD_NO_TEAM_HELP 2u         // frame-granular search: the frames of this submission do not ask their workgroup for help
 struct FarmEntry {                  // 64 bytes
 	unsigned long long post;        // owner -> helper: epoch16 << 48 | (k + 1)24 << 24 | py12 << 12 | px12   (k = posts so far)
 	unsigned long long best;        // helper -> owner: max over rays of (len^2 bits << 32 | ray index)

@@ -619,7 +619,7 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 // s_pro: the pipeline's prologue stream -- the anchor upload and the button test of a submission run there, ahead of time, so
 // that the chain on a streaming stream is pass -> publication -> pass: the button test (45 us inside a busy pipeline, plus a
 // hand-over) is off it.
-struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro; bool no_help; };
+struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro; };
 static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                           const smhv_anchors *anchors, hipStream_t s, hipStream_t sl, const SvcPublish *svc = nullptr) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
@@ -696,7 +696,6 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 		if (stages & SMHV_STAGE_MINIMAP) HIPCHK(launch_find_minimap(g, bf, n, s));
 		bf.rec_stages = SMH_REC_ON | (scales ? stages : (stages & ~SMHV_STAGE_SCALES));
 		bf.rec_bars = b->d_bars;
-		if (svc->no_help) bf.lsd_flags |= SMH_LSD_NO_TEAM_HELP;
 		STAGE_BEGIN(3, s);
 		HIPCHK(launch_svc_publish(svc->ctl, svc->ring, svc->slots, svc->slot, bf, n, svc->seq, svc->ring_log2, s));
 		STAGE_END(3, s);
@@ -1205,12 +1204,7 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	}
 	uint32_t seq = ++p->seq_counter;
 	if (seq == 0u) seq = ++p->seq_counter;
-	// Helping pays while waves run dry: with enough frames in flight that every wave always finds one of its own, the
-	// wave-time a helper spends (2.5 cycles for every cycle it saves its owner: speculative casts, window fills) is taken from
-	// frames that are waiting.  Measured, 1024 resident waves, frames in flight = depth x frames per submission: 3072: 519 k
-	// frames/s with helping, 456 k without; 3584: 519 / 513; 3840: 517 / 537; 4096: 519-527 / 544-551; 8192: 517-524 / 554-567.
-	const bool no_help = (uint64_t)p->depth * n * 4u >= (uint64_t)p->svc_wgs * p->svc_waves * 15u;   // >= 3.75 frames per wave
-	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot], no_help};
+	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot]};
 	// The submission is counted BEFORE its kernels are enqueued: from here on the service does not regard itself as drained
 	// (were it counted afterwards, its items could be there -- and a wave at work on them -- while the count still said
 	// "everything complete", and the service would close under that wave).

@@ -523,9 +523,8 @@ def _oracle_batch(frames, infos, stages=0xF):
 @pytest.mark.parametrize("W,H,N", [(1920, 1080, 256), (2560, 1440, 128)])
 def test_headline_configuration_pipelined_depth4(vision, W, H, N):
     """The EXACT configuration bench.py's `value` is measured on (BASELINE configs[2] / configs[3]): N resident frames,
-    smhv_pipeline with sixteen (256 x 1080p: four frames per resident wave of the search service, nobody helps) or twelve
-    (128 x 1440p: help desk) batches in flight, the submissions of its first phase -- the frame-granular search service, one
-    wave per frame -- back to back -- and the configuration it was measured on until round 3: four batches in flight, batch-granular
+    smhv_pipeline with twelve batches in flight, the submissions of its first phase -- the frame-granular search service, one
+    wave per frame, help desk -- back to back -- and the configuration it was measured on until round 3: four batches in flight, batch-granular
     search (k_lsd_tile, 512-thread workgroups, occupancy policy), twelve submissions.  Every slot's N records must equal, byte
     for byte, a plain smhv_batch_run of the same frames (k_lsd_tile with 1024-thread workgroups, nothing beside it), the
     depth-1 pipeline (k_lsd with helper workgroups at 1080p) must give them too, and eight frames spread over the batch are
@@ -542,7 +541,7 @@ def test_headline_configuration_pipelined_depth4(vision, W, H, N):
     want = bytes(want_raw)
     recs = smh.results_to_dicts(want_raw)
     fb.close()
-    for depth, subs in ((16 if N == 256 else 12, 38 if N == 256 else 30), (4, 12)):   # bench.py's defaults for the two configurations; round 3's
+    for depth, subs in ((12, 30), (4, 12)):                          # bench.py's default; round 3's
         pipe = smh.Pipeline(vision, W, H, N, depth)
         for j in range(subs):
             assert pipe.submit(d.data_ptr(), N, anchors=anchors) == j % depth
