@@ -39,6 +39,7 @@ class IngestQueue:
         self.w, self.h, self.capacity = int(w), int(h), int(capacity)
         self.frame_bytes = self.w * self.h * 4
         self._vision = vision                                   # keeps the context alive
+        self._views = {}
         check(self._lib.smhv_ingest_create_ex(vision._ctx, self.w, self.h, int(slots), self.capacity, 1 if roi_upload else 0, C.byref(self._q)))
 
     def close(self):
@@ -56,8 +57,11 @@ class IngestQueue:
         """Next pinned staging buffer as an (h, w, 4) uint8 array to capture into; then commit()."""
         p = C.c_void_p()
         check(self._lib.smhv_ingest_acquire(self._q, C.byref(p)))
-        buf = (C.c_uint8 * self.frame_bytes).from_address(p.value)
-        return np.frombuffer(buf, dtype=np.uint8).reshape(self.h, self.w, 4)
+        a = self._views.get(p.value)                            # (the staging buffers are few and fixed: one array object each)
+        if a is None:
+            buf = (C.c_uint8 * self.frame_bytes).from_address(p.value)
+            a = self._views[p.value] = np.frombuffer(buf, dtype=np.uint8).reshape(self.h, self.w, 4)
+        return a
 
     def commit(self):
         check(self._lib.smhv_ingest_commit(self._q))
