@@ -85,6 +85,30 @@ def test_record_layout_matches_header(built):
     assert "#define SMHV_FRAME_OK 0u" in hdr and "#define SMHV_FRAME_LSD_STUCK 1u" in hdr and "uint32_t status;" in hdr
 
 
+def test_pipeline_options_and_flags_match_the_header(built):
+    """smhv_pipeline_options as the binding declares it == the struct in the header, field for field (all uint32_t, in order),
+    and the SMHV_SEARCH_* / SMHV_PIPE_* / SMHV_INGEST_* values the binding uses are the header's.  A C program compiled against
+    the header agrees on the size."""
+    import re
+    import subprocess
+    from squad_mortar_helper_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "smh_vision_hip.h")).read()
+    body = re.search(r"typedef struct \{([^}]*)\} smhv_pipeline_options;", hdr).group(1)
+    fields = re.findall(r"uint32_t\s+(\w+);", body)
+    assert fields == [f[0] for f in _lib.PipelineOptions._fields_] and all(f[1] is C.c_uint32 for f in _lib.PipelineOptions._fields_)
+    defs = dict(re.findall(r"#define (SMHV_(?:SEARCH|PIPE|INGEST)_\w+) (\d+)u", hdr))
+    assert (int(defs["SMHV_SEARCH_AUTO"]), int(defs["SMHV_SEARCH_BATCH"]), int(defs["SMHV_SEARCH_FRAME"])) == (_lib.SEARCH_AUTO, _lib.SEARCH_BATCH, _lib.SEARCH_FRAME)
+    assert (int(defs["SMHV_PIPE_NO_TEAM_HELP"]), int(defs["SMHV_PIPE_NO_STREAM_PRIORITY"]), int(defs["SMHV_PIPE_NO_PROLOGUE"])) == \
+        (_lib.PIPE_NO_TEAM_HELP, _lib.PIPE_NO_STREAM_PRIORITY, _lib.PIPE_NO_PROLOGUE)
+    assert int(defs["SMHV_INGEST_ROI_UPLOAD"]) == 1 and sorted(k for k in defs if k.startswith("SMHV_PIPE_")) == ["SMHV_PIPE_NO_PROLOGUE", "SMHV_PIPE_NO_STREAM_PRIORITY", "SMHV_PIPE_NO_TEAM_HELP"]
+    src = os.path.join(os.environ.get("TMPDIR", "/tmp"), "smhv_opt_size.c")
+    exe = src[:-2]
+    with open(src, "w") as f:
+        f.write('#include <stdio.h>\n#include "smh_vision_hip.h"\nint main(void) { printf("%zu\\n", sizeof(smhv_pipeline_options)); return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+    assert int(subprocess.check_output([exe]).decode()) == C.sizeof(_lib.PipelineOptions) == 32
+
+
 def test_host_crc32_equals_zlib_for_ragged_lengths_and_alignments(built):
     """smhv_crc32_host (smh_crc_host.cpp: carry-less-multiply folding with constants derived from the polynomial, table loop
     for the head / tail and short messages) == zlib.crc32 == crc32fast::hash (src/capture.rs:44): the ingest queue's
