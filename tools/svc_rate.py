@@ -99,6 +99,8 @@ if os.environ.get("SVC_RATE_WPROF"):
         acc += np.array([r.meters[20 + k] for k in range(9)])
     prof = dict(zip(("list_build", "dispatch", "setup", "units", "verdict", "u_first_batches", "u_long_rays", "u_end_points", "n_units"), (acc / N).tolist()))
     prof["rounds"] = float(np.mean([r.rounds for r in recs]))
+    prof["s_window_fill"] = float(np.mean([r.meters[30] for r in recs]))
+    prof["s_cull_scan"] = float(np.mean([r.meters[31] for r in recs]))
 pipe.close()
 print(json.dumps({"frames_per_s": N * passes / dt, "ms_per_pass": dt / passes * 1e3, "N": N, "depth": depth, "stages": stages, "frame": [W, H],
                   "slots_equal_plain_run": all(equal), "env": {k: v for k, v in os.environ.items() if k.startswith(("SMH_", "RATE_"))}, "search_service": st, "scan_profile_cycles_per_frame": prof, "stage_ms": stage_ms, "slow_submits": len(slow)}))
