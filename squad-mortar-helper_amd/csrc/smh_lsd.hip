@@ -257,19 +257,23 @@ enum { RAY_CONTINUE = 0, RAY_ABORTED = 1, RAY_LEFT_IMAGE = 2 };
 // non-white sample, and restores the position where that run started.
 //   RAY_ABORTED    : the run started at global step s.gk0 + s.gj; samples taken = *steps
 //   RAY_LEFT_IMAGE : the first out-of-image position is step s.k0 + s.nexit
-template <int MODE>
+// G: samples whose LDS reads are in flight together (8, 16 or 32).
+template <int MODE, int G = 8>
 __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float dx, float dy, uint32_t T, RayState &s, uint32_t &steps) {
+	static_assert((G == 8 || G == 16 || G == 32) && (MODE != LSD_MODE_TILE || G == 8), "group size");
 	float xo = s.bxo, yo = s.byo, x = 0.0f, y = 0.0f;
 	uint32_t Wm = 0;
 	// 4 x 8 samples: eight LDS reads in flight per wave keep the register footprint small enough for
-	// 16 waves per CU; the whiteness bits are shifted in from the top (sample j ends up in bit j).
+	// 16 waves per CU; the whiteness bits are shifted in from the top (sample j ends up in bit j).  (G = 16 / 32: the
+	// one-wave-per-frame scan of the search service, a single wave on its SIMD beside the streaming pass, where an LDS round
+	// trip takes several hundred cycles and there is nobody else to hide it behind.)
 	uint32_t taken = 0;
 #pragma unroll 1
-	for (int jj = 0; jj < 4; ++jj) {
+	for (int jj = 0; jj < 32 / G; ++jj) {
 		if constexpr (MODE == LSD_MODE_TILE) tile_raw8(m, xs, ys, dx, dy, xo, yo, x, y, Wm);
 		else
 #pragma unroll
-		for (int j = 0; j < 8; ++j) {
+		for (int j = 0; j < G; ++j) {
 			x = xo + xs; y = yo + ys;                   // x = x_offset + x_start
 			// shifts in bit 0 of its first operand
 			if (MODE == LSD_MODE_ROWS) Wm = __builtin_amdgcn_alignbit(win_raw_rows(m, x, y), Wm, 1);
@@ -278,7 +282,7 @@ __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float
 			else Wm = __builtin_amdgcn_alignbit(win_raw<MODE == LSD_MODE_GLOBAL>(m, (int)x, (int)y), Wm, 1);
 			xo += dx; yo += dy;                         // x_offset += dx
 		}
-		taken += 8u;
+		taken += (uint32_t)G;
 		// Early out: when the most recent T+1 samples of EVERY lane of the wave are non-white, every
 		// ray of the wave has aborted inside this batch (most rays die T+1 samples after leaving the
 		// blob they start in), so the remaining samples of the batch cannot matter.
