@@ -33,3 +33,21 @@ def test_build_falls_back_to_tracked_loads_when_the_check_fails(tmp_path):
     out2 = str(tmp_path / "libsmh_strict.so")
     r = subprocess.run(["make", "-C", csrc, "-B", "OUT=" + out2], env=dict(env, SMH_STRICT_ISA="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and not os.path.exists(out2)
+
+
+def test_the_search_service_has_no_scratch_access_inside_a_loop():
+    """tools/scratch_in_loops.py on the compiled search service (k_lsd_service and the two noinline bodies it calls, svc_frame and
+    svc_help): spills are allowed in prologues / epilogues (loop depth 0) only.  A wave that shares its CU with the HBM-bound
+    streaming pass waits microseconds for every vector-memory access; fifteen reloads in the candidate loop once made the scan
+    twice as slow.  Reading wider groups of window samples at once (SEQ_RAY_GROUP = 32) fails exactly this."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "scratch_in_loops.py")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = [ln for ln in p.stdout.splitlines() if "scratch (loads, stores) by loop depth" in ln]
+    names = " ".join(rows)
+    assert "k_lsd_service" in names and "svc_frame" in names, p.stdout
+    for ln in rows:
+        depths = [int(d) for d in re.findall(r"(\d+): \[", ln.split("by loop depth:")[1])]
+        assert all(d == 0 for d in depths), ln
+
