@@ -1064,8 +1064,8 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		p->svc_ring_log2 = lg;
 		int cus = 0;
 		if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-		// One service workgroup per CU where four waves of it fit beside the streaming pass (up to 1080p); larger frames (three
-		// waves per workgroup, 110 KB of a CU's LDS) leave a quarter of the CUs to the streaming pass alone -- measured at
+		// One service workgroup per CU where four waves of it fit beside the streaming pass (up to 1080p); larger frames (two
+		// waves per workgroup at 1440p, most of a CU's LDS all the same) leave a quarter of the CUs to the streaming pass alone -- measured at
 		// 128 x 1440p, depth 12, one box: 256 / 208 / 192 / 176 workgroups: 229 / 247 / 252 / 236 k frames/s (1080p: 540 / - /
 		// 490 / - k: every CU).
 		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(p->svc_waves >= 4u ? cus : cus * 3 / 4, 1);
