@@ -212,6 +212,8 @@ class Pipeline:
         d = dict(zip(keys, [int(v) for v in out[:10]]))
         d["avail"] = d["avail"] - (1 << 64) if d["avail"] >= (1 << 63) else d["avail"]
         d["slots"] = [(int(v) >> 32, int(v) & 0xFFFFFFFF) for v in out[10:14]]
+        d["service_workgroups"], d["waves_per_workgroup"] = int(out[14]) >> 32, int(out[14]) & 0xFFFFFFFF
+        d["lds_words_per_wave"], d["lds_bytes_dynamic"] = int(out[15]) >> 32, int(out[15]) & 0xFFFFFFFF
         return d
 
     def wait(self, slot=None):

@@ -962,6 +962,9 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 // the streaming pass is capped as well (its workgroups walk the items with a grid stride).  Frame sizes whose tile index
 // leaves no room for that (4K and up) get no policy.
 #define SMH_PIPE_TILE_LIMIT(g) ((g).rh > 900u ? 320u : 200u)   // a 1080p scene has 36-126 mask tiles, the 1440p screenshots up to 261
+// ... and of the search service's waves: 272 above 1080p is what lets THREE waves of a service workgroup (36.6 KB each) fit a
+// CU at 1440p instead of two (the reference's 1440p screenshots have up to 261 mask tiles)
+#define SMH_SVC_TILE_LIMIT(g) ((g).rh > 900u ? 272u : 200u)
 #define SMH_PIPE_MAP_GRID 1024u
 #define SMH_LDS_PER_CU 163840u
 #define SMH_ADAPT_OFF 3.5f              // line search / streaming pass, launch durations: above -> no occupancy policy
@@ -1006,7 +1009,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 	p->ctx = c; p->depth = depth; p->opt = opt;
 	// Frame-granular search (smh_kernels.h): depth >= 3 and a frame size whose tile store fits beside the streaming pass
 	if (opt.search != SMHV_SEARCH_BATCH && depth >= 3 && (opt.search == SMHV_SEARCH_FRAME || depth >= SMH_SVC_AUTO_DEPTH) && max_frames < (1u << 24)) {
-		p->svc_waves = svc_waves_for(g0, SMH_PIPE_TILE_LIMIT(g0), &p->svc_part_words, &p->svc_tile_cap, &p->svc_list_cap, &p->svc_lds);
+		p->svc_waves = svc_waves_for(g0, SMH_SVC_TILE_LIMIT(g0), &p->svc_part_words, &p->svc_tile_cap, &p->svc_list_cap, &p->svc_lds);
 		p->svc = p->svc_waves > 0u;
 	}
 	if (opt.search == SMHV_SEARCH_FRAME && !p->svc) {
@@ -1064,11 +1067,12 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		p->svc_ring_log2 = lg;
 		int cus = 0;
 		if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-		// One service workgroup per CU where four waves of it fit beside the streaming pass (up to 1080p); larger frames (two
-		// waves per workgroup at 1440p, most of a CU's LDS all the same) leave a quarter of the CUs to the streaming pass alone -- measured at
-		// 128 x 1440p, depth 12, one box: 256 / 208 / 192 / 176 workgroups: 229 / 247 / 252 / 236 k frames/s (1080p: 540 / - /
-		// 490 / - k: every CU).
-		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(p->svc_waves >= 4u ? cus : cus * 3 / 4, 1);
+		// One service workgroup per CU where four waves of it fit beside the streaming pass (up to 1080p).  Larger frames (three
+		// waves per workgroup at 1440p, most of a CU's LDS all the same) do better with the service on five eighths of the CUs
+		// and the others left to the streaming pass alone -- measured at 128 x 1440p, depth 12, one box, three waves per
+		// workgroup: 256 / 224 / 192 / 176 / 160 / 144 / 128 / 112 workgroups: 225 / 239 / 254 / 261 / 271 / 272 / 251 / 227 k
+		// frames/s (two waves per workgroup: 229 k with 256, 252 k with 192; 1080p, four waves: 540 / 531 / 514 / - / 490 k: every CU).
+		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(p->svc_waves >= 4u ? cus : cus * 5 / 8, 1);
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ctl, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMemset(p->d_svc_ctl, 0, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ring, sizeof(unsigned long long) << lg);
@@ -1416,6 +1420,7 @@ extern "C" SMHV_API int smhv_debug_pipeline_peek(smhv_pipeline *p, uint64_t out[
 	HIPCHK(hipSetDevice(p->ctx->device));
 	const unsigned long long st = __atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE);
 	out[0] = st >> 32; out[1] = (uint32_t)st; out[2] = p->h_svc->launches; out[3] = p->seq_counter;
+	out[14] = ((uint64_t)p->svc_wgs << 32) | p->svc_waves; out[15] = ((uint64_t)p->svc_part_words << 32) | p->svc_lds;   // geometry of the service's launches
 	static hipStream_t s_peek = nullptr;
 	if (!s_peek) HIPCHK(hipStreamCreateWithFlags(&s_peek, hipStreamNonBlocking));
 	static SvcCtl *h_ctl = nullptr;

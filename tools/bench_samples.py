@@ -31,12 +31,14 @@ def main():
     vision = smh.HipVision.init(0)
     depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     search = os.environ.get("SAMPLES_SEARCH", "auto")
+    if os.environ.get("SAMPLES_TILE_CAP"):
+        smh._lib.load().smhv_debug_lsd_tile_cap(int(os.environ["SAMPLES_TILE_CAP"]))
     if os.environ.get("SAMPLES_TOUCH_FIRST"):
         torch.zeros(int(os.environ["SAMPLES_TOUCH_FIRST"]), dtype=torch.uint8).cuda()
         torch.cuda.synchronize()
     if os.environ.get("SAMPLES_FRAMES_FIRST"):
         d = torch.from_numpy(batch).cuda()
-    pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth, search=search)
+    pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth, search=search, service_workgroups=int(os.environ.get("SAMPLES_WGS", "0")))
     if not os.environ.get("SAMPLES_FRAMES_FIRST"):
         d = torch.from_numpy(batch).cuda()
     torch.cuda.synchronize()
