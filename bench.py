@@ -250,7 +250,7 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=200):
 
     def rate(dep):
         pipe = smh.Pipeline(vision, 2560, 1440, batch, depth=dep)
-        for _ in range(26 * dep if dep >= 8 else 2 * dep):     # (from depth 8 on the pipeline first measures both of its searches: 24 x depth submissions)
+        for _ in range(26 * dep if dep >= 6 else 2 * dep):     # (from depth 6 on the pipeline first measures both of its searches: 24 x depth submissions)
             pipe.submit(d.data_ptr(), batch, stages=stages, max_gap=15)
         pipe.wait()
         modes[str(dep)] = (pipe.search_stats() or {}).get("mode", "batch-granular")
@@ -678,11 +678,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # a pipeline with SMHV_SEARCH_AUTO at depth >= 8 times both of its line searches on the workload before it settles on one
+    # a pipeline with SMHV_SEARCH_AUTO at depth >= 6 times both of its line searches on the workload before it settles on one
     # (24 x depth submissions, smh_runtime.cpp mode_control): that belongs to the warm-up, whatever --warmup says.  The number
     # of extra steps is computed, not polled: every rank must run the same number of passes (each gathers).
     extra_warmup = 0
-    if depth >= 8 and args.search == "auto":
+    if depth >= 6 and args.search == "auto":
         extra_warmup = max(0, -(-(26 * depth - args.warmup * rounds) // rounds))
         for _ in range(extra_warmup):
             step()

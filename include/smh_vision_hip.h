@@ -282,7 +282,7 @@ SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
  *     synchronize by anybody still returns) and is launched again by the next submission.  A third of the wave-time per frame,
  *     but a frame is one wave's work from start to end: it needs ~3000 light frames in flight (three per resident wave: 12 x
  *     256 frames at 1080p, 526-538 k frames/s; more changes nothing).
- *   SMHV_SEARCH_AUTO (the default): below depth 8 batch-granular.  From depth 8 on the pipeline has both and MEASURES which is
+ *   SMHV_SEARCH_AUTO (the default): below depth 6 batch-granular.  From depth 6 on the pipeline has both and MEASURES which is
  *     faster on the workload it is given -- a window of 8 x depth submissions in each, after warm-ups, ~24 x depth submissions in
  *     all; again every 16384 submissions and when the submissions change shape -- keeping the faster one (both write
  *     byte-identical records).  Measured at depth 12: the synthetic 256 x 1080p scene 519 k frames/s on the frame-granular
@@ -292,7 +292,7 @@ typedef struct smhv_pipeline smhv_pipeline;
 SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth, smhv_pipeline **out);
 /* The same with explicit choices: zero-initialise, set `size` = sizeof(smhv_pipeline_options), change what you need (every 0 is
  * the library's default; there are no environment variables). */
-#define SMHV_SEARCH_AUTO 0u             /* batch-granular below depth 8; from 8 on whichever of the two the pipeline measures faster on its workload */
+#define SMHV_SEARCH_AUTO 0u             /* batch-granular below depth 6; from 6 on whichever of the two the pipeline measures faster on its workload */
 #define SMHV_SEARCH_BATCH 1u
 #define SMHV_SEARCH_FRAME 2u            /* SMHV_E_INVALID when depth < 3 or the frame's mask tiles do not fit the LDS beside the streaming pass (8K) */
 #define SMHV_PIPE_NO_TEAM_HELP 1u       /* flags, diagnostics (A/B): frame-granular search without waves helping the heavy frames of their workgroup */

@@ -197,7 +197,7 @@ class Pipeline:
         d["help_cycles_per_frame"] = int(out[12]) / max(d["frames"], 1)
         d["cycles_per_frame"] = d["busy_cycles"] / max(d["frames"], 1)
         d["busy_fraction"] = d["busy_cycles"] / max(d["resident_cycles"], 1)
-        # SMHV_SEARCH_AUTO at depth >= 8: the pipeline times both searches on the workload it is given and keeps the faster
+        # SMHV_SEARCH_AUTO at depth >= 6: the pipeline times both searches on the workload it is given and keeps the faster
         d["adaptive"] = bool(int(out[13]) & 2)
         d["settled"] = bool(int(out[13]) & 4) or not d["adaptive"]
         d["mode"] = "frame-granular" if int(out[13]) & 1 else "batch-granular"

@@ -982,10 +982,10 @@ static LaunchTuning pipeline_tuning(const Geom &g) {
 }
 
 // Defaults of smhv_pipeline_options (all zero): which search a pipeline gets is decided from what was measured on MI355X
-// (DESIGN.md): the frame-granular service needs ~2000 frames in flight to hide its one-wave-per-frame latency (256-frame
-// batches: 455 k frames/s at depth 8 and 510 k at depth 12, against 435 k for the batch-granular search at depth 4), below
-// that the batch-granular search with its occupancy policy is ahead (depth 4: 435 k against 275 k).
-#define SMH_SVC_AUTO_DEPTH 8u
+// (DESIGN.md).  One box, frames/s batch-granular / frame-granular: 256 x 1080p at depth 5 / 6 / 7 / 8: 340 / 328, 377 / 376,
+// 407 / 421, 409 / 462 k; 128 x 1440p: 209 / 202, 233 / 232, 251 / 254, 254 / 273 k.  Below depth 6 the batch-granular search;
+// from there on the pipeline has both and measures (mode_control).
+#define SMH_SVC_AUTO_DEPTH 6u
 #define SMH_OWN_QUEUES 16u
 #define SMH_OWN_QUEUES_PROCESS 20u
 static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t max_frames, uint32_t depth, const smhv_pipeline_options *opt_in, smhv_pipeline **out) {
