@@ -256,6 +256,10 @@ SMHV_API int smhv_debug_skip_line_search(int on);
  * watchdog gives its frame up (SMHV_FRAME_LSD_STUCK).  0 restores the default (4,000,000: about a second).  The tests lower
  * it to 1 to force the error path. */
 SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
+/* diagnostic (process-wide): pipelines created while this is on behave as on a platform whose device cannot perform atomics
+ * on mapped host memory (no PCIe atomics: smhv_pipeline_create probes for them) -- SMHV_SEARCH_AUTO keeps the batch-granular
+ * search, an explicit SMHV_SEARCH_FRAME is SMHV_E_INVALID.  The tests use it to walk that path on a machine that has them. */
+SMHV_API int smhv_debug_no_host_atomics(int on);
 /* ---- pipeline: several batches in flight, scheduled by the library ----------------------------------------------
  * `depth` output buffer sets (smhv_batch objects) of max_frames frames.  The library owns every stream of the schedule (created
  * in a fixed order: the throughput does not depend on what streams the host created before or on how it interleaves its calls).
@@ -298,6 +302,8 @@ SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t fram
 #define SMHV_PIPE_NO_TEAM_HELP 1u       /* flags, diagnostics (A/B): frame-granular search without waves helping the heavy frames of their workgroup */
 #define SMHV_PIPE_NO_STREAM_PRIORITY 2u /*   ... without wave priority for the streaming pass */
 #define SMHV_PIPE_NO_PROLOGUE 4u        /*   ... button test and anchor upload on the streaming streams instead of a stream of their own */
+#define SMHV_PIPE_NO_REMOTE_HELP 8u     /*   ... a heavy frame is helped by the waves of its own workgroup only, not by idle waves of other workgroups */
+#define SMHV_PIPE_HELP_FIRST 16u        /*   ... frames ask other workgroups, and waves answer, even while frames are waiting for a wave (default: only then not) */
 typedef struct {
 	uint32_t size;
 	uint32_t search;                    /* SMHV_SEARCH_* */
@@ -308,6 +314,9 @@ typedef struct {
 	                                       workload is search-bound, 1 = always, 2 = never */
 	uint32_t service_workgroups;        /* frame-granular, diagnostic: workgroups of the search kernel (0 = one per CU) */
 	uint32_t flags;                     /* SMHV_PIPE_* */
+	uint32_t remote_after;              /* frame-granular: search rounds after which a frame asks the waves of OTHER workgroups for help (0 = 24) */
+	uint32_t remote_tickets;            /*   ... and how many of them it asks for (0 = 3; at most 12 attach) */
+	uint32_t remote_last;               /*   ... once at most 1 / remote_last of its submission's frames are still at work (0 = 6) */
 } smhv_pipeline_options;
 SMHV_API int smhv_pipeline_create_ex(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
                                      const smhv_pipeline_options *options, smhv_pipeline **out);
@@ -322,8 +331,13 @@ SMHV_API int smhv_pipeline_hold(smhv_pipeline *p, uint32_t slot, void *stream);
  * pipeline has one, [1] launches of the search kernel so far, [2] frames it searched, [3] waves that came and went, [4] cycles
  * those waves spent on frames, [5] cycles they were resident, [6] waves per launch, [7] submissions completed, [8..11] the cycles of [4] by phase: cache invalidation after the claim,
  * tile store + search, record (scale ratio + derived outputs), write-back + counting the frame off; [12] cycles the waves spent
- * casting candidates for other waves' frames (not part of [4]). */
-SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[16]);
+ * casting candidates for other waves' frames (not part of [4]); [13..15] the search the pipeline is on and the two measured rates;
+ * [16] help requests frames opened to other workgroups, [17] helpers that attached to one, [18] candidates they cast,
+ * [19] help tickets nobody has taken; [20..22] in ticks of the 100 MHz timer, summed: publication -> a wave takes the frame (over frames), publication -> last frame
+ * counted off (over submissions), how long that last frame was at work; [23..29] the helpers of other workgroups' frames: polls of a
+ * request's ring, polls that found nothing to take, claims lost, exits because nothing came / because the request closed, cycles attached,
+ * cycles of those spent casting; [30..31] 0. */
+SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[32]);
 /* diagnostic, does NOT synchronise the device (usable from another thread while a wait is stuck): [0] submissions counted,
  * [1] epoch of the search launch alive (0: none), [2] launches, [3] last sequence number handed out, [4..9] the ring's
  * counters (available, head, reserved, closing epoch, submissions completed, waves at work), [10..13] slots 0-3:

@@ -154,7 +154,7 @@ class Pipeline:
         opt.size = C.sizeof(L.PipelineOptions)
         opt.search = {None: L.SEARCH_AUTO, "auto": L.SEARCH_AUTO, "batch": L.SEARCH_BATCH, "frame": L.SEARCH_FRAME}[search]
         for k, v in options.items():
-            if k not in ("streams", "idle_close_us", "occupancy_policy", "late_helpers", "service_workgroups", "flags"):
+            if k not in ("streams", "idle_close_us", "occupancy_policy", "late_helpers", "service_workgroups", "flags", "remote_after", "remote_tickets", "remote_last"):
                 raise TypeError("Pipeline: unknown option %r" % k)
             setattr(opt, k, int(v))
         L.check(self._lib.smhv_pipeline_create_ex(vision._ctx, frame_w, frame_h, max_frames, depth, C.byref(opt), C.byref(p)))
@@ -187,7 +187,7 @@ class Pipeline:
 
     def search_stats(self):
         """Diagnostic (synchronises): the frame-granular line search of a pipeline of depth >= 3 -> dict, or None."""
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 32)()
         L.check(self._lib.smhv_debug_pipeline_stats(self._p, out))
         if not out[0]:
             return None
@@ -195,8 +195,15 @@ class Pipeline:
         d = dict(zip(keys, [int(v) for v in out[1:8]]))
         d["cycles_per_frame_by_phase"] = dict(zip(("acquire", "search", "record", "release"), [int(v) / max(d["frames"], 1) for v in out[8:12]]))
         d["help_cycles_per_frame"] = int(out[12]) / max(d["frames"], 1)
+        d["remote_help"] = {"requests": int(out[16]), "helpers_attached": int(out[17]), "candidates_cast": int(out[18]), "tickets_left": int(out[19]) - (1 << 64) if int(out[19]) >= (1 << 63) else int(out[19])}
         d["cycles_per_frame"] = d["busy_cycles"] / max(d["frames"], 1)
         d["busy_fraction"] = d["busy_cycles"] / max(d["resident_cycles"], 1)
+        # where a submission's time goes (100 MHz ticks -> ms): publication -> a wave takes the frame (mean over frames); publication ->
+        # last frame counted off (mean over submissions); how long that last frame was at work
+        d["remote_help"].update({"polls": int(out[23]), "polls_empty": int(out[24]), "claims_lost": int(out[25]), "exits_idle": int(out[26]), "exits_closed": int(out[27]),
+                                 "cycles_attached_per_helper": int(out[28]) / max(int(out[17]), 1), "cast_fraction_of_attached": int(out[29]) / max(int(out[28]), 1)})
+        d["timeline_ms"] = {"frame_wait": int(out[20]) / max(d["frames"], 1) / 1e5, "submission_search": int(out[21]) / max(d["submissions"], 1) / 1e5,
+                            "last_frame_at_work": int(out[22]) / max(d["submissions"], 1) / 1e5}
         # SMHV_SEARCH_AUTO at depth >= 6: the pipeline times both searches on the workload it is given and keeps the faster
         d["adaptive"] = bool(int(out[13]) & 2)
         d["settled"] = bool(int(out[13]) & 4) or not d["adaptive"]

@@ -171,13 +171,46 @@ struct SvcSlot {
 	uint32_t seq;                       // its sequence number (never 0)
 	uint32_t done;                      // frames finished so far
 	uint32_t pad;
+	unsigned long long t_pub;           // s_memrealtime (100 MHz) when the items were published (diagnostics: where a submission's time goes)
 };
+// ---- help across workgroups (round 5) -----------------------------------------------------------------------------------------
+// The help desk of smh_lsd_seq.inc lives in the owner's LDS: only the waves of its workgroup (three or four) can serve it, and a
+// frame with several hundred rounds still takes milliseconds -- long enough to block its submission's slot.  A frame that has
+// been at work for SvcParams::remote_after rounds therefore also asks the waves of OTHER workgroups: it writes its tile store
+// (the mask as it holds it in LDS: the non-empty tiles + the 16-bit index) into its own block of SvcParams::remote_store,
+// opens its SvcRemote and puts `tickets` into the service's help ring; a wave between two frames of its own that pops a
+// ticket attaches (compare-and-swap on SvcRemote::state), copies the store into its own LDS block and casts the candidates the
+// owner posts in SvcRemote::ring -- exactly what a helper of the owner's workgroup does through LDS, with 8-byte agent-scope
+// granules in global memory instead.  The owner matches results to pixels and visits the scan's pixels in the scan's order:
+// lines, rounds and sample counts are the sequential reference's whoever cast what (a cast is a pure function of mask and pixel).
+#define SVC_REMOTE_RING 12u             // posts a frame may have out to helpers of other workgroups
+#define SVC_REMOTE_OPEN 0x80000000ull
+struct SvcRemoteEntry {                 // 64 bytes
+	unsigned long long post;            // owner -> helpers: k32 << 32 | py16 << 16 | px16 (k = 1, 2, ...: the request's posts in order; 0 = none); one 8-byte agent-scope granule
+	unsigned long long claim;           // the highest k anybody has taken (atomic max: a helper to cast it, or the owner taking it back)
+	// helper -> owner: the result as two 16-byte granules, each written by ONE write-through store and read by ONE 16-byte load,
+	// each carrying the post's number -- a half is valid when its k is the one waited for, whatever the order the two arrive in
+	// (one round trip for the owner instead of tag-then-payload):
+	uint32_t res_a[4];                  //   k, mask samples, len^2 bits of the longest exactly evaluated ray (0: none), its ray index
+	uint32_t res_b[4];                  //   k, ex bits, ey bits (that ray's end point), start point: (2 pty)16 << 16 | (2 ptx)16 (get_centre yields multiples of 0.5)
+	unsigned long long pad[2];
+};
+struct SvcRemote {                      // one per wave of the service launch (owner = workgroup * waves + wave)
+	unsigned long long state;           // request number32 << 32 | SVC_REMOTE_OPEN | helpers attached
+	unsigned long long info;            // non-empty tiles of the frame's store (what a helper has to copy), written before the request opens
+	unsigned long long pad[6];
+	SvcRemoteEntry ring[SVC_REMOTE_RING];
+};
+#define SVC_HELP_RING 256u              // tickets in flight (a power of two)
 struct SvcCtl {
 	// (avail and closing are what an idle wave looks at: one 8-byte load.  Every idle wave of the chip polls this one address,
 	// i.e. one memory channel: smh_service.inc spaces the polls out -- at 2 us per wave the streaming pass beside them took 1.6 ms
 	// instead of 0.9: a pass is as slow as its slowest channel)
 	int32_t avail;                      // items published and not yet claimed (semaphore; transiently negative)
 	uint32_t closing;                   // epoch of the service launch that has closed
+	int32_t help_avail;                 // help tickets nobody has taken (semaphore): the second word of an idle wave's look
+	uint32_t help_head, help_reserve;   // help tickets handed out / reserved by owners
+	uint32_t stat_remote;               // diagnostics: candidates cast for frames of other workgroups
 	uint32_t head;                      // tickets handed out
 	uint32_t reserve;                   // ring entries reserved by publishers
 	uint32_t completed;                 // submissions finished (counts like SvcHost::state >> 1)
@@ -186,8 +219,16 @@ struct SvcCtl {
 	unsigned long long stat_busy, stat_life;   // cycles spent on frames / between a wave's first poll and its exit, summed over those waves
 	unsigned long long stat_phase[4];   // of stat_busy: acquire (cache invalidation), tile store + search, record (scale ratio + derived outputs), release + count
 	unsigned long long stat_help;       // cycles spent casting candidates for other waves' frames (not in stat_busy)
-	uint32_t pad[2];
-	// ring entries follow: gen32 << 32 | slot << 24 | frame, gen = (ticket >> log2 cap) + 1
+	uint32_t stat_requests, stat_attached;   // help requests opened across workgroups; helpers that attached to one
+	// where a submission's time goes, in ticks of s_memrealtime (100 MHz), summed: publication -> a wave takes the frame (per frame);
+	// publication -> the submission's last frame is counted off (per submission); how long that last frame itself was at work
+	unsigned long long stat_t_wait, stat_t_sub, stat_t_last;
+	// helpers of other workgroups' frames: polls of a request's ring, polls that found nothing to take, claims lost to somebody quicker, exits because
+	// nothing came / the request closed, cycles attached
+	uint32_t stat_h_polls, stat_h_empty, stat_h_lost, stat_h_idle_exit, stat_h_closed_exit, stat_h_pad;
+	unsigned long long stat_h_cycles, stat_h_cast_cycles;
+	unsigned long long help_ring[SVC_HELP_RING];   // ticket gen32 << 32 | request number16 << 16 | owner16
+	// (the item ring is an allocation of its own: gen32 << 32 | slot << 24 | frame, gen = (ticket >> log2 cap) + 1)
 };
 struct SvcHost {
 	// submissions so far << 32 | epoch of the service launch that is alive (0: none).  The host adds submissions and -- only
@@ -214,9 +255,19 @@ struct SvcParams {
 	uint32_t epoch;                     // of this launch (> 0)
 	uint32_t idle_short, idle_long;     // in units of 1024 cycles
 	uint32_t flags;                     // experiments (SMH_SVC_FLAGS; results may be WRONG): 1 = no cache invalidation per item, 2 = no write-back per frame, 4 = s_setprio 3, 8 = no helping among the waves of a workgroup
+	// help across workgroups (null / 0: none)
+	SvcRemote *remote;                  // one per wave of the launch
+	uint32_t *remote_store;             // owner o's tile store: remote_store + o * remote_store_words
+	uint32_t remote_store_words;
+	uint32_t remote_after;              // rounds a frame works (with its workgroup's help) before it asks the other workgroups
+	uint32_t remote_tickets;            // helpers it asks for
+	uint32_t remote_last_div;           // ... once it is among the last 1 / remote_last_div of its submission's frames still at work
+	// (flags & 16: frames ask, and waves take tickets, whether or not frames are waiting for a wave -- A/B)
 };
 // waves per service workgroup and LDS per workgroup for this frame size (0 waves: the frame size does not fit -> no service)
 uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes);
+uint32_t svc_store_words_for(const Geom &g, uint32_t tile_cap);   // words of a frame's tile store (tiles + index), rounded up to whole 16-byte quads
+hipError_t svc_probe_host_atomics(SvcHost *h, SvcHost *d_h, bool *ok);   // pipeline creation: do device-side system-scope atomics reach mapped host memory?
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s);
 hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s);
 

@@ -1468,6 +1468,31 @@ uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words,
 	return w;
 }
 
+uint32_t svc_store_words_for(const Geom &g, uint32_t tile_cap) { return (tile_mask_words(g.rw, g.rh, tile_cap) + 7u) & ~3u; }
+
+// -> *ok: a device-side 64-bit system-scope compare-and-swap on the mapped host block `h` (device address d_h) took effect
+// and the host sees it (synchronous; pipeline creation)
+hipError_t svc_probe_host_atomics(SvcHost *h, SvcHost *d_h, bool *ok) {
+	*ok = false;
+	uint32_t *d_ok = nullptr;
+	hipError_t e = hipMalloc((void **)&d_ok, sizeof(uint32_t));
+	if (e != hipSuccess) return e;
+	const unsigned long long expect = 0x0123456789ABCDEFull, desired = 0xFEDCBA9876543210ull;
+	unsigned long long *w = (unsigned long long *)&h->pad[0];
+	__atomic_store_n(w, expect, __ATOMIC_RELEASE);
+	__atomic_store_n(&h->pad[2], 0u, __ATOMIC_RELEASE);
+	e = hipMemset(d_ok, 0, sizeof(uint32_t));
+	uint32_t dev_ok = 0;
+	if (e == hipSuccess) { hipLaunchKernelGGL(k_svc_probe, dim3(1), dim3(1), 0, nullptr, d_h, expect, desired, d_ok); e = hipGetLastError(); }
+	if (e == hipSuccess) e = hipMemcpy(&dev_ok, d_ok, sizeof dev_ok, hipMemcpyDeviceToHost);   // (synchronises with the probe)
+	(void)hipFree(d_ok);
+	if (e != hipSuccess) return e;
+	*ok = dev_ok == 1u && __atomic_load_n(w, __ATOMIC_ACQUIRE) == desired && __atomic_load_n(&h->pad[2], __ATOMIC_ACQUIRE) == 0x600Du;
+	__atomic_store_n(w, 0ull, __ATOMIC_RELEASE);
+	__atomic_store_n(&h->pad[2], 0u, __ATOMIC_RELEASE);
+	return hipSuccess;
+}
+
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s) {
 	hipLaunchKernelGGL(k_svc_publish, dim3(1), dim3(256), 0, s, ctl, ring, slots, slot, b, n, seq, ring_log2);
 	return hipGetLastError();

@@ -441,6 +441,11 @@ extern "C" SMHV_API int smhv_debug_skip_line_search(int on) {
 	return SMHV_OK;
 }
 
+static std::atomic<bool> g_no_host_atomics{false};
+extern "C" SMHV_API int smhv_debug_no_host_atomics(int on) {
+	g_no_host_atomics.store(on != 0, std::memory_order_relaxed);
+	return SMHV_OK;
+}
 extern "C" SMHV_API int smhv_debug_lsd_threads(uint32_t threads) {
 	if (threads != 0 && (threads < 128 || threads > 1024 || threads % 64)) return fail(SMHV_E_INVALID, "lsd_threads: 0 or a multiple of 64 from 128 to 1024");
 	lsd_set_threads(threads);
@@ -619,7 +624,8 @@ extern "C" SMHV_API int smhv_batch_enable_timing(smhv_batch *b, int enable) {
 // s_pro: the pipeline's prologue stream -- the anchor upload and the button test of a submission run there, ahead of time, so
 // that the chain on a streaming stream is pass -> publication -> pass: the button test (45 us inside a busy pipeline, plus a
 // hand-over) is off it.
-struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro; };
+struct SvcPublish { SvcCtl *ctl; unsigned long long *ring; SvcSlot *slots; uint32_t slot, seq, ring_log2; const uint32_t *cull_tab; bool have_cull; hipStream_t s_pro; hipEvent_t ev_pro;
+                    bool *published; };   // <- set once k_svc_publish has been enqueued (from then on the device WILL complete the submission)
 static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint32_t stages, int grayscale, uint32_t max_gap,
                           const smhv_anchors *anchors, hipStream_t s, hipStream_t sl, const SvcPublish *svc = nullptr) {
 	if (!b || !d_frames || n == 0 || n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments (n=%u, capacity %u)", n, b ? b->max_frames : 0);
@@ -698,6 +704,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 		bf.rec_bars = b->d_bars;
 		STAGE_BEGIN(3, s);
 		HIPCHK(launch_svc_publish(svc->ctl, svc->ring, svc->slots, svc->slot, bf, n, svc->seq, svc->ring_log2, s));
+		if (svc->published) *svc->published = true;
 		STAGE_END(3, s);
 		STAGE_BEGIN(4, s);
 		STAGE_END(4, s);
@@ -888,7 +895,13 @@ struct smhv_pipeline {
 	unsigned long long *d_svc_ring = nullptr;
 	SvcSlot *d_svc_slots = nullptr;
 	SvcHost *h_svc = nullptr, *d_svc_host = nullptr;
+	SvcRemote *d_svc_remote = nullptr;  // help across workgroups: one exchange block and one tile-store block per wave of the service
+	uint32_t *d_svc_store = nullptr;
+	uint32_t svc_store_words = 0;
 	hipStream_t s_search = nullptr, s_pro = nullptr;   // (s_pro: anchor uploads and button tests, ahead of the streaming streams)
+	std::mutex peek_mu;                 // smhv_debug_pipeline_peek (any thread)
+	hipStream_t s_peek = nullptr;
+	SvcCtl *h_peek = nullptr;
 	std::vector<hipEvent_t> ev_pub;     // per slot: the slot's items have been published
 	std::vector<hipEvent_t> ev_pro;     // per slot: its button test has run
 	std::vector<uint32_t> seq;          // per slot: sequence number of its most recent submission (0: none yet)
@@ -942,11 +955,15 @@ extern "C" SMHV_API void smhv_pipeline_destroy(smhv_pipeline *p) {
 	if (p->ctx) g_own_queues[(uint32_t)p->ctx->device & 63u].fetch_sub((int)p->own_queues, std::memory_order_relaxed);
 	if (p->s_search) (void)hipStreamDestroy(p->s_search);
 	if (p->s_pro) (void)hipStreamDestroy(p->s_pro);
+	if (p->s_peek) (void)hipStreamDestroy(p->s_peek);
+	if (p->h_peek) (void)hipHostFree(p->h_peek);
 	for (auto e : p->ev_pub) if (e) (void)hipEventDestroy(e);
 	for (auto e : p->ev_pro) if (e) (void)hipEventDestroy(e);
 	if (p->d_svc_ctl) (void)hipFree(p->d_svc_ctl);
 	if (p->d_svc_ring) (void)hipFree(p->d_svc_ring);
 	if (p->d_svc_slots) (void)hipFree(p->d_svc_slots);
+	if (p->d_svc_remote) (void)hipFree(p->d_svc_remote);
+	if (p->d_svc_store) (void)hipFree(p->d_svc_store);
 	if (p->h_svc) (void)hipHostFree(p->h_svc);
 	ctx_release(p->ctx);
 	delete p;
@@ -1017,6 +1034,30 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		delete p;
 		return fail(SMHV_E_INVALID, "pipeline_create_ex: the frame-granular search needs depth >= 3 and a frame size whose mask tiles fit the LDS beside the streaming pass (%ux%u, depth %u)", W, H, depth);
 	}
+	if (p->svc) {
+		// The service's life cycle is a handshake of 64-bit system-scope atomics on mapped host memory (SvcHost).  A platform that
+		// does not route them (no PCIe atomics: some hosts, VMs, passthrough) would leave a launch that can never close: ask the
+		// runtime, then try one.  Without them: the batch-granular search (an explicit SMHV_SEARCH_FRAME is an error).
+		bool atomics_ok = false;
+		int native = 0;
+		hipError_t ea = hipHostMalloc((void **)&p->h_svc, sizeof(SvcHost), hipHostMallocMapped | hipHostMallocCoherent);
+		if (ea == hipSuccess) { memset(p->h_svc, 0, sizeof(SvcHost)); ea = hipHostGetDevicePointer((void **)&p->d_svc_host, p->h_svc, 0); }
+		if (ea == hipSuccess && hipDeviceGetAttribute(&native, hipDeviceAttributeHostNativeAtomicSupported, c->device) != hipSuccess) { native = -1; (void)hipGetLastError(); }
+		if (ea == hipSuccess) ea = svc_probe_host_atomics(p->h_svc, p->d_svc_host, &atomics_ok);
+		if (g_no_host_atomics.load(std::memory_order_relaxed)) atomics_ok = false;
+		if (ea != hipSuccess || !atomics_ok) {
+			(void)hipGetLastError();
+			logf(c, 2, "pipeline: device-side atomics on mapped host memory %s (hipDeviceAttributeHostNativeAtomicSupported = %d): no frame-granular search",
+			     ea != hipSuccess ? hipGetErrorString(ea) : "do not take effect", native);
+			if (p->h_svc) { (void)hipHostFree(p->h_svc); p->h_svc = nullptr; p->d_svc_host = nullptr; }
+			p->svc = false;
+			if (opt.search == SMHV_SEARCH_FRAME) {
+				ctx_release(c);
+				delete p;
+				return fail(SMHV_E_INVALID, "pipeline_create_ex: the frame-granular search needs device-side 64-bit atomics on mapped host memory (PCIe atomics), which this platform does not provide");
+			}
+		}
+	}
 	p->batch.assign(depth, nullptr); p->done.assign(depth, nullptr); p->hold.assign(depth, nullptr); p->held.assign(depth, 0); p->last_sl.assign(depth, nullptr);
 	hipError_t e = hipSuccess;
 	{
@@ -1079,9 +1120,14 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (e == hipSuccess) e = hipMemset(p->d_svc_ring, 0, sizeof(unsigned long long) << lg);
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_slots, sizeof(SvcSlot) * depth);
 		if (e == hipSuccess) e = hipMemset(p->d_svc_slots, 0, sizeof(SvcSlot) * depth);
-		if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_svc, sizeof(SvcHost), hipHostMallocMapped | hipHostMallocCoherent);
-		if (e == hipSuccess) { memset(p->h_svc, 0, sizeof(SvcHost)); e = hipHostGetDevicePointer((void **)&p->d_svc_host, p->h_svc, 0); }
-
+		if (!(opt.flags & (SMHV_PIPE_NO_REMOTE_HELP | SMHV_PIPE_NO_TEAM_HELP)) && (uint64_t)p->svc_wgs * p->svc_waves <= 0xFFFFu) {
+			// help across workgroups (smh_kernels.h): per wave of the launch an exchange block and room for its frame's tile store
+			const size_t owners = (size_t)p->svc_wgs * p->svc_waves;
+			p->svc_store_words = svc_store_words_for(g0, p->svc_tile_cap);
+			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_remote, sizeof(SvcRemote) * owners);
+			if (e == hipSuccess) e = hipMemset(p->d_svc_remote, 0, sizeof(SvcRemote) * owners);
+			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_store, sizeof(uint32_t) * owners * p->svc_store_words);
+		}
 	}
 	if (e != hipSuccess) { smhv_pipeline_destroy(p); return fail(SMHV_E_HIP, "pipeline streams / events: %s", hipGetErrorString(e)); }
 	for (uint32_t i = 0; i < depth; ++i) {
@@ -1136,6 +1182,12 @@ static int svc_launch(smhv_pipeline *p, uint32_t slot) {
 	sp.idle_short = p->opt.idle_close_us ? p->opt.idle_close_us * 2u : 100u;   // x 1024 cycles: ~45 us without work and nothing outstanding
 	sp.flags = (p->opt.flags & SMHV_PIPE_NO_TEAM_HELP) ? 8u : 0u;
 	sp.idle_long = 50000u;                                               // ~20 ms without work, nobody at work: the streaming side is stuck
+	if (p->opt.flags & SMHV_PIPE_HELP_FIRST) sp.flags |= 16u;
+	if (p->opt.flags & 32u) sp.flags |= 32u;
+	sp.remote = p->d_svc_remote; sp.remote_store = p->d_svc_store; sp.remote_store_words = p->svc_store_words;
+	sp.remote_after = p->opt.remote_after ? p->opt.remote_after : 24u;
+	sp.remote_tickets = std::min<uint32_t>(p->opt.remote_tickets ? p->opt.remote_tickets : 3u, 16u);
+	sp.remote_last_div = p->opt.remote_last ? p->opt.remote_last : 6u;
 	__atomic_fetch_or(&p->h_svc->state, (unsigned long long)sp.epoch, __ATOMIC_ACQ_REL);   // (the low half is 0: only then is this called)
 	hipError_t e = hipStreamWaitEvent(p->s_search, p->ev_pub[slot], 0);
 	if (e == hipSuccess) e = launch_lsd_service(p->batch[slot]->g, sp, p->svc_wgs, p->svc_waves, p->svc_lds, p->s_search);
@@ -1156,10 +1208,13 @@ static int svc_wait_slot(smhv_pipeline *p, uint32_t slot) {
 	uint64_t spins = 0;
 	struct timespec t0;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
-	while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != target) {
+	// (sequence numbers only grow, modulo 2^32: "reached" is a signed difference, so a slot whose flag has moved PAST the number
+	// waited for -- a submission the host gave up on but the device completed -- still reads as complete)
+	auto reached = [flag, target]() { return (int32_t)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - target) >= 0; };
+	while (!reached()) {
 		if (!svc_alive(p)) {
 			// no launch alive with work outstanding: the service gave way (its streaming side did not move for idle_long): again
-			if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == target) break;
+			if (reached()) break;
 			int rc = svc_launch(p, slot);
 			if (rc) return rc;
 		}
@@ -1196,7 +1251,20 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	if (want_cull) { rc = sector_table_for(p->ctx, max_gap, st, &probe); if (rc) return rc; }
 	if (!p->svc_key_valid || p->svc_cull != probe.cull_tab || p->svc_max_gap != max_gap) {
 		for (uint32_t i = 0; i < p->depth; ++i) { rc = svc_wait_slot(p, i); if (rc) return rc; }
-		while (svc_alive(p)) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+		struct timespec td0;
+		clock_gettime(CLOCK_MONOTONIC, &td0);
+		for (uint64_t spins = 0; svc_alive(p); ++spins) {      // (everything is complete: the launch closes within idle_short; bounded like svc_wait_slot)
+			struct timespec ts = {0, 20000}, td1;
+			nanosleep(&ts, nullptr);
+			if ((spins & 1023u) == 1023u) {
+				clock_gettime(CLOCK_MONOTONIC, &td1);
+				if (td1.tv_sec - td0.tv_sec > 60) {
+					const unsigned long long stw = __atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE);
+					return fail(SMHV_E_STATE, "pipeline_submit: the line-search service did not close within 60 s of its last submission (another gap threshold needs a new launch; "
+					            "submissions %u, launch alive %u, launches %u)", (uint32_t)(stw >> 32), (uint32_t)stw, p->h_svc->launches);
+				}
+			}
+		}
 		p->svc_key_valid = true; p->svc_cull = probe.cull_tab; p->svc_max_gap = max_gap;
 	}
 	// (what the submission has to wait for gates its first kernel: the button test, on the prologue stream when there is one;
@@ -1212,16 +1280,21 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	}
 	uint32_t seq = ++p->seq_counter;
 	if (seq == 0u) seq = ++p->seq_counter;
-	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot]};
+	bool published = false;
+	SvcPublish pub{p->d_svc_ctl, p->d_svc_ring, p->d_svc_slots, slot, seq, p->svc_ring_log2, probe.cull_tab, true, p->s_pro, p->ev_pro[slot], &published};
 	// The submission is counted BEFORE its kernels are enqueued: from here on the service does not regard itself as drained
 	// (were it counted afterwards, its items could be there -- and a wave at work on them -- while the count still said
 	// "everything complete", and the service would close under that wave).
 	__atomic_fetch_add(&p->h_svc->state, 1ull << 32, __ATOMIC_ACQ_REL);
 	rc = batch_run_impl(b, d_frames, n, stages, grayscale, max_gap, anchors, st, st, &pub);
-	if (rc) {
+	if (rc && !published) {
 		__atomic_fetch_sub(&p->h_svc->state, 1ull << 32, __ATOMIC_ACQ_REL);   // nothing of it was published: take the count back
 		return rc;
 	}
+	// (an error AFTER the publication kernel went in -- a failing event record, a sticky error of some earlier call: the device
+	// completes the submission all the same, so it stays counted and the slot waits for ITS sequence number; the error is
+	// still the caller's)
+	const int rc_late = rc;
 	p->seq[slot] = seq;
 	p->slot_st[slot] = st;
 	p->last_sl[slot] = st;
@@ -1235,7 +1308,7 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	}
 	p->submitted++;
 	if (slot_out) *slot_out = slot;
-	return SMHV_OK;
+	return rc_late;
 }
 
 
@@ -1396,9 +1469,9 @@ extern "C" SMHV_API int smhv_pipeline_wait_all(smhv_pipeline *p) {
 	return rc;
 }
 
-extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[16]) {
+extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out[32]) {
 	if (!p || !out) return fail(SMHV_E_INVALID, "bad arguments");
-	memset(out, 0, sizeof(uint64_t) * 16);
+	memset(out, 0, sizeof(uint64_t) * 32);
 	if (!p->svc) return SMHV_OK;
 	HIPCHK(hipSetDevice(p->ctx->device));
 	HIPCHK(hipDeviceSynchronize());                           // (the service closes by itself once nothing is outstanding)
@@ -1408,6 +1481,9 @@ extern "C" SMHV_API int smhv_debug_pipeline_stats(smhv_pipeline *p, uint64_t out
 	out[6] = (uint64_t)p->svc_wgs * p->svc_waves; out[7] = c.completed;
 	for (int k = 0; k < 4; ++k) out[8 + k] = c.stat_phase[k];
 	out[12] = c.stat_help;
+	out[16] = c.stat_requests; out[17] = c.stat_attached; out[18] = c.stat_remote; out[19] = (uint64_t)(int64_t)c.help_avail;
+	out[20] = c.stat_t_wait; out[21] = c.stat_t_sub; out[22] = c.stat_t_last;
+	out[23] = c.stat_h_polls; out[24] = c.stat_h_empty; out[25] = c.stat_h_lost; out[26] = c.stat_h_idle_exit; out[27] = c.stat_h_closed_exit; out[28] = c.stat_h_cycles; out[29] = c.stat_h_cast_cycles;
 	out[13] = (p->adaptive ? 2u : 0u) | (p->mode_frame ? 1u : 0u) | (p->mc.phase == 4u ? 4u : 0u); out[14] = (uint64_t)p->mc.rate[1]; out[15] = (uint64_t)p->mc.rate[0];
 	return SMHV_OK;
 }
@@ -1421,12 +1497,13 @@ extern "C" SMHV_API int smhv_debug_pipeline_peek(smhv_pipeline *p, uint64_t out[
 	const unsigned long long st = __atomic_load_n(&p->h_svc->state, __ATOMIC_ACQUIRE);
 	out[0] = st >> 32; out[1] = (uint32_t)st; out[2] = p->h_svc->launches; out[3] = p->seq_counter;
 	out[14] = ((uint64_t)p->svc_wgs << 32) | p->svc_waves; out[15] = ((uint64_t)p->svc_part_words << 32) | p->svc_lds;   // geometry of the service's launches
-	static hipStream_t s_peek = nullptr;
-	if (!s_peek) HIPCHK(hipStreamCreateWithFlags(&s_peek, hipStreamNonBlocking));
-	static SvcCtl *h_ctl = nullptr;
-	if (!h_ctl) HIPCHK(hipHostMalloc((void **)&h_ctl, sizeof(SvcCtl)));
-	HIPCHK(hipMemcpyAsync(h_ctl, p->d_svc_ctl, sizeof(SvcCtl), hipMemcpyDeviceToHost, s_peek));
-	HIPCHK(hipStreamSynchronize(s_peek));
+	// (callable from another thread while a wait is stuck: its stream and staging block belong to the pipeline, under a lock)
+	std::lock_guard<std::mutex> lk(p->peek_mu);
+	if (!p->s_peek) HIPCHK(hipStreamCreateWithFlags(&p->s_peek, hipStreamNonBlocking));
+	if (!p->h_peek) HIPCHK(hipHostMalloc((void **)&p->h_peek, sizeof(SvcCtl)));
+	SvcCtl *h_ctl = p->h_peek;
+	HIPCHK(hipMemcpyAsync(h_ctl, p->d_svc_ctl, sizeof(SvcCtl), hipMemcpyDeviceToHost, p->s_peek));
+	HIPCHK(hipStreamSynchronize(p->s_peek));
 	out[4] = (uint64_t)(int64_t)h_ctl->avail; out[5] = h_ctl->head; out[6] = h_ctl->reserve; out[7] = h_ctl->closing; out[8] = h_ctl->completed; out[9] = h_ctl->busy;
 	for (uint32_t i = 0; i < 4 && i < p->depth; ++i) out[10 + i] = ((uint64_t)p->seq[i] << 32) | __atomic_load_n(&p->h_svc->done_seq[i], __ATOMIC_ACQUIRE);
 	return SMHV_OK;

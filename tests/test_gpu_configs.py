@@ -312,6 +312,95 @@ def test_sample_screenshots_through_the_batch_path(vision):
         lib.smhv_debug_lsd_tile_cap(0)
 
 
+def test_sample_screenshots_through_the_search_service(vision):
+    """The same screenshots through the pipelined line search, k_lsd_service (one wave per frame, help desk, helpers of other
+    workgroups): grouped by size, at depth 3 and 12, culled and exact statistics, the tile store at its own cap and capped at
+    64 tiles (the larger scenes then go through the global-memory scan inside the service).  More submissions than slots, so
+    that slots are reused while waves are still helping; lines, rounds and (exact) sample counts against the goldens."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    import fixtures as fx
+    lib = smh._lib.load()
+    by_size = {}
+    for stem in fx.OPEN_STEMS:
+        frame, e, g = fx.load_fixture(stem)
+        by_size.setdefault(frame.shape[:2], []).append((stem, frame, e, g))
+    try:
+        for (H, W), items in sorted(by_size.items()):
+            frames = np.stack([it[1] for it in items])
+            n = len(items)
+            d = torch.from_numpy(frames).cuda()
+            for depth in (3, 12):
+                for cap in (0, 64):
+                    lib.smhv_debug_lsd_tile_cap(cap)          # (read when the pipeline is created)
+                    pipe = smh.Pipeline(vision, W, H, n, depth, search="frame")
+                    lib.smhv_debug_lsd_tile_cap(0)
+                    for exact in (0, smh.STAGE_EXACT_STATS, 0):
+                        slots = [pipe.submit(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=15) for _ in range(depth + 2)]
+                        pipe.wait()
+                        for s_ in sorted(set(slots)):
+                            got = smh.results_to_dicts(pipe.slots[s_].read_results(0, n))
+                            for i, (stem, _, e, g) in enumerate(items):
+                                assert got[i]["n_lines"] == len(g["lines"]) and np.array_equal(got[i]["lines"], g["lines"]), (stem, depth, cap, s_, bool(exact))
+                                assert got[i]["rounds"] == e["rounds"], (stem, depth, cap, s_, bool(exact))
+                                if exact:
+                                    assert got[i]["ray_steps"] == e["steps"], (stem, depth, cap, s_)
+                    pipe.close()
+    finally:
+        lib.smhv_debug_lsd_tile_cap(0)
+
+
+def test_search_service_1440p_geometry_with_frames_beyond_its_tile_store(vision):
+    """Above 1080p the service runs three waves per workgroup with a tile store of 272 tiles (smh_runtime.cpp,
+    SMH_SVC_TILE_LIMIT).  The reference's 1440p screenshots stay below that (<= 261 tiles); here they are run in a batch
+    together with copies that carry a few hundred extra marker specks each -- more non-empty tiles than the store holds, so
+    those frames take the service's scan on the mask in global memory while their neighbours take the tile store and ask
+    for help.  Every record against the oracle, culled and exact."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    import fixtures as fx
+    W, H = 2560, 1440
+    base = [fx.load_fixture(stem)[0] for stem in fx.OPEN_STEMS]
+    base = [f for f in base if f.shape[:2] == (H, W)]
+    assert len(base) >= 4
+    rng = np.random.default_rng(272)
+    x, y, rw, rh = smh.map_bounds(W, H)
+    frames = []
+    for k, f in enumerate(base):
+        frames.append(f)
+        if k % 7 == 0:
+            g = f.copy()
+            m = 300 + 10 * k
+            g[y + rng.integers(0, rh, m), x + rng.integers(0, rw, m)] = PURPLE
+            frames.append(g)
+    frames = np.stack(frames)
+    n = len(frames)
+    ref = o.process_batch(frames, min(os.cpu_count() or 1, n), stages=0x1, max_gap=15)
+    # (32 x 8 px tiles of the dilated mask, as frame_setup_tile counts them)
+    tiles = []
+    for f in frames[:]:
+        mask = o.mask_marker_lines(np.ascontiguousarray(f[y:y + rh, x:x + rw, 2::-1])) != 0
+        mp = np.zeros(((rh + 7) // 8 * 8, (rw + 31) // 32 * 32), bool)
+        mp[:rh, :rw] = mask
+        tiles.append(int(mp.reshape(mp.shape[0] // 8, 8, mp.shape[1] // 32, 32).any(axis=(1, 3)).sum()))
+    assert max(tiles) > 272 and min(tiles) <= 261, tiles
+    d = torch.from_numpy(frames).cuda()
+    pipe = smh.Pipeline(vision, W, H, n, 12, search="frame")
+    geo = pipe.peek()
+    assert geo["waves_per_workgroup"] == 3 and geo["service_workgroups"] < 256, geo
+    for exact, subs in ((0, 14), (smh.STAGE_EXACT_STATS, 3), (0, 3)):
+        slots = [pipe.submit(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=15) for _ in range(subs)]
+        pipe.wait()
+        for s_ in sorted(set(slots)):
+            got = smh.results_to_dicts(pipe.slots[s_].read_results(0, n))
+            for i in range(n):
+                assert got[i]["n_lines"] == ref[i].n_lines and np.array_equal(got[i]["lines"], _lines(ref[i])), (i, s_, bool(exact), tiles[i])
+                assert got[i]["rounds"] == ref[i].rounds, (i, s_, bool(exact), tiles[i])
+                if exact:
+                    assert got[i]["ray_steps"] == ref[i].steps, (i, s_, tiles[i])
+    pipe.close()
+
+
 def test_8k_frames_take_the_large_tile_index(vision):
     """7680x4320: the 16-bit tile index of the map ROI alone is 106 KB, so k_lsd_tile runs one workgroup per CU with 140 KB of
     dynamic LDS instead of two with 60 KB each.  Two synthetic frames, both line-search kernels, against the oracle."""
@@ -404,6 +493,44 @@ def test_fused_streaming_pass_on_threshold_frames(vision):
                 if (stages & 0x8) and per[i][1]:
                     assert np.array_equal(fb.read_image(smh._lib.VIEW_FIND_SCALES_INPUT, i)[per[i][0]:], ref["scales"][per[i][0]:]), (W, H, stages, i)
         fb.close()
+
+
+def test_pipeline_without_host_atomics_keeps_the_batch_granular_search(vision):
+    """The search service's life cycle needs device-side 64-bit atomics on mapped host memory; smhv_pipeline_create probes for
+    them.  With the probe's answer forced to "no" (smhv_debug_no_host_atomics): the default search of a deep pipeline is the
+    batch-granular one (no service: search_stats() is None), an explicit "frame" is E_INVALID, and the records are those of a
+    plain run."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    lib = smh._lib.load()
+    W, H, N = 1920, 1080, 12
+    fr, inf = synth.make_batch(W, H, N, first_idx=4100, n_lines=3)
+    d = torch.from_numpy(fr).cuda()
+    a = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in inf])
+    fb = smh.FrameBatch(vision, W, H, N)
+    fb.run(d.data_ptr(), N, anchors=a, stream=torch.cuda.current_stream().cuda_stream)
+    want = bytes(fb.read_results(0, N))
+    fb.close()
+    lib.smhv_debug_no_host_atomics(1)
+    try:
+        with pytest.raises(smh.VisionError) as ei:
+            smh.Pipeline(vision, W, H, N, 8, search="frame")
+        assert ei.value.code == smh._lib.E_INVALID and "atomics" in str(ei.value)
+        pipe = smh.Pipeline(vision, W, H, N, 8)
+        slots = [pipe.submit(d.data_ptr(), N, anchors=a) for _ in range(10)]
+        pipe.wait()
+        assert pipe.search_stats() is None
+        for s_ in sorted(set(slots)):
+            assert bytes(pipe.slots[s_].read_results(0, N)) == want, s_
+        pipe.close()
+    finally:
+        lib.smhv_debug_no_host_atomics(0)
+    pipe = smh.Pipeline(vision, W, H, N, 8, search="frame")             # (the probe itself passes on this machine)
+    s_ = pipe.submit(d.data_ptr(), N, anchors=a)
+    pipe.wait()
+    assert bytes(pipe.slots[s_].read_results(0, N)) == want
+    pipe.close()
 
 
 def test_pipeline_object_gives_the_records_of_plain_runs(vision):

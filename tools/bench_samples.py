@@ -38,7 +38,8 @@ def main():
         torch.cuda.synchronize()
     if os.environ.get("SAMPLES_FRAMES_FIRST"):
         d = torch.from_numpy(batch).cuda()
-    pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth, search=search, service_workgroups=int(os.environ.get("SAMPLES_WGS", "0")))
+    pipe = smh.Pipeline(vision, 2560, 1440, n, depth=depth, search=search, service_workgroups=int(os.environ.get("SAMPLES_WGS", "0")),
+                        flags=int(os.environ.get("SAMPLES_FLAGS", "0")), remote_after=int(os.environ.get("SAMPLES_AFTER", "0")), remote_tickets=int(os.environ.get("SAMPLES_TICKETS", "0")), remote_last=int(os.environ.get("SAMPLES_LAST", "0")))
     if not os.environ.get("SAMPLES_FRAMES_FIRST"):
         d = torch.from_numpy(batch).cuda()
     torch.cuda.synchronize()
@@ -63,7 +64,7 @@ def main():
     got = smh.results_to_dicts(pipe.slots[slot].read_results(0, n))
     pipe_stats = pipe.search_stats()
     if pipe_stats:
-        pipe_stats = {k: pipe_stats[k] for k in ("launches", "frames", "busy_fraction", "cycles_per_frame", "help_cycles_per_frame", "adaptive", "mode", "measured_frames_per_s") if k in pipe_stats}
+        pipe_stats = {k: pipe_stats[k] for k in ("launches", "frames", "busy_fraction", "cycles_per_frame", "help_cycles_per_frame", "remote_help", "timeline_ms", "adaptive", "mode", "measured_frames_per_s") if k in pipe_stats}
     t1 = time.perf_counter()
     ref = orc.process_batch(np.stack(frames), min(os.cpu_count() or 1, k), stages=STAGES, max_gap=15)
     cdt = time.perf_counter() - t1

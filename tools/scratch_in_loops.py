@@ -6,7 +6,7 @@ import os, re, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "..", "squad-mortar-helper_amd", "csrc")
 src = sys.argv[1] if len(sys.argv) > 1 else "smh_lsd.hip"
-flt = sys.argv[2] if len(sys.argv) > 2 else "svc_|k_lsd_service|seq_"
+flt = sys.argv[2] if len(sys.argv) > 2 else "svc_|k_lsd_service|seq_|remote_"
 extra = sys.argv[3:]
 out = subprocess.run(["make", "-pn", "-C", CSRC, "print-nothing"], capture_output=True, text=True).stdout
 arch = re.search(r"^ARCH \??:?= (.*)$", out, re.M).group(1).strip()

@@ -36,7 +36,7 @@ if _env("RATE_TILE_CAP"):                               # (process-wide diagnost
     smh._lib.load().smhv_debug_lsd_tile_cap(int(_env("RATE_TILE_CAP")))
 pipe = smh.Pipeline(vision, W, H, N, depth, search=_env("RATE_SEARCH", "auto"), streams=int(_env("RATE_STREAMS", "0")), idle_close_us=int(_env("RATE_IDLE_US", "0")),
                     service_workgroups=int(_env("RATE_WGS", "0")), flags=int(_env("RATE_FLAGS", "0")), occupancy_policy=int(_env("RATE_POLICY", "0")),
-                    late_helpers=int(_env("RATE_LATE", "0")))
+                    late_helpers=int(_env("RATE_LATE", "0")), remote_after=int(_env("RATE_AFTER", "0")), remote_tickets=int(_env("RATE_TICKETS", "0")), remote_last=int(_env("RATE_LAST", "0")))
 
 
 def watchdog():
