@@ -87,6 +87,12 @@ def parse_args():
                     help="diagnostic: create this many HIP streams before the pipeline (the schedule must not depend on them)")
     ap.add_argument("--search", default="auto", choices=("auto", "batch", "frame"),
                     help="line-search schedule of the pipeline (smhv_pipeline_options::search); auto: frame-granular from depth 8 on")
+    ap.add_argument("--room", default="auto", choices=("auto", "on", "off"),
+                    help="smhv_pipeline_options::room_for_others: the search kernel leaves an eighth of the CUs without a workgroup of its own so that "
+                         "other owners' kernels (RCCL's gather) find a CU; auto: on when --gpus > 1 (every pass gathers over RCCL), off for one GPU")
+    ap.add_argument("--side-probe", type=int, default=32,
+                    help="workgroups of the co-residency probe (a kernel with RCCL's footprint: 21 KB LDS, 280 VGPRs) launched once per pass beside "
+                         "a pipeline with room_for_others, after the timed region (N=1, config 2; 0 = skip): `co_residency` in the JSON line")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-real-samples", action="store_true", help="skip the leg on the reference's own 1440p screenshots (real_samples)")
@@ -229,6 +235,108 @@ def records_equal_oracle(np, rec, ref):
             and np.array_equal(rec["lines"], lines) and rec["mpx"] == (ref.mpx if ref.has_mpx else None))
 
 
+class DeviceWatch:
+    """Shader clock, temperature and power of the device while a region runs (sysfs hwmon of the amdgpu card, sampled by a thread
+    every 50 ms; best effort: None where the box does not show them).  A 513 k vs 551 k spread between boxes is attributable
+    only with these beside the value."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.files = {}
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(card, "vendor")).read().strip() != "0x1002":
+                    continue
+                if pci_bus_id and pci_bus_id.lower() not in os.path.realpath(card).lower():
+                    continue
+            except OSError:
+                continue
+            for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+                for key, names in (("sclk_mhz", ("freq1_input",)), ("temp_c", ("temp2_input", "temp1_input")), ("power_w", ("power1_average", "power1_input"))):
+                    for nm in names:
+                        fpath = os.path.join(hw, nm)
+                        if key not in self.files and os.path.exists(fpath):
+                            self.files[key] = fpath
+            if self.files:
+                break
+        self.samples = {k: [] for k in self.files}
+        self._stop = None
+        self._thr = None
+
+    def _read(self):
+        scale = {"sclk_mhz": 1e-6, "temp_c": 1e-3, "power_w": 1e-6}
+        for k, f in self.files.items():
+            try:
+                self.samples[k].append(float(open(f).read().strip()) * scale[k])
+            except (OSError, ValueError):
+                pass
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self._read()
+                self._stop.wait(0.05)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thr.join(timeout=1.0)
+
+    def summary(self):
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = {"min": min(v), "max": max(v), "mean": sum(v) / len(v), "samples": len(v)}
+        return out or None
+
+
+def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, probe_wgs, passes=300):
+    """Can a kernel of ANOTHER owner run beside the pipeline (never `value`)?  A pipeline created with room_for_others (what every
+    N > 1 run uses: its gather is an RCCL kernel) is saturated; once per pass a probe kernel with RCCL's footprint on gfx950 (21 KB
+    of LDS, 280 VGPRs per 256-thread workgroup; smhv_debug_side_kernel) goes onto a stream of its own.  -> the pipeline's rate
+    without and with the probes, and the probes' enqueue-to-completion times (hipEvents on the probe stream)."""
+    import numpy as np
+    lib = smh._lib.load()
+    pipe = smh.Pipeline(vision, W, H, n, depth, search="frame", room_for_others=1)
+    side = torch.cuda.Stream()
+
+    def run(with_probe):
+        for _ in range(2 * depth):
+            pipe.submit(fptr, n, stages=stages, anchors=anchors)
+        pipe.wait()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            pipe.submit(fptr, n, stages=stages, anchors=anchors)
+            if with_probe:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                smh._lib.check(lib.smhv_debug_side_kernel(vision._ctx, probe_wgs, side.cuda_stream))
+                e1.record(side)
+                evs.append((e0, e1))
+        pipe.wait()
+        dt = time.perf_counter() - t0
+        side.synchronize()
+        return n * passes / dt, (np.array([a.elapsed_time(b) for a, b in evs]) if evs else None)
+
+    r0, _ = run(False)
+    r1, lat = run(True)
+    r2, _ = run(False)
+    geo = pipe.peek()
+    pipe.close()
+    base = 0.5 * (r0 + r2)
+    return {"frames_per_s_without_probe": base, "frames_per_s_with_probe": r1, "cost": 1.0 - r1 / base,
+            "probe_ms": {"median": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
+            "probe": "%d workgroups x 256 threads, 21 KB LDS, 280 VGPRs (RCCL's kernels on gfx950: 19.7-21.2 KB, 261-280), one launch per pass on its own stream" % probe_wgs,
+            "service_workgroups": geo["service_workgroups"], "waves_per_workgroup": geo["waves_per_workgroup"], "pipeline_depth": depth, "passes": passes,
+            "note": "room_for_others = 1 (an eighth of the CUs without a search workgroup): what bench.py --gpus N > 1 and smhv_node run with"}
+
+
 def real_samples_leg(smh, torch, vision, depth, batch=128, steps=200):
     """The reference's own screenshots beside the synthetic scene (never `value`): the 2560x1440 open-map fixtures of
     tests/golden (crops of vision-common/samples/*, the images the reference's one GPU test runs on, vision-gpu/src/lib.rs:571)
@@ -268,7 +376,7 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=200):
     modes = {}
     dt, got = rate(depth)
     by_depth = {str(depth): batch * steps / dt}
-    for dep in (4, 8):                                     # (depth 4: the batch-granular search; 8 and up: the search service)
+    for dep in (4, 8, 20):                                 # (depth 4: the batch-granular search; 20: frames are cheap to keep in flight -- 24 GB of the 288)
         if dep != depth:
             dt2, got2 = rate(dep)
             by_depth[str(dep)] = batch * steps / dt2
@@ -609,7 +717,8 @@ def main():
     idle_streams = [torch.cuda.Stream() for _ in range(max(0, args.idle_streams))]   # noqa: F841 (kept alive on purpose)
     if args.tile_cap > 0:
         smh._lib.load().smhv_debug_lsd_tile_cap(args.tile_cap)
-    pipe = smh.Pipeline(vision, W, H, n, depth, search=args.search)
+    room = {"auto": 1 if (world > 1 and nccl) else 0, "on": 1, "off": 2}[args.room]
+    pipe = smh.Pipeline(vision, W, H, n, depth, search=args.search, room_for_others=room)
     anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 0x8 else None
     fptr = frames.data_ptr()
 
@@ -692,7 +801,16 @@ def main():
     if not args.no_stage_timing:
         for b in pipe.slots:
             b.enable_timing(True)
-    regions = timed(pipe, args.steps)
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        watch = DeviceWatch("%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id) if hasattr(pr, "pci_bus_id") and world > 1 else None)
+    except Exception:  # noqa: BLE001  (diagnostic only)
+        watch = None
+    if watch is not None and watch.files:
+        with watch:
+            regions = timed(pipe, args.steps)
+    else:
+        regions = timed(pipe, args.steps)
     stages_ms = None
     if not args.no_stage_timing:
         first = (args.warmup + extra_warmup) * rounds            # submissions before the timed region: slot = submission % depth
@@ -706,6 +824,7 @@ def main():
     dt_total = sum(dt for dt, _ in regions)
 
     svc_stats = pipe.search_stats()                     # the frame-granular line search's own counters (None: batch-granular search)
+    svc_geo = pipe.peek() if svc_stats else None
     # ---- every slot of the pipeline must hold the same records (same frames, same stages): byte for byte ----
     used = min(depth, args.steps * rounds + args.warmup * rounds)
     slot_bytes = [bytes(pipe.slots[s].read_results(0, n)) for s in range(used)]
@@ -810,7 +929,9 @@ def main():
                    "distinct_frames_per_gpu": (n if args.distinct <= 0 else min(args.distinct, n)),
                    "passes_per_step": rounds, "frames_per_step": frames_per_step,
                    "marker_lines_per_frame": args.lines, "parallelism": "frames block-sharded, dp%d" % world,
-                   "pipeline_depth": depth, "schedule": ("smhv_pipeline, frame-granular line search (k_lsd_service: one long-lived kernel pulls (slot, frame) items from a device ring)"
+                   "pipeline_depth": depth, "room_for_others": bool(room == 1),
+                   "service_workgroups": (svc_geo["service_workgroups"] if svc_geo else None), "service_waves_per_workgroup": (svc_geo["waves_per_workgroup"] if svc_geo else None),
+                   "schedule": ("smhv_pipeline, frame-granular line search (k_lsd_service: one long-lived kernel pulls (slot, frame) items from a device ring)"
                                 if svc_stats and svc_stats.get("mode") == "frame-granular" else "smhv_pipeline, batch-granular line search (one launch per batch)") +
                                ("; chosen by the pipeline's own measurement of both on this workload" if svc_stats and svc_stats.get("adaptive") else "")},
         "value_is": "median of %d sub-regions of the %d timed steps (each bracketed by barrier + synchronize)" % (len(regions), args.steps),
@@ -821,6 +942,7 @@ def main():
         "value_depth1": value_d1, "value_depth1_min_max": d1_minmax, "ms_per_pass_depth1": (ms_d1 / rounds if ms_d1 is not None else None),
         "h2d_seconds_for_batch": h2d_s,
         "search_service": svc_stats,
+        "device_during_timed_region": (watch.summary() if watch is not None else None),
         "all_map_open": bool(all_open),
         "slots_identical": bool(slots_identical), "slots_compared": used,
     }
@@ -839,18 +961,25 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         kname = "k_map_brq_pass" if (stages & 0xC) and (stages & 0x3) else "k_map_pass"
+        # `achieved` / `frac`: the kernel's algorithmic bytes per launch / its launch duration -- of a launch that runs ALONE when the
+        # isolated pass was timed (hipEvents on the launch's stream, live, after the timed region), which is the figure that
+        # says something about the kernel.  The launches INSIDE the timed region of a deep pipeline overlap each other and the
+        # search (their per-launch duration is a diagnostic: `in_pipeline`); what the whole pipeline moves per second is
+        # `pipeline_hbm_frac`.
         out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                            "algorithmic_bytes_per_frame": kernel_bytes, "launch_ms": stages_ms["map_pass"],
-                           "note": "launch duration from hipEvents on the launch's stream inside the timed region: with pipeline_depth > 1 "
-                                   "the launches of several batches overlap each other and the other batches' line-segment searches, so a "
-                                   "launch takes longer than the kernel needs while the pipeline as a whole moves more bytes per second "
-                                   "(pipeline_algorithmic_GBps); roofline_isolated is the same kernel in a pass that runs alone, with the "
-                                   "box's own device-copy rate beside it"}
+                           "launch_is": "inside the timed region (launches of several batches overlap)",
+                           "in_pipeline": {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "launch_ms": stages_ms["map_pass"],
+                                           "note": "per-launch figure of OVERLAPPING launches (two streaming launches and the search run side by side "
+                                                   "most of the time): a launch takes longer than the kernel needs while the pipeline as a whole moves "
+                                                   "more bytes per second -- a diagnostic, not a roofline fraction"}}
         if iso_ms is not None and iso_ms["map_pass"] > 0:
             a2 = n * kernel_bytes / (iso_ms["map_pass"] * 1e-3) / 1e9
             out["roofline_isolated"] = {"kernel": kname, "achieved": a2, "frac": a2 / HBM_PEAK_GBS, "unit": "GB/s",
                                         "launch_ms": iso_ms["map_pass"], "stages_ms": iso_ms}
+            out["roofline"].update({"achieved": a2, "frac": a2 / HBM_PEAK_GBS, "launch_ms": iso_ms["map_pass"],
+                                    "launch_is": "a launch that runs alone (plain smhv_batch_run after the timed region; hipEvents on its stream)"})
             if b2b_ms is not None:
                 a3 = n * kernel_bytes / (b2b_ms * 1e-3) / 1e9
                 out["roofline_isolated"]["back_to_back"] = {
@@ -929,6 +1058,7 @@ def main():
         out["stages_ms"] = stages_ms
         out["pipeline_algorithmic_GBps"] = value / world * full_bytes / 1e9
         out["pipeline_hbm_frac"] = value / world * full_bytes / 1e9 / HBM_PEAK_GBS
+        out["roofline"]["pipeline_frac"] = out["pipeline_hbm_frac"]   # algorithmic bytes of the WHOLE pipeline per second / peak: the aggregate that means something at depth > 1
         # the same with the MEASURED bytes of a whole pass (every kernel; committed PMC run) and against what this box copies at
         try:
             if tj.get("frame") == [W, H] and stages == tj.get("stages", 0xF) and tj.get("pass_bytes") and tj.get("frames"):
@@ -946,6 +1076,8 @@ def main():
     if args.ingest_frames > 0 and world == 1 and args.config == 2 and not custom:
         out["ingest"] = ingest_leg(smh, torch, vision, pipe, frames_host, anchors, stages, args.ingest_frames, W, H, n)
     pipe.close()                                           # (its streams hold hardware queues the next leg's pipelines should get)
+    if args.side_probe > 0 and world == 1 and args.config == 2 and not custom and depth >= 3:
+        out["co_residency"] = co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, args.side_probe)
     if not args.no_real_samples and world == 1 and args.config == 2 and not custom:
         out["real_samples"] = real_samples_leg(smh, torch, vision, depth)
 

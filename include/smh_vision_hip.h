@@ -260,6 +260,11 @@ SMHV_API int smhv_debug_lsd_spin_limit(uint32_t polls);
  * on mapped host memory (no PCIe atomics: smhv_pipeline_create probes for them) -- SMHV_SEARCH_AUTO keeps the batch-granular
  * search, an explicit SMHV_SEARCH_FRAME is SMHV_E_INVALID.  The tests use it to walk that path on a machine that has them. */
 SMHV_API int smhv_debug_no_host_atomics(int on);
+/* co-residency probe: launches, asynchronously on `stream`, `workgroups` (1..1024) 256-thread workgroups of a kernel with the
+ * footprint of a collective's kernel -- 21 KB of LDS and 280 VGPRs, what RCCL's kernels take on gfx950 -- that does next to
+ * nothing.  A host that runs kernels of its own beside a pipeline (RCCL, torch) can measure with it how soon they get onto the
+ * chip (tests/test_gpu_configs.py, bench.py --side-probe). */
+SMHV_API int smhv_debug_side_kernel(smhv_ctx *ctx, uint32_t workgroups, void *stream);
 /* ---- pipeline: several batches in flight, scheduled by the library ----------------------------------------------
  * `depth` output buffer sets (smhv_batch objects) of max_frames frames.  The library owns every stream of the schedule (created
  * in a fixed order: the throughput does not depend on what streams the host created before or on how it interleaves its calls).
@@ -317,6 +322,13 @@ typedef struct {
 	uint32_t remote_after;              /* frame-granular: search rounds after which a frame asks the waves of OTHER workgroups for help (0 = 24) */
 	uint32_t remote_tickets;            /*   ... and how many of them it asks for (0 = 3; at most 12 attach) */
 	uint32_t remote_last;               /*   ... once at most 1 / remote_last of its submission's frames are still at work (0 = 6) */
+	uint32_t room_for_others;           /* frame-granular: 1 = the search kernel leaves an eighth of the CUs without a workgroup of its own, so that kernels of
+	                                       OTHER owners (RCCL's: 21 KB of LDS and 280 VGPRs per workgroup; torch's) always find a CU to run on beside the pipeline.
+	                                       A search workgroup holds most of its CU's LDS for as long as the pipeline is busy: with one on EVERY CU (the default
+	                                       up to 1080p: the fastest when the pipeline has the GPU to itself, +7 %) such a kernel waits until the pipeline runs
+	                                       dry -- and holds up the queues behind it meanwhile (measured: seconds, and a quarter of the pipeline's rate).
+	                                       smhv_node_create sets it (its gather is an RCCL kernel); set it when the process launches anything else beside a
+	                                       pipeline.  0 = the library's choice (off; on for smhv_node), 1 = on, 2 = off */
 } smhv_pipeline_options;
 SMHV_API int smhv_pipeline_create_ex(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth,
                                      const smhv_pipeline_options *options, smhv_pipeline **out);
@@ -351,7 +363,9 @@ SMHV_API int smhv_debug_pipeline_peek(smhv_pipeline *p, uint64_t out[16]);
  *   run    : asynchronous; d_frames[i] = n[i] resident frames on devices[i] (n[i] <= max_frames_per_device, may be 0),
  *            anchors[i] (optional) the shard's anchors.
  *   gather : all records of the most recent run in device order (sum of n[i]) into `out`; synchronises.
- *   ctx    : the per-device context / pipeline (for uploads, images, device pointers). */
+ *   ctx    : the per-device context / pipeline (for uploads, images, device pointers).
+ *   depth  : slots of every device's pipeline; 0 = 12 (what bench.py runs one GPU with).  The pipelines are created with
+ *            smhv_pipeline_options::room_for_others: the gather's RCCL kernel has to find a CU beside the search kernel. */
 typedef struct smhv_node smhv_node;
 SMHV_API void smhv_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
 SMHV_API int smhv_node_create(const int *devices, uint32_t n_devices, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames_per_device,

@@ -116,6 +116,7 @@ SIGNATURES = {
     "smhv_debug_lsd_threads": (C.c_int, [C.c_uint32]),
     "smhv_debug_skip_line_search": (C.c_int, [C.c_int]),
     "smhv_debug_no_host_atomics": (C.c_int, [C.c_int]),
+    "smhv_debug_side_kernel": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "smhv_debug_pattern_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
@@ -137,7 +138,7 @@ SIGNATURES = {
 class PipelineOptions(C.Structure):
     """smhv_pipeline_options (include/smh_vision_hip.h): every 0 is the library's default."""
     _fields_ = [("size", C.c_uint32), ("search", C.c_uint32), ("streams", C.c_uint32), ("idle_close_us", C.c_uint32), ("occupancy_policy", C.c_uint32),
-                ("late_helpers", C.c_uint32), ("service_workgroups", C.c_uint32), ("flags", C.c_uint32), ("remote_after", C.c_uint32), ("remote_tickets", C.c_uint32), ("remote_last", C.c_uint32)]
+                ("late_helpers", C.c_uint32), ("service_workgroups", C.c_uint32), ("flags", C.c_uint32), ("remote_after", C.c_uint32), ("remote_tickets", C.c_uint32), ("remote_last", C.c_uint32), ("room_for_others", C.c_uint32)]
 
 
 SEARCH_AUTO, SEARCH_BATCH, SEARCH_FRAME = 0, 1, 2

@@ -154,7 +154,7 @@ class Pipeline:
         opt.size = C.sizeof(L.PipelineOptions)
         opt.search = {None: L.SEARCH_AUTO, "auto": L.SEARCH_AUTO, "batch": L.SEARCH_BATCH, "frame": L.SEARCH_FRAME}[search]
         for k, v in options.items():
-            if k not in ("streams", "idle_close_us", "occupancy_policy", "late_helpers", "service_workgroups", "flags", "remote_after", "remote_tickets", "remote_last"):
+            if k not in ("streams", "idle_close_us", "occupancy_policy", "late_helpers", "service_workgroups", "flags", "remote_after", "remote_tickets", "remote_last", "room_for_others"):
                 raise TypeError("Pipeline: unknown option %r" % k)
             setattr(opt, k, int(v))
         L.check(self._lib.smhv_pipeline_create_ex(vision._ctx, frame_w, frame_h, max_frames, depth, C.byref(opt), C.byref(p)))

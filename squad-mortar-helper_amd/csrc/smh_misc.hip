@@ -141,6 +141,23 @@ __global__ void k_marker_table(uint32_t *bits) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
+// Co-residency probe (smhv_debug_side_kernel): a kernel with the footprint of a collective's kernel -- RCCL's rcclGenericKernel on
+// gfx950 takes 19.7-21.2 KB of LDS and 261-280 VGPRs per 256-thread workgroup -- that does next to nothing.  What the tests and
+// bench.py measure with it is whether such a kernel gets onto the chip at all beside a saturated pipeline, and how soon.
+__global__ void __launch_bounds__(256) k_side_probe(uint32_t *out, uint32_t spin) {
+	__shared__ uint32_t lds[21u * 256u];                        // 21 KB
+	asm volatile("; the register footprint of the kernel this one stands in for" ::: "v255", "a23");   // 256 + 24 of the unified file
+	for (uint32_t i = threadIdx.x; i < 21u * 256u; i += blockDim.x) lds[i] = i ^ blockIdx.x;
+	__syncthreads();
+	uint32_t acc = lds[(threadIdx.x * 37u) % (21u * 256u)];
+	for (uint32_t i = 0; i < spin; ++i) acc = acc * 1664525u + 1013904223u;
+	if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+hipError_t launch_side_probe(uint32_t *d_out, uint32_t workgroups, uint32_t spin, hipStream_t s) {
+	hipLaunchKernelGGL(k_side_probe, dim3(workgroups), dim3(256), 0, s, d_out, spin);
+	return hipGetLastError();
+}
+
 hipError_t launch_scale_ratio(const Geom &g, const Buffers &b, uint32_t n, uint32_t *d_bars, hipStream_t s) {
 	hipLaunchKernelGGL(k_scale_ratio, dim3(n), dim3(64 * SMHV_MAX_SCALES), 0, s, g, b, d_bars);
 	return hipGetLastError();

@@ -117,7 +117,15 @@ extern "C" SMHV_API int smhv_node_create(const int *devices, uint32_t n_devices,
 	nd->n_last.assign(n_devices, 0); nd->slot_last.assign(n_devices, 0);
 	for (uint32_t i = 0; i < n_devices && !rc; ++i) {
 		rc = smhv_init(devices[i], log, &nd->ctx[i]);
-		if (!rc) rc = smhv_pipeline_create(nd->ctx[i], frame_w, frame_h, max_frames_per_device, depth ? depth : 4, &nd->pipe[i]);
+		if (!rc) {
+			// depth 0: what bench.py runs a single GPU with (12 slots, frame-granular search); the node's gather is an RCCL kernel, which
+			// needs a CU without a search workgroup to run on (smhv_pipeline_options::room_for_others)
+			smhv_pipeline_options opt;
+			memset(&opt, 0, sizeof opt);
+			opt.size = sizeof opt;
+			opt.room_for_others = 1u;
+			rc = smhv_pipeline_create_ex(nd->ctx[i], frame_w, frame_h, max_frames_per_device, depth ? depth : 12u, &opt, &nd->pipe[i]);
+		}
 		if (!rc) {
 			hipError_t e = hipSetDevice(devices[i]);
 			if (e == hipSuccess) e = hipStreamCreateWithFlags(&nd->gstream[i], hipStreamNonBlocking);

@@ -247,6 +247,7 @@ struct smhv_ctx {
 	uint32_t *sector_tab[SECTOR_CACHE] = {};
 	int sector_n = 0;
 	float *d_ray_off = nullptr;         // Buffers::ray_off (built at init, rebuilt by smhv_set_ray_table)
+	uint32_t *d_side = nullptr;         // smhv_debug_side_kernel's output words
 	std::mutex mu;                      // serialises (re)allocation only
 	// Lifetime: batches and ingest queues hold a reference, so smhv_shutdown with children still alive releases the
 	// context's own resources and marks it closed, and the object itself goes with the last child (their destroy
@@ -402,6 +403,7 @@ extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
 	for (int i = 0; i < c->sector_n; ++i) (void)hipFree(c->sector_tab[i]);
 	c->sector_n = 0;
 	if (c->d_ray_off) { (void)hipFree(c->d_ray_off); c->d_ray_off = nullptr; }
+	if (c->d_side) { (void)hipFree(c->d_side); c->d_side = nullptr; }
 	if (c->d_frame) (void)hipFree(c->d_frame);
 	if (c->h_ocr) (void)hipHostFree(c->h_ocr);
 	if (c->h_scales) (void)hipHostFree(c->h_scales);
@@ -444,6 +446,16 @@ extern "C" SMHV_API int smhv_debug_skip_line_search(int on) {
 static std::atomic<bool> g_no_host_atomics{false};
 extern "C" SMHV_API int smhv_debug_no_host_atomics(int on) {
 	g_no_host_atomics.store(on != 0, std::memory_order_relaxed);
+	return SMHV_OK;
+}
+// A kernel with the resource footprint of a collective's kernel (21 KB of LDS, 280 VGPRs per 256-thread workgroup) that does
+// next to nothing, asynchronous on `stream`: the co-residency probe of the tests and of bench.py --side-probe.
+extern "C" SMHV_API int smhv_debug_side_kernel(smhv_ctx *c, uint32_t workgroups, void *stream) {
+	if (!c || workgroups == 0 || workgroups > 1024u) return fail(SMHV_E_INVALID, "side_kernel: 1..1024 workgroups");
+	CTX_OPEN(c);
+	HIPCHK(hipSetDevice(c->device));
+	if (!c->d_side) HIPCHK(hipMalloc((void **)&c->d_side, 1024u * sizeof(uint32_t)));
+	HIPCHK(launch_side_probe(c->d_side, workgroups, 64u, (hipStream_t)stream));
 	return SMHV_OK;
 }
 extern "C" SMHV_API int smhv_debug_lsd_threads(uint32_t threads) {
@@ -1014,7 +1026,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (opt_in->size < 2 * sizeof(uint32_t) || opt_in->size > 4096u) return fail(SMHV_E_INVALID, "pipeline_create_ex: options.size is not set");
 		memcpy(&opt, opt_in, opt_in->size < sizeof opt ? opt_in->size : sizeof opt);   // (a caller built against an older, shorter struct)
 	}
-	if (opt.search > SMHV_SEARCH_FRAME || opt.occupancy_policy > 2u || opt.late_helpers > 2u || opt.streams > 8u)
+	if (opt.search > SMHV_SEARCH_FRAME || opt.occupancy_policy > 2u || opt.late_helpers > 2u || opt.streams > 8u || opt.room_for_others > 2u)
 		return fail(SMHV_E_INVALID, "pipeline_create_ex: bad option value");
 	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
@@ -1113,7 +1125,11 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		// and the others left to the streaming pass alone -- measured at 128 x 1440p, depth 12, one box, three waves per
 		// workgroup: 256 / 224 / 192 / 176 / 160 / 144 / 128 / 112 workgroups: 225 / 239 / 254 / 261 / 271 / 272 / 251 / 227 k
 		// frames/s (two waves per workgroup: 229 k with 256, 252 k with 192; 1080p, four waves: 540 / 531 / 514 / - / 490 k: every CU).
-		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(p->svc_waves >= 4u ? cus : cus * 5 / 8, 1);
+		// room_for_others: an eighth of the CUs stays without a service workgroup (measured with a 21 KB-LDS / 280-VGPR probe kernel
+		// launched once per submission beside a saturated 1080p pipeline: 224 of 256 workgroups -- every probe on the chip within
+		// 0.9 ms, the pipeline 0.3 % slower than without probes; 240 or 248 -- sometimes fine, sometimes seconds)
+		const int svc_cus = opt.room_for_others == 1u ? cus - std::max(cus / 8, 1) : cus;
+		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(p->svc_waves >= 4u ? svc_cus : std::min(cus * 5 / 8, svc_cus), 1);
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ctl, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMemset(p->d_svc_ctl, 0, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ring, sizeof(unsigned long long) << lg);

@@ -533,6 +533,72 @@ def test_pipeline_without_host_atomics_keeps_the_batch_granular_search(vision):
     pipe.close()
 
 
+def test_foreign_kernel_runs_beside_the_search_service(vision):
+    """A search workgroup holds most of its CU's LDS for as long as the pipeline is busy, so a kernel of another owner with a
+    large footprint -- RCCL's kernels on gfx950 take 19.7-21.2 KB of LDS and 261-280 VGPRs per workgroup -- fits no CU that
+    has one.  A pipeline created with room_for_others (what smhv_node and bench.py --gpus N > 1 use) leaves an eighth of the
+    CUs without: a probe kernel with that footprint (smhv_debug_side_kernel, 32 workgroups), launched once per pass on a
+    stream of its own beside a SATURATED frame-granular depth-12 pipeline at 1080p, gets onto the chip within a millisecond
+    every time and costs the pipeline under 5 %; the records stay those of a plain run."""
+    import time
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    lib = smh._lib.load()
+    W, H, N, depth, passes = 1920, 1080, 256, 12, 240
+    fr, inf = synth.make_batch(W, H, 64, first_idx=700, n_lines=2)
+    fr = np.concatenate([fr] * 4)
+    inf = [inf[i % 64] for i in range(N)]
+    d = torch.from_numpy(fr).cuda()
+    a = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in inf])
+    fb = smh.FrameBatch(vision, W, H, N)
+    fb.run(d.data_ptr(), N, anchors=a, stream=torch.cuda.current_stream().cuda_stream)
+    want = bytes(fb.read_results(0, N))
+    fb.close()
+    pipe = smh.Pipeline(vision, W, H, N, depth, search="frame", room_for_others=1)
+    geo = pipe.peek()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert geo["service_workgroups"] == cus - max(cus // 8, 1), geo
+    side = torch.cuda.Stream()
+
+    def run(with_probe):
+        for _ in range(2 * depth):
+            pipe.submit(d.data_ptr(), N, anchors=a)
+        pipe.wait()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            pipe.submit(d.data_ptr(), N, anchors=a)
+            if with_probe:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                smh._lib.check(lib.smhv_debug_side_kernel(vision._ctx, 32, side.cuda_stream))
+                e1.record(side)
+                evs.append((e0, e1))
+        pipe.wait()
+        dt = time.perf_counter() - t0
+        side.synchronize()
+        return N * passes / dt, np.array([x.elapsed_time(y) for x, y in evs]) if evs else None
+
+    best = None
+    for attempt in range(3):                                     # (a shared box: the best of three, each measured between two runs without probes)
+        r0, _ = run(False)
+        r1, lat = run(True)
+        r2, _ = run(False)
+        cost = 1.0 - r1 / (0.5 * (r0 + r2))
+        if best is None or cost < best[0]:
+            best = (cost, lat)
+        assert lat.max() < 20.0, (attempt, float(lat.max()))     # never the seconds a pipeline without room shows
+        if cost < 0.05 and np.percentile(lat, 99) < 1.0:
+            break
+    cost, lat = best
+    assert np.median(lat) < 1.0 and np.percentile(lat, 99) < 1.0, (float(np.median(lat)), float(np.percentile(lat, 99)), float(lat.max()))
+    assert cost < 0.05, cost
+    for s_ in range(depth):
+        assert bytes(pipe.slots[s_].read_results(0, N)) == want, s_
+    pipe.close()
+
+
 def test_pipeline_object_gives_the_records_of_plain_runs(vision):
     """smhv_pipeline_*: depth 1..4 with the batch-granular search, depth 3 / 4 / 8 with the frame-granular search service
     (with and without the workgroup help desk, with one and three streaming streams), with idle streams the host created

@@ -100,13 +100,15 @@ def test_pipeline_options_and_flags_match_the_header(built):
     assert (int(defs["SMHV_SEARCH_AUTO"]), int(defs["SMHV_SEARCH_BATCH"]), int(defs["SMHV_SEARCH_FRAME"])) == (_lib.SEARCH_AUTO, _lib.SEARCH_BATCH, _lib.SEARCH_FRAME)
     assert (int(defs["SMHV_PIPE_NO_TEAM_HELP"]), int(defs["SMHV_PIPE_NO_STREAM_PRIORITY"]), int(defs["SMHV_PIPE_NO_PROLOGUE"])) == \
         (_lib.PIPE_NO_TEAM_HELP, _lib.PIPE_NO_STREAM_PRIORITY, _lib.PIPE_NO_PROLOGUE)
-    assert int(defs["SMHV_INGEST_ROI_UPLOAD"]) == 1 and sorted(k for k in defs if k.startswith("SMHV_PIPE_")) == ["SMHV_PIPE_NO_PROLOGUE", "SMHV_PIPE_NO_STREAM_PRIORITY", "SMHV_PIPE_NO_TEAM_HELP"]
+    assert (int(defs["SMHV_PIPE_NO_REMOTE_HELP"]), int(defs["SMHV_PIPE_HELP_FIRST"])) == (_lib.PIPE_NO_REMOTE_HELP, _lib.PIPE_HELP_FIRST)
+    assert int(defs["SMHV_INGEST_ROI_UPLOAD"]) == 1 and sorted(k for k in defs if k.startswith("SMHV_PIPE_")) == \
+        ["SMHV_PIPE_HELP_FIRST", "SMHV_PIPE_NO_PROLOGUE", "SMHV_PIPE_NO_REMOTE_HELP", "SMHV_PIPE_NO_STREAM_PRIORITY", "SMHV_PIPE_NO_TEAM_HELP"]
     src = os.path.join(os.environ.get("TMPDIR", "/tmp"), "smhv_opt_size.c")
     exe = src[:-2]
     with open(src, "w") as f:
         f.write('#include <stdio.h>\n#include "smh_vision_hip.h"\nint main(void) { printf("%zu\\n", sizeof(smhv_pipeline_options)); return 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
-    assert int(subprocess.check_output([exe]).decode()) == C.sizeof(_lib.PipelineOptions) == 32
+    assert int(subprocess.check_output([exe]).decode()) == C.sizeof(_lib.PipelineOptions) == 48
 
 
 def test_host_crc32_equals_zlib_for_ragged_lengths_and_alignments(built):
