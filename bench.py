@@ -305,7 +305,7 @@ def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, 
     pipe = smh.Pipeline(vision, W, H, n, depth, search="frame", room_for_others=1)
     side = torch.cuda.Stream()
 
-    def run(with_probe):
+    def run(with_probe, wgs=8):
         for _ in range(2 * depth):
             pipe.submit(fptr, n, stages=stages, anchors=anchors)
         pipe.wait()
@@ -316,7 +316,7 @@ def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, 
             if with_probe:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side)
-                smh._lib.check(lib.smhv_debug_side_kernel(vision._ctx, probe_wgs, side.cuda_stream))
+                smh._lib.check(lib.smhv_debug_side_kernel(vision._ctx, wgs, side.cuda_stream))
                 e1.record(side)
                 evs.append((e0, e1))
         pipe.wait()
@@ -325,16 +325,47 @@ def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, 
         return n * passes / dt, (np.array([a.elapsed_time(b) for a, b in evs]) if evs else None)
 
     r0, _ = run(False)
-    r1, lat = run(True)
-    r2, _ = run(False)
+    by_size = {}
+    for wg in sorted({8, probe_wgs}):
+        r1, lat = run(True, wg)
+        r2, _ = run(False)
+        base = 0.5 * (r0 + r2)
+        by_size[str(wg)] = {"frames_per_s_without_probe": base, "frames_per_s_with_probe": r1, "cost": 1.0 - r1 / base,
+                            "probe_ms": {"median": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())}}
+        r0 = r2
     geo = pipe.peek()
     pipe.close()
-    base = 0.5 * (r0 + r2)
-    return {"frames_per_s_without_probe": base, "frames_per_s_with_probe": r1, "cost": 1.0 - r1 / base,
-            "probe_ms": {"median": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
-            "probe": "%d workgroups x 256 threads, 21 KB LDS, 280 VGPRs (RCCL's kernels on gfx950: 19.7-21.2 KB, 261-280), one launch per pass on its own stream" % probe_wgs,
+    first = by_size[str(min(int(k) for k in by_size))]
+    return {"frames_per_s_without_probe": first["frames_per_s_without_probe"], "frames_per_s_with_probe": first["frames_per_s_with_probe"], "cost": first["cost"],
+            "probe_ms": first["probe_ms"], "by_probe_workgroups": by_size,
+            "probe": "8 (headline figures) and %d workgroups x 256 threads, 21 KB LDS, 280 VGPRs (RCCL's kernels on gfx950: 19.7-21.2 KB, 261-280), one launch per pass on its own stream" % probe_wgs,
             "service_workgroups": geo["service_workgroups"], "waves_per_workgroup": geo["waves_per_workgroup"], "pipeline_depth": depth, "passes": passes,
             "note": "room_for_others = 1 (an eighth of the CUs without a search workgroup): what bench.py --gpus N > 1 and smhv_node run with"}
+
+
+def trait_path_leg(smh, vision, frame, labels, reps=40):
+    """The per-call (drop-in) path on one frame of the workload (never `value`): VisionState.process -- load_frame, crop_to_map,
+    find_minimap, then the markers branch and the scales branch on two threads -- `reps` times; wall time per frame and the
+    library's own per-call table (smhv_trait_times: the reference wraps every trait call in a Timeshares entry,
+    vision-common/src/debug.rs:3-30, src/vision/mod.rs:54-66)."""
+    state = smh.VisionState()
+    for _ in range(5):
+        state.process(vision, frame, ocr_labels=labels)
+    vision.trait_times(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = state.process(vision, frame, ocr_labels=labels)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    tt = vision.trait_times(reset=True)
+    state.close()
+    per = {k: v[0] / max(v[1], 1) for k, v in tt.items() if v[1]}
+    crit = per.get("load_frame", 0.0) + per.get("crop_to_map", 0.0) + per.get("find_minimap", 0.0) + max(
+        per.get("isolate_map_markers", 0.0) + per.get("mask_marker_lines", 0.0) + per.get("find_marker_lines", 0.0),
+        per.get("ocr_preprocess", 0.0) + per.get("find_scales_preprocess", 0.0) + per.get("calc_meters_to_px_ratio", 0.0))
+    return {"ms_per_frame": ms, "per_call_ms": per, "critical_path_ms": crit, "frames": reps, "lines": int(len(res.markers)),
+            "what": "VisionState.process through the C ABI's trait functions (host frame in pageable memory -> results on the host), one frame at a time; "
+                    "per_call_ms = the library's wall-clock table per trait call; critical_path_ms = load_frame + crop_to_map + find_minimap + the longer branch; "
+                    "the rest of ms_per_frame is the Python caller (thread hand-over, ctypes)"}
 
 
 def real_samples_leg(smh, torch, vision, depth, batch=128, steps=200):
@@ -1076,6 +1107,8 @@ def main():
     if args.ingest_frames > 0 and world == 1 and args.config == 2 and not custom:
         out["ingest"] = ingest_leg(smh, torch, vision, pipe, frames_host, anchors, stages, args.ingest_frames, W, H, n)
     pipe.close()                                           # (its streams hold hardware queues the next leg's pipelines should get)
+    if world == 1 and args.config == 2 and not custom and len(frames_host):
+        out["trait_path"] = trait_path_leg(smh, vision, frames_host[0], infos[0]["anchors"])
     if args.side_probe > 0 and world == 1 and args.config == 2 and not custom and depth >= 3:
         out["co_residency"] = co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, args.side_probe)
     if not args.no_real_samples and world == 1 and args.config == 2 and not custom:

@@ -92,6 +92,13 @@ SMHV_API int smhv_load_frame_device(smhv_ctx *ctx, const void *d_bgra, uint32_t 
  * fraction < 0.65): nothing else is written.  Otherwise roi = [x,y,w,h] and, if ui_rgba != NULL,
  * w*h*4 bytes of RGBA (grayscale: luma,luma,luma,255) are written to it. */
 SMHV_API int smhv_crop_to_map(smhv_ctx *ctx, int grayscale, int *map_open, uint32_t roi[4], uint8_t *ui_rgba);
+/* ... and the form that does not wait for the image: with ui_rgba == NULL crop_to_map returns as soon as the button test is known
+ * (one host wait; the pass over the ROI, the marker mask and the minimap walk are enqueued with it), and the ui_map travels to
+ * pinned host memory of the context on a stream of its own while the caller starts its two branches -- what the reference's
+ * PinnedGpuImage is to its GPU back-end (vision-gpu/src/gpuimage.rs:117-166: copied when somebody looks).  smhv_ui_map waits for
+ * that copy and hands out the pinned image: w x h RGBA8, tightly packed, readable until the SECOND crop_to_map after this
+ * frame's (two buffers take turns).  SMHV_E_STATE when the map is closed. */
+SMHV_API int smhv_ui_map(smhv_ctx *ctx, const uint8_t **rgba, uint32_t *w, uint32_t *h);
 /* number of "Close Deployment" red pixels counted by the last crop_to_map (diagnostic) */
 SMHV_API int smhv_red_pixels(smhv_ctx *ctx, uint32_t *count);
 
@@ -126,6 +133,24 @@ SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *ctx, const uint32_t *scales,
 SMHV_API int smhv_find_minimap(smhv_ctx *ctx, uint32_t rect[4], int *found);
 /* Vision::get_debug_view (vision-cpu/src/lib.rs:451-460): RGBA copy; rgba may be NULL to query w,h. */
 SMHV_API int smhv_get_debug_view(smhv_ctx *ctx, int which, uint8_t *rgba, uint32_t *w, uint32_t *h);
+/* The per-call path's counterpart of the reference's Timeshares waterfall (vision-common/src/debug.rs:3-30; src/vision/mod.rs:54-66
+ * wraps every trait call in one): host wall time of every call of the trait surface on this context, summed, and the number of
+ * calls, since the context was created or last reset.  The two branches run on two threads: the time of a frame is
+ * load_frame + crop_to_map + find_minimap + max(markers branch, scales branch), not the sum of everything. */
+#define SMHV_T_LOAD_FRAME 0
+#define SMHV_T_CROP_TO_MAP 1
+#define SMHV_T_FIND_MINIMAP 2
+#define SMHV_T_ISOLATE_MAP_MARKERS 3
+#define SMHV_T_MASK_MARKER_LINES 4
+#define SMHV_T_FIND_MARKER_LINES 5
+#define SMHV_T_OCR_PREPROCESS 6
+#define SMHV_T_FIND_SCALES_PREPROCESS 7
+#define SMHV_T_CALC_METERS_TO_PX_RATIO 8
+#define SMHV_T_GET_DEBUG_VIEW 9
+#define SMHV_T_FIND_LONGEST_LINE 10
+#define SMHV_T_UI_MAP 11
+#define SMHV_TRAIT_CALLS 12
+SMHV_API int smhv_trait_times(smhv_ctx *ctx, uint64_t ns[SMHV_TRAIT_CALLS], uint64_t calls[SMHV_TRAIT_CALLS], int reset);
 
 /* ---- batched pipeline (BASELINE configs 2-5): frames resident in HBM -------------------------- */
 #define SMHV_STAGE_MARKERS 0x1u /* button test + marker mask + dilation + LSD                  */

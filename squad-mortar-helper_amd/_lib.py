@@ -117,6 +117,8 @@ SIGNATURES = {
     "smhv_debug_skip_line_search": (C.c_int, [C.c_int]),
     "smhv_debug_no_host_atomics": (C.c_int, [C.c_int]),
     "smhv_debug_side_kernel": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "smhv_trait_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "smhv_ui_map": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "smhv_debug_pattern_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "smhv_debug_marker_table": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),

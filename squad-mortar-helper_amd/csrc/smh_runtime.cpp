@@ -224,6 +224,15 @@ struct smhv_ctx {
 	int device = 0;
 	smhv_log_fn log = nullptr;
 	hipStream_t s_main = nullptr, s_markers = nullptr, s_scales = nullptr;
+	// crop_to_map's ui_map travels to pinned host memory on a stream of its own while the two branches run (the reference hands
+	// its caller a pinned image that is copied when somebody looks at it: PinnedGpuImage, vision-gpu/src/gpuimage.rs:117-166);
+	// two buffers in turn, so that the map of frame k stays readable while frame k + 1 is processed
+	hipStream_t s_ui = nullptr;
+	hipEvent_t ev_map = nullptr, ev_ui[2] = {nullptr, nullptr};
+	uint8_t *h_ui[2] = {nullptr, nullptr};
+	size_t h_ui_cap[2] = {0, 0};
+	uint32_t ui_turn = 0;
+	bool ui_pending = false, minimap_cached = false;
 	// current frame (per-call trait path); ~ GpuMemory
 	uint32_t W = 0, H = 0;
 	bool have_frame = false;
@@ -248,6 +257,9 @@ struct smhv_ctx {
 	int sector_n = 0;
 	float *d_ray_off = nullptr;         // Buffers::ray_off (built at init, rebuilt by smhv_set_ray_table)
 	uint32_t *d_side = nullptr;         // smhv_debug_side_kernel's output words
+	// host wall time of every trait call, summed (smhv_trait_times: the per-call path's counterpart of the reference's Timeshares
+	// waterfall, vision-common/src/debug.rs:3-30); two threads call in, hence atomics
+	std::atomic<uint64_t> tt_ns[SMHV_TRAIT_CALLS] = {}, tt_calls[SMHV_TRAIT_CALLS] = {};
 	std::mutex mu;                      // serialises (re)allocation only
 	// Lifetime: batches and ingest queues hold a reference, so smhv_shutdown with children still alive releases the
 	// context's own resources and marks it closed, and the object itself goes with the last child (their destroy
@@ -374,9 +386,12 @@ extern "C" SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out) {
 	hipError_t he = hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking);
 	if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->s_markers, hipStreamNonBlocking);
 	if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->s_scales, hipStreamNonBlocking);
+	if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->s_ui, hipStreamNonBlocking);
+	if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_map, hipEventDisableTiming);
+	for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&c->ev_ui[i], hipEventDisableTiming);
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_res, sizeof(smhv_frame_result) * 4);
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_aux, sizeof(FrameAux));
-	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4);
+	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 + sizeof(smhv_anchors));   // (+ the anchors of calc_meters_to_px_ratio)
 	if (he == hipSuccess) he = hipMalloc((void **)&c->d_ray_off, sizeof(float) * 2 * SMH_LSD_RAYS * (SMH_RAY_OFF_BATCHES + 1));
 	if (he == hipSuccess) he = launch_build_ray_offsets(c->d_ray_off, c->s_main);
 	if (he == hipSuccess) he = hipStreamSynchronize(c->s_main);
@@ -414,6 +429,10 @@ extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
 	if (c->s_main) (void)hipStreamDestroy(c->s_main);
 	if (c->s_markers) (void)hipStreamDestroy(c->s_markers);
 	if (c->s_scales) (void)hipStreamDestroy(c->s_scales);
+	if (c->s_ui) (void)hipStreamDestroy(c->s_ui);
+	if (c->ev_map) (void)hipEventDestroy(c->ev_map);
+	for (int i = 0; i < 2; ++i) { if (c->ev_ui[i]) (void)hipEventDestroy(c->ev_ui[i]); if (c->h_ui[i]) (void)hipHostFree(c->h_ui[i]); c->ev_ui[i] = nullptr; c->h_ui[i] = nullptr; c->h_ui_cap[i] = 0; }
+	c->s_ui = nullptr; c->ev_map = nullptr;
 	c->d_frame = nullptr; c->d_frame_cap = 0; c->h_ocr = c->h_scales = nullptr; c->h_res = nullptr; c->h_aux = nullptr; c->h_bars = nullptr;
 	c->s_main = c->s_markers = c->s_scales = nullptr;
 	logf(c, 3, "smh_vision_hip shut down");
@@ -1575,11 +1594,33 @@ static int ensure_frame_buffers(smhv_ctx *c, uint32_t w, uint32_t h) {
 	return SMHV_OK;
 }
 
+struct TraitTimer {                                         // one per trait call: its wall time goes to the context's table
+	smhv_ctx *c; int idx; struct timespec t0;
+	TraitTimer(smhv_ctx *c_, int idx_) : c(c_), idx(idx_) { clock_gettime(CLOCK_MONOTONIC, &t0); }
+	~TraitTimer() {
+		if (!c) return;
+		struct timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		c->tt_ns[idx].fetch_add((uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)), std::memory_order_relaxed);
+		c->tt_calls[idx].fetch_add(1u, std::memory_order_relaxed);
+	}
+};
+extern "C" SMHV_API int smhv_trait_times(smhv_ctx *c, uint64_t ns[SMHV_TRAIT_CALLS], uint64_t calls[SMHV_TRAIT_CALLS], int reset) {
+	if (!c) return fail(SMHV_E_INVALID, "null context");
+	for (int i = 0; i < SMHV_TRAIT_CALLS; ++i) {
+		if (ns) ns[i] = c->tt_ns[i].load(std::memory_order_relaxed);
+		if (calls) calls[i] = c->tt_calls[i].load(std::memory_order_relaxed);
+		if (reset) { c->tt_ns[i].store(0, std::memory_order_relaxed); c->tt_calls[i].store(0, std::memory_order_relaxed); }
+	}
+	return SMHV_OK;
+}
+
 static void reset_frame_state(smhv_ctx *c) {
-	c->have_frame = true; c->cropped = false; c->map_open = false; c->isolated = false; c->mask_valid = false;
+	c->have_frame = true; c->cropped = false; c->map_open = false; c->isolated = false; c->mask_valid = false; c->minimap_cached = false;
 }
 
 extern "C" SMHV_API int smhv_load_frame(smhv_ctx *c, const uint8_t *bgra, uint32_t w, uint32_t h) {
+	TraitTimer tt_(c, SMHV_T_LOAD_FRAME);
 	if (!c || !bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
 	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
@@ -1600,7 +1641,7 @@ extern "C" SMHV_API int smhv_load_frame(smhv_ctx *c, const uint8_t *bgra, uint32
 	const uint32_t y1 = (g.ry + g.rh > g.by + g.bh) ? g.ry + g.rh : g.by + g.bh;
 	const size_t off = (size_t)y0 * w * 4, len = (size_t)(y1 - y0) * w * 4;
 	HIPCHK(hipMemcpyAsync(c->d_frame + off, bgra + off, len, hipMemcpyHostToDevice, c->s_main));
-	HIPCHK(hipStreamSynchronize(c->s_main));
+	HIPCHK(wait_stream(c->s_main));              // (the caller's buffer is its own again when the call returns)
 	c->frame_ptr = c->d_frame;
 	reset_frame_state(c);
 	return SMHV_OK;
@@ -1639,6 +1680,7 @@ extern "C" SMHV_API int smhv_load_frame_view(smhv_ctx *c, const uint8_t *parent_
 }
 
 extern "C" SMHV_API int smhv_load_frame_device(smhv_ctx *c, const void *d_bgra, uint32_t w, uint32_t h) {
+	TraitTimer tt_(c, SMHV_T_LOAD_FRAME);
 	if (!c || !d_bgra || w == 0 || h == 0) return fail(SMHV_E_INVALID, "bad arguments");
 	CTX_OPEN(c);
 	HIPCHK(hipSetDevice(c->device));
@@ -1649,7 +1691,9 @@ extern "C" SMHV_API int smhv_load_frame_device(smhv_ctx *c, const void *d_bgra, 
 	return SMHV_OK;
 }
 
+static int require_open(smhv_ctx *c, const char *what);
 extern "C" SMHV_API int smhv_crop_to_map(smhv_ctx *c, int grayscale, int *map_open, uint32_t roi[4], uint8_t *ui_rgba) {
+	TraitTimer tt_(c, SMHV_T_CROP_TO_MAP);
 	if (!c || !map_open) return fail(SMHV_E_INVALID, "bad arguments");
 	if (!c->have_frame) return fail(SMHV_E_INVALID, "crop_to_map called before load_frame");
 	HIPCHK(hipSetDevice(c->device));
@@ -1657,22 +1701,60 @@ extern "C" SMHV_API int smhv_crop_to_map(smhv_ctx *c, int grayscale, int *map_op
 	const Geom &g = b->g;
 	Buffers bf = make_buffers(b, c->frame_ptr, 0);
 	hipStream_t s = c->s_main;
+	// ONE host wait per call: the button test, the pass over the ROI (ui_map and, speculatively, the marker mask -- the
+	// reference's cropped_map / isolate / mask sequence re-reads the crop three times; mask_marker_lines then only has to
+	// publish it) and the minimap walk (src/vision/mod.rs:85 asks for it next) are enqueued back to back, then the few bytes
+	// that decide how the call returns.  On a frame whose map is closed the pass ran for nothing (~20 us of the GPU, nobody
+	// waits for it).
 	HIPCHK(launch_button(g, bf, 1, 0, s));
+	HIPCHK(launch_map_pass(g, bf, 1, MAP_UI | MAP_MASK, grayscale, s));
+	HIPCHK(hipEventRecord(c->ev_map, s));
+	Buffers bm = make_buffers(b, c->frame_ptr, 3);             // the minimap's own record slot
+	HIPCHK(launch_find_minimap(g, bm, 1, s));
 	HIPCHK(hipMemcpyAsync(c->h_aux, b->d_aux, sizeof(FrameAux), hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
-	c->cropped = true; c->isolated = false; c->mask_valid = false;
+	HIPCHK(hipMemcpyAsync(&c->h_res[3], b->d_results + 3, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
+	HIPCHK(wait_stream(s));
+	c->cropped = true; c->isolated = false; c->mask_valid = false; c->ui_pending = false;
 	c->map_open = c->h_aux->open != 0;
 	*map_open = c->map_open ? 1 : 0;
 	if (!c->map_open) return SMHV_OK;          // Ok(None)
+	c->minimap_cached = true;
 	if (roi) { roi[0] = g.rx; roi[1] = g.ry; roi[2] = g.rw; roi[3] = g.rh; }
-	// One pass over the ROI produces ui_map and, speculatively, the marker mask (the reference's
-	// cropped_map / isolate / mask sequence re-reads the crop three times); mask_marker_lines then
-	// only has to publish it.
-	HIPCHK(launch_map_pass(g, bf, 1, MAP_UI | MAP_MASK, grayscale, s));
 	c->mask_valid = true;
-	if (ui_rgba)
-		HIPCHK(hipMemcpy2DAsync(ui_rgba, (size_t)g.rw * 4, b->d_ui + (size_t)g.m_xoff * 4, g.ui_pitch, (size_t)g.rw * 4, g.rh, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	// ui_map: to pinned host memory on a stream of its own, behind the pass -- the call does not wait for those 3.2 MB (1080p);
+	// smhv_ui_map does, when somebody wants to look at the image, usually after the two branches have been started
+	const uint32_t t = (c->ui_turn++) & 1u;
+	const size_t ui_bytes = (size_t)g.rw * g.rh * 4;
+	if (c->h_ui_cap[t] < ui_bytes) {
+		if (c->h_ui[t]) { HIPCHK(hipEventSynchronize(c->ev_ui[t])); (void)hipHostFree(c->h_ui[t]); c->h_ui[t] = nullptr; c->h_ui_cap[t] = 0; }
+		HIPCHK(hipHostMalloc((void **)&c->h_ui[t], ui_bytes, hipHostMallocDefault));
+		c->h_ui_cap[t] = ui_bytes;
+	}
+	HIPCHK(hipStreamWaitEvent(c->s_ui, c->ev_map, 0));
+	HIPCHK(hipMemcpy2DAsync(c->h_ui[t], (size_t)g.rw * 4, b->d_ui + (size_t)g.m_xoff * 4, g.ui_pitch, (size_t)g.rw * 4, g.rh, hipMemcpyDeviceToHost, c->s_ui));
+	HIPCHK(hipEventRecord(c->ev_ui[t], c->s_ui));
+	c->ui_pending = true;
+	if (ui_rgba) {                                  // the eager form: the image in the caller's memory when the call returns
+		HIPCHK(wait_event(c->ev_ui[t]));
+		memcpy(ui_rgba, c->h_ui[t], ui_bytes);
+	}
+	return SMHV_OK;
+}
+
+// The ui_map of the frame crop_to_map last ran on, in pinned host memory owned by the context: rw x rh RGBA8, tightly packed,
+// readable until the SECOND crop_to_map after this one's (two buffers take turns).  Waits for the copy crop_to_map started.
+extern "C" SMHV_API int smhv_ui_map(smhv_ctx *c, const uint8_t **rgba, uint32_t *w, uint32_t *h) {
+	TraitTimer tt_(c, SMHV_T_UI_MAP);
+	int rc = require_open(c, "ui_map");
+	if (rc) return rc;
+	if (!rgba) return fail(SMHV_E_INVALID, "null output");
+	if (!c->ui_pending) return fail(SMHV_E_STATE, "ui_map: crop_to_map has not produced a map for this frame");
+	HIPCHK(hipSetDevice(c->device));
+	const uint32_t t = (c->ui_turn - 1u) & 1u;
+	HIPCHK(wait_event(c->ev_ui[t]));
+	*rgba = c->h_ui[t];
+	if (w) *w = c->fb->g.rw;
+	if (h) *h = c->fb->g.rh;
 	return SMHV_OK;
 }
 
@@ -1691,6 +1773,7 @@ static int require_open(smhv_ctx *c, const char *what) {
 }
 
 extern "C" SMHV_API int smhv_ocr_preprocess(smhv_ctx *c, const uint8_t **out, size_t *len) {
+	TraitTimer tt_(c, SMHV_T_OCR_PREPROCESS);
 	int rc = require_open(c, "ocr_preprocess");
 	if (rc) return rc;
 	if (!out || !len) return fail(SMHV_E_INVALID, "null output");
@@ -1707,6 +1790,7 @@ extern "C" SMHV_API int smhv_ocr_preprocess(smhv_ctx *c, const uint8_t **out, si
 }
 
 extern "C" SMHV_API int smhv_find_scales_preprocess(smhv_ctx *c, uint32_t scales_start_y, const uint8_t **out, uint32_t *w, uint32_t *h) {
+	TraitTimer tt_(c, SMHV_T_FIND_SCALES_PREPROCESS);
 	int rc = require_open(c, "find_scales_preprocess");
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(c->device));
@@ -1726,6 +1810,7 @@ extern "C" SMHV_API int smhv_find_scales_preprocess(smhv_ctx *c, uint32_t scales
 }
 
 extern "C" SMHV_API int smhv_isolate_map_markers(smhv_ctx *c) {
+	TraitTimer tt_(c, SMHV_T_ISOLATE_MAP_MARKERS);
 	int rc = require_open(c, "isolate_map_markers");
 	if (rc) return rc;
 	// The isolated crop is only observable through DebugView::LSDPreprocess; it is materialised
@@ -1735,6 +1820,7 @@ extern "C" SMHV_API int smhv_isolate_map_markers(smhv_ctx *c) {
 }
 
 extern "C" SMHV_API int smhv_mask_marker_lines(smhv_ctx *c) {
+	TraitTimer tt_(c, SMHV_T_MASK_MARKER_LINES);
 	int rc = require_open(c, "mask_marker_lines");
 	if (rc) return rc;
 	if (c->mask_valid) return SMHV_OK;
@@ -1769,6 +1855,7 @@ extern "C" SMHV_API int smhv_get_lsd_image(smhv_ctx *c, uint8_t *out, uint32_t *
 }
 
 extern "C" SMHV_API int smhv_find_longest_line(smhv_ctx *c, float px, float py, float max_gap, smhv_line *line, float *len_sq) {
+	TraitTimer tt_(c, SMHV_T_FIND_LONGEST_LINE);
 	int rc = require_mask(c, "find_longest_line");
 	if (rc) return rc;
 	if (!line || !len_sq) return fail(SMHV_E_INVALID, "null output");
@@ -1785,6 +1872,7 @@ extern "C" SMHV_API int smhv_find_longest_line(smhv_ctx *c, float px, float py, 
 }
 
 extern "C" SMHV_API int smhv_find_marker_lines(smhv_ctx *c, uint32_t max_gap, smhv_line out[SMHV_MAX_LINES], uint32_t *n) {
+	TraitTimer tt_(c, SMHV_T_FIND_MARKER_LINES);
 	int rc = require_mask(c, "find_marker_lines");
 	if (rc) return rc;
 	if (!out || !n) return fail(SMHV_E_INVALID, "null output");
@@ -1826,6 +1914,7 @@ extern "C" SMHV_API int smhv_lsd_stats(smhv_ctx *c, uint32_t max_gap, int exact,
 }
 
 extern "C" SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *c, const uint32_t *scales, uint32_t n, double *ratio, int *has, uint32_t *bars) {
+	TraitTimer tt_(c, SMHV_T_CALC_METERS_TO_PX_RATIO);
 	int rc = require_open(c, "calc_meters_to_px_ratio");
 	if (rc) return rc;
 	if (!ratio || !has || (n && !scales)) return fail(SMHV_E_INVALID, "null argument");
@@ -1841,8 +1930,10 @@ extern "C" SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *c, const uint32_t
 	memcpy(an.scales, scales, sizeof(uint32_t) * 3 * n);
 	Buffers bf = make_buffers(b, c->frame_ptr, 1);
 	hipStream_t s = c->s_scales;
-	HIPCHK(hipMemcpyAsync(b->d_anchors, &an, sizeof an, hipMemcpyHostToDevice, s));
-	HIPCHK(hipStreamSynchronize(s));            // `an` is a stack object
+	// (the anchors travel through pinned memory of the context: the copy is asynchronous and nothing waits for it but the kernel)
+	smhv_anchors *h_an = (smhv_anchors *)(c->h_bars + SMHV_MAX_SCALES * 4);
+	*h_an = an;
+	HIPCHK(hipMemcpyAsync(b->d_anchors, h_an, sizeof an, hipMemcpyHostToDevice, s));
 	HIPCHK(launch_scale_ratio(b->g, bf, 1, b->d_bars, s));
 	HIPCHK(hipMemcpyAsync(&c->h_res[1], b->d_results + 1, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(c->h_bars, b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4, hipMemcpyDeviceToHost, s));
@@ -1854,9 +1945,15 @@ extern "C" SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *c, const uint32_t
 }
 
 extern "C" SMHV_API int smhv_find_minimap(smhv_ctx *c, uint32_t rect[4], int *found) {
+	TraitTimer tt_(c, SMHV_T_FIND_MINIMAP);
 	int rc = require_open(c, "find_minimap");
 	if (rc) return rc;
 	if (!rect || !found) return fail(SMHV_E_INVALID, "null output");
+	if (c->minimap_cached) {                                   // crop_to_map ran the walk with its own pass and fetched the record
+		*found = c->h_res[3].has_minimap ? 1 : 0;
+		memcpy(rect, c->h_res[3].minimap, sizeof(uint32_t) * 4);
+		return SMHV_OK;
+	}
 	HIPCHK(hipSetDevice(c->device));
 	smhv_batch *b = c->fb;
 	Buffers bf = make_buffers(b, c->frame_ptr, 3);          // its own record slot: runs on the crop stream
@@ -1870,6 +1967,7 @@ extern "C" SMHV_API int smhv_find_minimap(smhv_ctx *c, uint32_t rect[4], int *fo
 }
 
 extern "C" SMHV_API int smhv_get_debug_view(smhv_ctx *c, int which, uint8_t *rgba, uint32_t *w, uint32_t *h) {
+	TraitTimer tt_(c, SMHV_T_GET_DEBUG_VIEW);
 	if (!c) return fail(SMHV_E_INVALID, "null context");
 	if (which == SMHV_VIEW_NONE) { if (w) *w = 0; if (h) *h = 0; return SMHV_OK; }
 	if (which < 0 || which > SMHV_VIEW_CROPPED_BRQ) return fail(SMHV_E_INVALID, "unknown debug view %d", which);

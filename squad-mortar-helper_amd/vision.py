@@ -102,20 +102,33 @@ class HipVision:
     def get_cpu_frame(self):
         return self._frame
 
-    def crop_to_map(self, grayscale=True):
-        """-> None when the map is closed, else (ui_map uint8[h,w,4] RGBA, [x,y,w,h])."""
+    def crop_to_map(self, grayscale=True, lazy=False):
+        """-> None when the map is closed, else (ui_map uint8[h,w,4] RGBA, [x,y,w,h]).  lazy: the call returns when the button
+        test is known and the ui_map is None -- it travels to pinned host memory meanwhile; ui_map() hands it out (what the
+        reference's PinnedGpuImage is to its GPU back-end, vision-gpu/src/gpuimage.rs:117-166)."""
         if getattr(self, "_size", None) is None:
             raise L.VisionError(L.E_INVALID, "crop_to_map called before load_frame")
         w, h = self._size
-        _, _, rw, rh = map_bounds(w, h)
-        ui = np.empty((rh, rw, 4), np.uint8)
         is_open = C.c_int()
         roi = (C.c_uint32 * 4)()
-        L.check(self._lib.smhv_crop_to_map(self._ctx, int(bool(grayscale)), C.byref(is_open), roi, ui.ctypes.data))
+        ui = None
+        if not lazy:
+            _, _, rw, rh = map_bounds(w, h)
+            ui = np.empty((rh, rw, 4), np.uint8)
+        L.check(self._lib.smhv_crop_to_map(self._ctx, int(bool(grayscale)), C.byref(is_open), roi, ui.ctypes.data if ui is not None else None))
         if not is_open.value:
             return None
         self._roi = list(roi)
         return ui, list(roi)
+
+    def ui_map(self, copy=False):
+        """The ui_map of the frame crop_to_map last ran on -> uint8[h,w,4] RGBA: a VIEW of the context's pinned staging buffer
+        (readable until the second crop_to_map after this frame's; copy=True for an array of the caller's own)."""
+        p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        L.check(self._lib.smhv_ui_map(self._ctx, C.byref(p), C.byref(w), C.byref(h)))
+        buf = (C.c_uint8 * (w.value * h.value * 4)).from_address(p.value)
+        a = np.frombuffer(buf, np.uint8).reshape(h.value, w.value, 4)
+        return a.copy() if copy else a
 
     def red_pixels(self):
         n = C.c_uint32()
@@ -197,6 +210,16 @@ class HipVision:
         L.check(self._lib.smhv_get_debug_view(self._ctx, choice, out.ctypes.data, C.byref(w), C.byref(h)))
         return out
 
+    TRAIT_CALLS = ("load_frame", "crop_to_map", "find_minimap", "isolate_map_markers", "mask_marker_lines", "find_marker_lines", "ocr_preprocess",
+                   "find_scales_preprocess", "calc_meters_to_px_ratio", "get_debug_view", "find_longest_line", "ui_map")
+
+    def trait_times(self, reset=False):
+        """Host wall time of every trait call on this context, summed, and the call counts (the reference wraps every call in a
+        Timeshares entry, src/vision/mod.rs:54-66) -> {name: (milliseconds, calls)}."""
+        ns, calls = (C.c_uint64 * len(self.TRAIT_CALLS))(), (C.c_uint64 * len(self.TRAIT_CALLS))()
+        L.check(self._lib.smhv_trait_times(self._ctx, ns, calls, int(bool(reset))))
+        return {k: (int(ns[i]) / 1e6, int(calls[i])) for i, k in enumerate(self.TRAIT_CALLS)}
+
     def debug_marker_table(self):
         bits = np.empty((1 << 24) // 32, np.uint32)
         L.check(self._lib.smhv_debug_marker_table(self._ctx, bits.ctypes.data))
@@ -255,21 +278,60 @@ class VisionState:
     then the markers branch and the scales branch CONCURRENTLY on two threads, each calling
     thread_ctx() first.  OCR (Tesseract) is outside this path: its label anchors are an input."""
 
-    def __init__(self, grayscale_map=True, detect_markers=True, max_gap=15):
+    def __init__(self, grayscale_map=True, detect_markers=True, max_gap=15, heightmap_selected=True):
         self.grayscale_map = grayscale_map
         self.detect_markers = detect_markers
         self.max_gap = max_gap
+        # src/vision/mod.rs:121: the scales branch only runs while a heightmap is selected (`heightmaps::is_set()`): without one
+        # nobody asks how many meters a pixel is
+        self.heightmap_selected = heightmap_selected
+        # the two branches run on two long-lived threads (the reference: rayon::join on its pool, mod.rs:103-218) -- starting a
+        # thread per branch and frame costs more than a branch takes
+        self._workers = None
+
+    def _pool(self):
+        if self._workers is None:
+            import queue
+            self._workers = []
+            for _ in range(2):
+                q_in, q_out = queue.SimpleQueue(), queue.SimpleQueue()
+
+                def loop(q_in=q_in, q_out=q_out):
+                    while True:
+                        job = q_in.get()
+                        if job is None:
+                            return
+                        job()
+                        q_out.put(True)
+                t = threading.Thread(target=loop, daemon=True)
+                t.start()
+                self._workers.append((t, q_in, q_out))
+        return self._workers
+
+    def close(self):
+        if self._workers:
+            for t, q_in, _ in self._workers:
+                q_in.put(None)
+            for t, _, _ in self._workers:
+                t.join(timeout=1.0)
+            self._workers = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def process(self, vision, frame, ocr_labels=None, debug_view=DebugView.NONE, ocr=None):
         """ocr_labels: [(meters, x, y)] label anchors, or `ocr`: a callable (image uint8[h,w], w, h) -> OCR hits
         (text/left/right/bottom) that plays the part of the reference's Tesseract call (`ocr::read`, mod.rs:169);
         its hits go through parse_ocr_labels exactly like the reference filters them."""
         vision.load_frame(frame)
-        cropped = vision.crop_to_map(self.grayscale_map)
+        cropped = vision.crop_to_map(self.grayscale_map, lazy=True)
         if cropped is None:
             return None
         res = VisionResults()
-        res.map, res.roi = cropped
+        _, res.roi = cropped
         res.minimap_bounds = vision.find_minimap()           # src/vision/mod.rs:85
         out, err = {}, []
 
@@ -285,6 +347,8 @@ class VisionState:
 
         def scales():
             try:
+                if not self.heightmap_selected:                 # mod.rs:121
+                    return
                 vision.thread_ctx()
                 out["ocr"] = vision.ocr_preprocess()
                 if ocr is not None:
@@ -302,8 +366,10 @@ class VisionState:
             except Exception as e:  # noqa: BLE001
                 err.append(e)
 
-        ta, tb = threading.Thread(target=markers), threading.Thread(target=scales)
-        ta.start(); tb.start(); ta.join(); tb.join()
+        (_, qa_in, qa_out), (_, qb_in, qb_out) = self._pool()
+        qa_in.put(markers); qb_in.put(scales)
+        res.map = vision.ui_map()                            # (the image arrives while the branches run)
+        qa_out.get(); qb_out.get()
         if err:
             raise err[0]
         res.markers = out.get("markers", res.markers)

@@ -122,6 +122,55 @@ def test_button_threshold_edge(vision):
     assert vision.crop_to_map(True) is None and vision.red_pixels() == 0
 
 
+def test_lazy_ui_map_heightmap_switch_and_per_call_times(vision):
+    """crop_to_map without a destination returns once the button test is known; smhv_ui_map hands out the image from pinned
+    memory -- the same bytes as the eager form, still readable while the NEXT frame is processed (two buffers take turns).
+    VisionState without a selected heightmap skips the scales branch (src/vision/mod.rs:121).  Every trait call leaves its wall
+    time in the context's table (the reference's Timeshares entry per call, mod.rs:54-66)."""
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H = 1920, 1080
+    f0, i0 = synth.make_frame(W, H, 40, n_lines=2)
+    f1, i1 = synth.make_frame(W, H, 41, n_lines=3)
+    r0 = o.process_frame(f0, stages=0xF, anchors=i0["anchors"], scales_start_y=i0["scales_start_y"], want_images=True)
+    r1 = o.process_frame(f1, stages=0xF, anchors=i1["anchors"], scales_start_y=i1["scales_start_y"], want_images=True)
+    vision.load_frame(f0)
+    eager = vision.crop_to_map(True)
+    assert np.array_equal(eager[0], r0["ui_map"])
+    vision.load_frame(f0)
+    lazy = vision.crop_to_map(True, lazy=True)
+    assert lazy is not None and lazy[0] is None and lazy[1] == eager[1]
+    m0 = vision.ui_map()
+    assert np.array_equal(m0, r0["ui_map"])
+    vision.load_frame(f1)                                            # the next frame: frame 0's map is still there
+    assert vision.crop_to_map(True, lazy=True) is not None
+    m1 = vision.ui_map()
+    assert np.array_equal(m1, r1["ui_map"]) and np.array_equal(m0, r0["ui_map"])
+    colour = vision.crop_to_map(False, lazy=True)
+    assert colour is not None and np.array_equal(vision.ui_map()[..., :3], f1[eager[1][1]:eager[1][1] + eager[1][3], eager[1][0]:eager[1][0] + eager[1][2], 2::-1])
+    # a closed map has no ui_map
+    closed = f0.copy()
+    bx, by, bw, bh = smh.button_bounds(W, H)
+    closed[by:by + bh, bx:bx + bw] = 0
+    vision.load_frame(closed)
+    assert vision.crop_to_map(True, lazy=True) is None
+    with pytest.raises(smh.VisionError):
+        vision.ui_map()
+    # the caller contract with and without a heightmap
+    vision.trait_times(reset=True)
+    st = smh.VisionState()
+    res = st.process(vision, f0, ocr_labels=i0["anchors"])
+    assert np.array_equal(res.map, r0["ui_map"]) and np.array_equal(res.markers, r0["lines"]) and res.meters_to_px_ratio == r0["mpx"]
+    tt = vision.trait_times()
+    for k in ("load_frame", "crop_to_map", "find_minimap", "find_marker_lines", "ocr_preprocess", "find_scales_preprocess", "calc_meters_to_px_ratio", "ui_map"):
+        assert tt[k][1] == 1 and tt[k][0] > 0.0, (k, tt[k])
+    st2 = smh.VisionState(heightmap_selected=False)
+    res2 = st2.process(vision, f0, ocr_labels=i0["anchors"])
+    assert np.array_equal(res2.markers, r0["lines"]) and res2.meters_to_px_ratio is None
+    assert vision.trait_times()["ocr_preprocess"][1] == 1            # (not called again)
+    st.close(); st2.close()
+
+
 @pytest.mark.parametrize("size", [(1920, 1080), (2560, 1440), (1024, 768), (1280, 1024), (1600, 1024), (3840, 2160)])
 def test_synthetic_frames_all_stages(vision, size):
     from squad_mortar_helper_amd import synth

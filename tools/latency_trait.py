@@ -17,18 +17,25 @@ def main():
     vision = smh.HipVision.init(0)
     state = smh.VisionState()
     rows = []
-    for stem in ("point_intersect_png", "points_intersect_png", "snowpoints_png", "fullmap_jpg", "whiteout_png"):
-        frame, e, g = fx.load_fixture(stem)
-        labels = [(300, 594, 433), (900, 594, 465)]                    # label anchors as OCR would deliver them
+    from squad_mortar_helper_amd import synth
+    for stem in ("synthetic_1080p", "point_intersect_png", "points_intersect_png", "snowpoints_png", "fullmap_jpg", "whiteout_png"):
+        if stem == "synthetic_1080p":
+            frame, info = synth.make_frame(1920, 1080, 0, n_lines=2)
+        else:
+            frame, e, g = fx.load_fixture(stem)
+        labels = info["anchors"] if stem == "synthetic_1080p" else [(300, 594, 433), (900, 594, 465)]   # label anchors as OCR would deliver them
         for _ in range(3):
             state.process(vision, frame, ocr_labels=labels)
+        vision.trait_times(reset=True)
         n = 20
         t0 = time.perf_counter()
         for _ in range(n):
             res = state.process(vision, frame, ocr_labels=labels)
         gpu_ms = (time.perf_counter() - t0) / n * 1e3
+        tt = vision.trait_times(reset=True)
+        print("  %-22s per call (ms): %s" % (stem, "  ".join("%s %.3f" % (k, v[0] / max(v[1], 1)) for k, v in tt.items() if v[1])))
         t0 = time.perf_counter()
-        ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=433)
+        ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=min(a[2] for a in labels))
         cpu_ms = (time.perf_counter() - t0) * 1e3
         same = res is not None and np.array_equal(res.markers, ref["lines"])
         rows.append((stem, frame.shape[1], frame.shape[0], ref["rounds"], ref["n_lines"], gpu_ms, cpu_ms, same))
