@@ -86,7 +86,7 @@ def parse_args():
     ap.add_argument("--idle-streams", type=int, default=0,
                     help="diagnostic: create this many HIP streams before the pipeline (the schedule must not depend on them)")
     ap.add_argument("--search", default="auto", choices=("auto", "batch", "frame"),
-                    help="line-search schedule of the pipeline (smhv_pipeline_options::search); auto: frame-granular from depth 8 on")
+                    help="line-search schedule of the pipeline (smhv_pipeline_options::search); auto: batch-granular below depth 6, from there on the pipeline measures both")
     ap.add_argument("--room", default="auto", choices=("auto", "on", "off"),
                     help="smhv_pipeline_options::room_for_others: the search kernel leaves an eighth of the CUs without a workgroup of its own so that "
                          "other owners' kernels (RCCL's gather) find a CU; auto: on when --gpus > 1 (every pass gathers over RCCL), off for one GPU")
@@ -487,8 +487,20 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     for q in qs:
         q.close()
     (_, _, rw, rh), (_, _, bw, bh) = smh.map_bounds(W, H), smh.button_bounds(W, H)
+    # the host CRC alone, one thread, on frames that do not fit the cache together (what a worker does between memcpys)
+    import ctypes as C
+    lib = smh._lib.load()
+    crc_level = lib.smhv_debug_crc32_host_level(None, 0, -1, None)
+    import numpy as np
+    bufs = [np.ascontiguousarray(src[i % len(src)]) for i in range(min(len(src), 24))]
+    t1 = time.perf_counter()
+    for _ in range(3):
+        for b_ in bufs:
+            lib.smhv_crc32_host(C.c_void_p(b_.ctypes.data), b_.nbytes)
+    crc_one = 3 * sum(b_.nbytes for b_ in bufs) / (time.perf_counter() - t1) / 1e9
     return {"frames_per_s": frames / dt, "frames": frames, "mode": "roi_upload", "staging_slots": slots, "host_cores": cores,
-            "host_crc_GBps": frames * W * H * 4 / dt / 1e9, "uploaded_fraction": round((rw * rh + bw * bh) / float(W * H), 3),
+            "host_crc_GBps": frames * W * H * 4 / dt / 1e9, "host_crc_loop": {2: "VPCLMULQDQ (512-bit folding)", 1: "PCLMULQDQ", 0: "tables"}.get(crc_level, "?"),
+            "host_crc_GBps_one_thread": crc_one, "uploaded_fraction": round((rw * rh + bw * bh) / float(W * H), 3),
             "h2d_GBps": frames * (rw * rh + bw * bh) * 4 / dt / 1e9,
             "full_upload_frames_per_s": frames_full / dt_full, "full_upload_h2d_GBps": frames_full * W * H * 4 / dt_full / 1e9,
             "push_frames_per_s": k / dt_push, "duplicates_dropped": dup,

@@ -316,12 +316,22 @@ SMHV_API int smhv_debug_side_kernel(smhv_ctx *ctx, uint32_t workgroups, void *st
  *     synchronize by anybody still returns) and is launched again by the next submission.  A third of the wave-time per frame,
  *     but a frame is one wave's work from start to end: it needs ~3000 light frames in flight (three per resident wave: 12 x
  *     256 frames at 1080p, 526-538 k frames/s; more changes nothing).
+ *     A frame that is still at work when most of its submission is done asks idle waves of OTHER workgroups as well (they copy its
+ *     mask tiles from global memory and answer through a ring of 8/16-byte granules; smhv_pipeline_options::remote_*).
  *   SMHV_SEARCH_AUTO (the default): below depth 6 batch-granular.  From depth 6 on the pipeline has both and MEASURES which is
  *     faster on the workload it is given -- a window of 8 x depth submissions in each, after warm-ups, ~24 x depth submissions in
- *     all; again every 16384 submissions and when the submissions change shape -- keeping the faster one (both write
- *     byte-identical records).  Measured at depth 12: the synthetic 256 x 1080p scene 519 k frames/s on the frame-granular
- *     search (419 k batch-granular); the reference's own 1440p screenshots in batches of 128 (0-372 search rounds per frame)
- *     289 k batch-granular (163 k frame-granular). */
+ *     all; again every 16384 submissions and when the submissions change shape for good (frames per submission by more than 25 %,
+ *     stages or gap threshold, for `depth` submissions in a row; at most four such re-measurements between two periodic ones) --
+ *     keeping the faster one (both write byte-identical records).  Measured at depth 12: the synthetic 256 x 1080p scene 540 k
+ *     frames/s on the frame-granular search (430 k batch-granular); the reference's own 1440p screenshots in batches of 128 (0-372
+ *     search rounds per frame) 300 k batch-granular, 243 k frame-granular (210 k without the help across workgroups); at depth 20
+ *     (24 GB of output slots) 290-300 k on either.
+ *   Completion: only smhv_pipeline_wait / smhv_pipeline_wait_all / smhv_pipeline_slot(.., &stream) guarantee a submission's
+ *     records.  A frame-granular submission's completion is not a point on any stream: a device-wide synchronize returns when the
+ *     search kernel has closed, which it also does after 20 ms without progress (e.g. behind a slow producer on `after_stream`) --
+ *     the library's waits launch it again, a bare hipDeviceSynchronize does not.
+ *   smhv_debug_skip_line_search and stage_ms[3..4] of smhv_batch_stage_ms apply to batch-granular submissions only (a frame-granular
+ *     submission's search and records are the service's: smhv_debug_pipeline_stats). */
 typedef struct smhv_pipeline smhv_pipeline;
 SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t max_frames, uint32_t depth, smhv_pipeline **out);
 /* The same with explicit choices: zero-initialise, set `size` = sizeof(smhv_pipeline_options), change what you need (every 0 is
@@ -450,6 +460,10 @@ SMHV_API int smhv_ingest_reset(smhv_ingest *q);
 SMHV_API int smhv_ingest_counts(smhv_ingest *q, uint64_t *n_new, uint64_t *n_dup);
 /* CRC-32/IEEE of nbytes of HOST memory (any length, any alignment; PCLMULQDQ folding where the CPU has it); needs no device */
 SMHV_API uint32_t smhv_crc32_host(const void *data, uint64_t nbytes);
+/* diagnostic: the same CRC by ONE of the library's three host loops -- level 2: VPCLMULQDQ (512-bit folding, 2048 bits per step),
+ * 1: PCLMULQDQ (128-bit lanes), 0: slicing-by-8 tables; a loop the machine lacks falls back to the next lower one.  Returns the
+ * machine's level (what smhv_crc32_host and the ingest workers use); level < 0 (data may be NULL) only reports it. */
+SMHV_API int smhv_debug_crc32_host_level(const void *data, uint64_t nbytes, int level, uint32_t *crc);
 /* CRC-32/IEEE of nbytes (multiple of 4) of device memory; == crc32fast::hash / zlib crc32 of the same bytes */
 SMHV_API int smhv_crc32_device(smhv_ctx *ctx, const void *d_data, uint64_t nbytes, uint32_t *crc);
 

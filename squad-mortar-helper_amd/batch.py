@@ -140,13 +140,13 @@ class FrameBatch:
 
 class Pipeline:
     """`depth` batches in flight on library-owned streams (smhv_pipeline_*): submit() is asynchronous and returns the slot;
-    the library owns every stream of the schedule and picks the line-search schedule for the depth (batch-granular below
-    depth 8, the frame-granular search service from there on)."""
+    the library owns every stream of the schedule and picks the line-search schedule: batch-granular below depth 6; from
+    depth 6 on it holds both and measures which one the workload runs faster on (SMHV_SEARCH_AUTO)."""
 
     def __init__(self, vision, frame_w, frame_h, max_frames, depth=4, search=None, **options):
-        """search: None / "auto" (the library decides from the depth: frame-granular from depth 8 on), "batch", "frame";
+        """search: None / "auto" (batch-granular below depth 6, measured from there on), "batch", "frame";
         options: the other fields of smhv_pipeline_options (streams, idle_close_us, occupancy_policy, late_helpers,
-        service_workgroups, flags)."""
+        service_workgroups, flags, remote_after, remote_tickets, remote_last, room_for_others)."""
         self._lib = L.load()
         self._vision = vision
         p = C.c_void_p()

@@ -77,13 +77,14 @@ uint64_t barrett_mu() {
 	for (int b = 0; b <= 32; ++b) if ((q >> b) & 1ull) refl |= 1ull << (32 - b);
 	return refl;
 }
-struct Consts { uint64_t k1, k2, k3, k4, k5, px, mu; };
+struct Consts { uint64_t k1, k2, k3, k4, k5, px, mu, w1, w2; };
 const Consts &consts() {
-	// distances of the folds in bits: 512 + 64 / 512 (four lanes), 128 + 64 / 128 (one lane), 64 (the 96 -> 64 step)
+	// distances of the folds in bits: 512 + 64 / 512 (four lanes), 128 + 64 / 128 (one lane), 64 (the 96 -> 64 step); w1 / w2: 2048 bits
+	// (four 512-bit registers of four lanes each: the VPCLMULQDQ loop)
 	static const Consts c = {fold_constant(4 * 128 + 32), fold_constant(4 * 128 - 32), fold_constant(128 + 32), fold_constant(128 - 32), fold_constant(64),
 	                         // P reflected over 33 bits
 	                         [] { uint64_t p = 0x104C11DB7ull, r = 0; for (int b = 0; b <= 32; ++b) if ((p >> b) & 1ull) r |= 1ull << (32 - b); return r; }(),
-	                         barrett_mu()};
+	                         barrett_mu(), fold_constant(16 * 128 + 32), fold_constant(16 * 128 - 32)};
 	return c;
 }
 
@@ -91,6 +92,7 @@ __attribute__((target("pclmul,sse4.1"))) inline __m128i fold(__m128i a, __m128i 
 	return _mm_xor_si128(_mm_xor_si128(b, _mm_clmulepi64_si128(a, k, 0x00)), _mm_clmulepi64_si128(a, k, 0x11));
 }
 
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc_clmul_finish(__m128i x3, __m128i x2, __m128i x1, __m128i x0, const __m128i *d, size_t n);
 // state -> state over n bytes, n >= 64
 __attribute__((target("pclmul,sse4.1"))) uint32_t crc_clmul_update(uint32_t st, const uint8_t *p, size_t n) {
 	const Consts &c = consts();
@@ -106,6 +108,11 @@ __attribute__((target("pclmul,sse4.1"))) uint32_t crc_clmul_update(uint32_t st, 
 		x0 = fold(x0, _mm_loadu_si128(d + 3), k1k2);
 		d += 4; n -= 64;
 	}
+	return crc_clmul_finish(x3, x2, x1, x0, d, n);
+}
+// the four 128-bit lanes (oldest first) folded into one, the remaining whole 16-byte blocks, 128 -> 64 -> 32 bits, the ragged tail
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc_clmul_finish(__m128i x3, __m128i x2, __m128i x1, __m128i x0, const __m128i *d, size_t n) {
+	const Consts &c = consts();
 	const __m128i k3k4 = _mm_set_epi64x((long long)c.k4, (long long)c.k3);
 	__m128i x = fold(x3, x2, k3k4);
 	x = fold(x, x1, k3k4);
@@ -126,9 +133,47 @@ bool have_clmul() {
 	static const bool v = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
 	return v;
 }
+
+// The same folding 2048 bits at a time: four 512-bit registers, each four independent 128-bit lanes, one VPCLMULQDQ pair per
+// register and step (Zen 4 / Zen 5, Ice Lake and later: where CPUID offers VPCLMULQDQ + AVX-512F/VL).  The sixteen lanes all fold
+// by the same distance, 2048 bits; at the end the four registers are folded into one (512 bits apart), its four lanes go through the
+// 128-bit finish above.  The ingest workers hash a frame in pieces of a few rows (61 KB): the set-up is nothing against that.
+#define SMH_V512 __attribute__((target("avx512f,avx512vl,avx512bw,vpclmulqdq,pclmul,sse4.1")))
+SMH_V512 inline __m512i fold512(__m512i a, __m512i b, __m512i k) {
+	return _mm512_ternarylogic_epi64(b, _mm512_clmulepi64_epi128(a, k, 0x00), _mm512_clmulepi64_epi128(a, k, 0x11), 0x96);
+}
+// state -> state over n bytes, n >= 256
+SMH_V512 uint32_t crc_vclmul_update(uint32_t st, const uint8_t *p, size_t n) {
+	const Consts &c = consts();
+	const __m512i *d = (const __m512i *)p;
+	__m512i y0 = _mm512_loadu_si512(d), y1 = _mm512_loadu_si512(d + 1), y2 = _mm512_loadu_si512(d + 2), y3 = _mm512_loadu_si512(d + 3);
+	d += 4; n -= 256;
+	y0 = _mm512_xor_si512(y0, _mm512_zextsi128_si512(_mm_cvtsi32_si128((int)st)));
+	const __m512i kw = _mm512_broadcast_i32x4(_mm_set_epi64x((long long)c.w2, (long long)c.w1));
+	while (n >= 256) {
+		y0 = fold512(y0, _mm512_loadu_si512(d), kw);
+		y1 = fold512(y1, _mm512_loadu_si512(d + 1), kw);
+		y2 = fold512(y2, _mm512_loadu_si512(d + 2), kw);
+		y3 = fold512(y3, _mm512_loadu_si512(d + 3), kw);
+		d += 4; n -= 256;
+	}
+	const __m512i k512 = _mm512_broadcast_i32x4(_mm_set_epi64x((long long)c.k2, (long long)c.k1));
+	__m512i y = fold512(y0, y1, k512);
+	y = fold512(y, y2, k512);
+	y = fold512(y, y3, k512);
+	while (n >= 64) { y = fold512(y, _mm512_loadu_si512(d), k512); ++d; n -= 64; }
+	return crc_clmul_finish(_mm512_extracti32x4_epi32(y, 0), _mm512_extracti32x4_epi32(y, 1), _mm512_extracti32x4_epi32(y, 2), _mm512_extracti32x4_epi32(y, 3), (const __m128i *)d, n);
+}
+bool have_vclmul() {
+	static const bool v = __builtin_cpu_supports("vpclmulqdq") && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
+	                      __builtin_cpu_supports("avx512bw") && have_clmul();
+	return v;
+}
 #else
 bool have_clmul() { return false; }
+bool have_vclmul() { return false; }
 uint32_t crc_clmul_update(uint32_t st, const uint8_t *, size_t) { return st; }
+uint32_t crc_vclmul_update(uint32_t st, const uint8_t *, size_t) { return st; }
 #endif
 
 }  // namespace
@@ -138,9 +183,29 @@ uint32_t crc_clmul_update(uint32_t st, const uint8_t *, size_t) { return st; }
 namespace smh {
 uint32_t crc32_host_update(uint32_t st, const uint8_t *p, size_t n) {
 	if (n == 0) return st;
+	if (n >= 512 && have_vclmul()) return crc_vclmul_update(st, p, n);
 	return have_clmul() && n >= 64 ? crc_clmul_update(st, p, n) : crc_table_update(st, p, n);
 }
+// which of the three loops this machine gets: 2 = VPCLMULQDQ (512-bit), 1 = PCLMULQDQ (128-bit), 0 = tables
+int crc32_host_level() { return have_vclmul() ? 2 : (have_clmul() ? 1 : 0); }
 }  // namespace smh
+
+// diagnostic: the CRC by ONE of the three loops (2 = VPCLMULQDQ, 1 = PCLMULQDQ, 0 = tables; a level the machine does not have falls
+// back to the next lower one) -- the tests run every loop the machine has against zlib; level < 0 only reports the machine's level
+extern "C" SMHV_API int smhv_debug_crc32_host_level(const void *data, uint64_t nbytes, int level, uint32_t *crc) {
+	const int have = smh::crc32_host_level();
+	if (level < 0 || !data || !crc) return have;
+	const uint8_t *p = (const uint8_t *)data;
+	const size_t n = (size_t)nbytes;
+	uint32_t st = 0xFFFFFFFFu;
+	if (n) {
+		if (level >= 2 && have >= 2 && n >= 512) st = crc_vclmul_update(st, p, n);
+		else if (level >= 1 && have >= 1 && n >= 64) st = crc_clmul_update(st, p, n);
+		else st = crc_table_update(st, p, n);
+	}
+	*crc = n ? ~st : 0u;
+	return have;
+}
 
 // CRC-32/IEEE of nbytes at data (== crc32fast::hash == zlib crc32(0, ..)); any length, any alignment.  Host only: needs no device.
 extern "C" SMHV_API uint32_t smhv_crc32_host(const void *data, uint64_t nbytes) {

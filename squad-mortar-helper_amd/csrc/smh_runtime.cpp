@@ -956,6 +956,9 @@ struct smhv_pipeline {
 	uint32_t own_queues = 0;               // streams of this pipeline that were given a hardware queue of their own
 	struct ModeCtl {
 		uint32_t phase = 0, count = 0, settle = 0, key_n = 0, key_stages = 0, key_gap = 0, decisions = 0;
+		uint32_t cand_n = 0, cand_stages = 0, cand_gap = 0, cand_count = 0;   // a shape other than the settled one, and for how many submissions in a row
+		uint32_t remeasured = 0;               // measurements started by a change of shape since the last periodic one (capped)
+		bool window_mixed = false;             // the shape changed inside a measurement window: that window does not count
 		uint64_t frames = 0;
 		struct timespec t0{};
 		double rate[2] = {0.0, 0.0};       // frames/s measured in the last window of [0] batch-granular, [1] frame-granular
@@ -1359,33 +1362,61 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 //   phase 3  measure it the same way -> rate[other]; keep the faster mode (the batch-granular search has to be 3 % ahead: on a
 //            tie -- a host that submits slower than either search runs, batches of one frame -- the service is the cheaper
 //            one for the host, one small publication kernel per submission instead of a search launch)
-//   phase 4  settled for SMH_MODE_RECHECK submissions, or until the submissions change shape (frames, stages, gap threshold)
+//   phase 4  settled for SMH_MODE_RECHECK submissions, or until the submissions change shape for good: frames per submission by
+//            more than 25 %, stages or gap threshold, for `depth` submissions in a row (at most SMH_MODE_REMEASURE_CAP such
+//            measurements between two periodic ones); a window inside which the shape changed is measured again
 #define SMH_MODE_RECHECK 16384u
+// A submission's shape as the controller sees it: frames per submission in buckets of +-25 % (a host whose batches vary -- ingest
+// slabs after duplicate drops, a short last batch -- is ONE workload), stages and gap threshold exactly.
+static inline bool same_shape(uint32_t n_a, uint32_t st_a, uint32_t gap_a, uint32_t n_b, uint32_t st_b, uint32_t gap_b) {
+	if (st_a != st_b || gap_a != gap_b) return false;
+	const uint64_t lo = std::min(n_a, n_b), hi = std::max(n_a, n_b);
+	return hi * 4u <= lo * 5u;                                 // within 25 %
+}
+#define SMH_MODE_REMEASURE_CAP 4u       // measurements a change of shape may start between two periodic ones
 static int mode_control(smhv_pipeline *p, uint32_t n, uint32_t stages, uint32_t max_gap) {
 	smhv_pipeline::ModeCtl &m = p->mc;
 	const uint32_t W = 8u * p->depth;
-	if (m.phase == 4 && (m.key_n != n || m.key_stages != stages || m.key_gap != max_gap)) { m.phase = 0; m.count = 0; }
-	m.key_n = n; m.key_stages = stages; m.key_gap = max_gap;
-	auto begin = [&m]() { m.count = 0; m.frames = 0; clock_gettime(CLOCK_MONOTONIC, &m.t0); };
+	auto begin = [&m]() { m.count = 0; m.frames = 0; m.window_mixed = false; clock_gettime(CLOCK_MONOTONIC, &m.t0); };
 	auto rate = [&m]() {
 		struct timespec t1;
 		clock_gettime(CLOCK_MONOTONIC, &t1);
 		const double dt = (double)(t1.tv_sec - m.t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - m.t0.tv_nsec);
 		return dt > 0.0 ? (double)m.frames / dt : 0.0;
 	};
+	const bool same = m.key_n == 0u || same_shape(n, stages, max_gap, m.key_n, m.key_stages, m.key_gap);
+	if (m.key_n == 0u) { m.key_n = n; m.key_stages = stages; m.key_gap = max_gap; }
+	if (m.phase == 4) {
+		// settled: a new shape has to PERSIST (depth submissions in a row) before it starts a new measurement, and only
+		// SMH_MODE_REMEASURE_CAP of those between two periodic ones -- a host that alternates shapes keeps what it has
+		if (same) m.cand_count = 0;
+		else {
+			if (m.cand_count && same_shape(n, stages, max_gap, m.cand_n, m.cand_stages, m.cand_gap)) m.cand_count++;
+			else { m.cand_n = n; m.cand_stages = stages; m.cand_gap = max_gap; m.cand_count = 1; }
+			if (m.cand_count >= p->depth && m.remeasured < SMH_MODE_REMEASURE_CAP) {
+				m.key_n = m.cand_n; m.key_stages = m.cand_stages; m.key_gap = m.cand_gap;
+				m.cand_count = 0; m.remeasured++;
+				m.phase = 0; m.count = 0;
+			}
+		}
+	} else if (!same) m.window_mixed = true;                   // (a window that saw two shapes is measured again)
 	int rc = SMHV_OK;
 	switch (m.phase) {
 	case 0:
 		if (m.count >= 2u * p->depth) { m.phase = 1; begin(); }
 		break;
 	case 1:
-		if (m.count >= W) { m.rate[p->mode_frame ? 1 : 0] = rate(); p->mode_frame = !p->mode_frame; m.phase = 2; m.count = 0; }
+		if (m.count >= W) {
+			if (m.window_mixed) { m.key_n = n; m.key_stages = stages; m.key_gap = max_gap; begin(); break; }
+			m.rate[p->mode_frame ? 1 : 0] = rate(); p->mode_frame = !p->mode_frame; m.phase = 2; m.count = 0;
+		}
 		break;
 	case 2:
 		if (m.count >= 6u * p->depth) { m.phase = 3; begin(); }
 		break;
 	case 3:
 		if (m.count >= W) {
+			if (m.window_mixed) { m.key_n = n; m.key_stages = stages; m.key_gap = max_gap; begin(); break; }
 			m.rate[p->mode_frame ? 1 : 0] = rate();
 			p->mode_frame = !(m.rate[0] > 1.03 * m.rate[1]);
 			m.decisions++;
@@ -1394,7 +1425,7 @@ static int mode_control(smhv_pipeline *p, uint32_t n, uint32_t stages, uint32_t 
 		}
 		break;
 	default:
-		if (m.count >= m.settle) { m.phase = 1; begin(); }
+		if (m.count >= m.settle) { m.phase = 1; m.remeasured = 0; begin(); }
 		break;
 	}
 	return rc;

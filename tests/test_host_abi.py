@@ -128,6 +128,30 @@ def test_host_crc32_equals_zlib_for_ragged_lengths_and_alignments(built):
     assert ingest.crc32_host(b"\xff" * 100000) == zlib.crc32(b"\xff" * 100000)
 
 
+def test_every_host_crc32_loop_equals_zlib(built):
+    """The library has three host loops for the CRC -- 512-bit VPCLMULQDQ folding (2048 bits per step), 128-bit PCLMULQDQ lanes,
+    slicing-by-8 tables -- and picks by CPUID.  smhv_debug_crc32_host_level runs ONE of them (a loop the machine lacks falls
+    back to the next lower one): every loop this machine has, against zlib, on lengths around every block size of the three
+    (16, 64, 256, 512 bytes) and a frame-sized message, at several alignments."""
+    import ctypes as C
+    import zlib
+    from squad_mortar_helper_amd import _lib
+    lib = _lib.load()
+    have = lib.smhv_debug_crc32_host_level(None, 0, -1, None)
+    assert have in (0, 1, 2)
+    rng = np.random.default_rng(11)
+    buf = rng.integers(0, 256, size=(8 << 20) + 128, dtype=np.uint8)
+    lengths = sorted(set(list(range(0, 80)) + [k + d for k in (128, 256, 512, 768, 1024, 2048, 61440, 65536) for d in (-17, -1, 0, 1, 15, 16, 63, 64, 65)] +
+                         [1920 * 1080 * 4, (8 << 20) - 5]))
+    c = C.c_uint32()
+    for n in lengths:
+        for off in (0, 3, 16, 33):
+            ref = zlib.crc32(buf[off:off + n].tobytes())
+            for level in range(have + 1):
+                assert lib.smhv_debug_crc32_host_level(C.c_void_p(buf.ctypes.data + off), n, level, C.byref(c)) == have
+                assert c.value == ref, (n, off, level)
+
+
 def test_shard_range_partitions_exactly(built):
     from squad_mortar_helper_amd.dist import shard_range
     for n in (1, 7, 8, 255, 256, 8192):
