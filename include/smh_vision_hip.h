@@ -430,6 +430,7 @@ SMHV_API int smhv_ingest_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_
  * frames then hold exactly those two rectangles (zero elsewhere), which is all smhv_batch_run / the pipelines read.  BGRA8
  * commits only. */
 #define SMHV_INGEST_ROI_UPLOAD 1u
+#define SMHV_INGEST_WORKERS(n) (((n) & 0xFFu) << 8)   /* diagnostic, with SMHV_INGEST_ROI_UPLOAD: hashing threads (0 = the library's choice: all but two of the cores the process may use) */
 SMHV_API int smhv_ingest_create_ex(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t slots, uint32_t capacity, uint32_t flags, smhv_ingest **out);
 SMHV_API void smhv_ingest_destroy(smhv_ingest *q);
 /* next pinned staging buffer (frame_w * frame_h * 4 bytes); blocks only when all `slots` uploads are in flight */

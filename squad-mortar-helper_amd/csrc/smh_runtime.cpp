@@ -859,7 +859,7 @@ static int copy_image_d2h(smhv_ctx *c, int slot, uint8_t *dst, const uint8_t *d_
 		c->h_stage_cap[slot] = bytes;
 	}
 	HIPCHK(hipMemcpyAsync(c->h_stage[slot], d_rows, bytes, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(wait_stream(s));
 	for (size_t r = 0; r < rows; ++r) memcpy(dst + r * width, c->h_stage[slot] + r * pitch + xoff, width);
 	return SMHV_OK;
 }
@@ -1704,7 +1704,7 @@ extern "C" SMHV_API int smhv_load_frame_view(smhv_ctx *c, const uint8_t *parent_
 	const uint32_t y1 = (g.ry + g.rh > g.by + g.bh) ? g.ry + g.rh : g.by + g.bh;
 	const uint8_t *src = parent_bgra + ((size_t)(y + y0) * parent_w + x) * 4;
 	HIPCHK(hipMemcpy2DAsync(c->d_frame + (size_t)y0 * w * 4, (size_t)w * 4, src, (size_t)parent_w * 4, (size_t)w * 4, y1 - y0, hipMemcpyHostToDevice, c->s_main));
-	HIPCHK(hipStreamSynchronize(c->s_main));
+	HIPCHK(wait_stream(c->s_main));
 	c->frame_ptr = c->d_frame;
 	reset_frame_state(c);
 	return SMHV_OK;
@@ -1859,7 +1859,7 @@ extern "C" SMHV_API int smhv_mask_marker_lines(smhv_ctx *c) {
 	smhv_batch *b = c->fb;
 	Buffers bf = make_buffers(b, c->frame_ptr, 0);
 	HIPCHK(launch_map_pass(b->g, bf, 1, MAP_MASK, 1, c->s_markers));
-	HIPCHK(hipStreamSynchronize(c->s_markers));
+	HIPCHK(wait_stream(c->s_markers));
 	c->mask_valid = true;
 	return SMHV_OK;
 }
@@ -1896,7 +1896,7 @@ extern "C" SMHV_API int smhv_find_longest_line(smhv_ctx *c, float px, float py, 
 	hipStream_t s = c->s_markers;
 	HIPCHK(launch_lsd(b->g, bf, 1, max_gap, 1, px, py, s, nullptr));
 	HIPCHK(hipMemcpyAsync(&c->h_res[2], b->d_results + 2, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(wait_stream(s));
 	*line = c->h_res[2].lines[0];
 	*len_sq = (float)c->h_res[2].length_px[0];
 	return SMHV_OK;
@@ -1917,7 +1917,7 @@ extern "C" SMHV_API int smhv_find_marker_lines(smhv_ctx *c, uint32_t max_gap, sm
 	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s, nullptr, 1024u, true));
 	HIPCHK(launch_finalize(b->g, bf, 1, SMHV_STAGE_MARKERS, s));
 	HIPCHK(hipMemcpyAsync(&c->h_res[0], b->d_results, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(wait_stream(s));
 	*n = c->h_res[0].n_lines;
 	memcpy(out, c->h_res[0].lines, sizeof(smhv_line) * SMHV_MAX_LINES);
 	return SMHV_OK;
@@ -1938,7 +1938,7 @@ extern "C" SMHV_API int smhv_lsd_stats(smhv_ctx *c, uint32_t max_gap, int exact,
 	// one frame, nothing beside it: the workgroup-synchronous kernel is as fast or faster (2.4 against 2.8 ms on the heaviest sample)
 	HIPCHK(launch_lsd(b->g, bf, 1, (float)max_gap, 0, 0.0f, 0.0f, s, nullptr, 1024u, true));
 	HIPCHK(hipMemcpyAsync(&c->h_res[2], b->d_results + 2, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(wait_stream(s));
 	*rounds = c->h_res[2].rounds;
 	*ray_steps = c->h_res[2].ray_steps;
 	return SMHV_OK;
@@ -1968,7 +1968,7 @@ extern "C" SMHV_API int smhv_calc_meters_to_px_ratio(smhv_ctx *c, const uint32_t
 	HIPCHK(launch_scale_ratio(b->g, bf, 1, b->d_bars, s));
 	HIPCHK(hipMemcpyAsync(&c->h_res[1], b->d_results + 1, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
 	HIPCHK(hipMemcpyAsync(c->h_bars, b->d_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(wait_stream(s));
 	*has = c->h_res[1].has_mpx ? 1 : 0;
 	*ratio = c->h_res[1].mpx;
 	if (bars) memcpy(bars, c->h_bars, sizeof(uint32_t) * 4 * n);
@@ -1991,7 +1991,7 @@ extern "C" SMHV_API int smhv_find_minimap(smhv_ctx *c, uint32_t rect[4], int *fo
 	hipStream_t s = c->s_main;
 	HIPCHK(launch_find_minimap(b->g, bf, 1, s));
 	HIPCHK(hipMemcpyAsync(&c->h_res[3], b->d_results + 3, sizeof(smhv_frame_result), hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(wait_stream(s));
 	*found = c->h_res[3].has_minimap ? 1 : 0;
 	memcpy(rect, c->h_res[3].minimap, sizeof(uint32_t) * 4);
 	return SMHV_OK;
@@ -2048,8 +2048,10 @@ extern "C" SMHV_API int smhv_debug_marker_table(smhv_ctx *c, uint32_t *bits) {
 struct smhv_ingest {
 	smhv_ctx *ctx = nullptr;
 	uint32_t W = 0, H = 0, slots = 0, capacity = 0;
+	uint32_t workers_opt = 0;                                // SMHV_INGEST_WORKERS(n) of the flags: hashing threads (0: the library's choice)
 	size_t frame_bytes = 0;
 	hipStream_t s = nullptr;
+	hipStream_t s_alt = nullptr;                             // region-of-interest mode: the packed uploads take s and s_alt in turn (two copy engines)
 	std::vector<uint8_t *> h_stage, d_stage, d_raw;           // d_raw: a slot's upload in a decoder's layout (allocated on first use)
 	std::vector<hipEvent_t> done;
 	uint32_t *d_acc = nullptr, *h_acc = nullptr;            // one CRC accumulator per slot (device / pinned host)
@@ -2187,6 +2189,7 @@ extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
 	}
 	if (q->ctx) (void)hipSetDevice(q->ctx->device);
 	if (q->s) (void)hipStreamSynchronize(q->s);
+	if (q->s_alt) (void)hipStreamSynchronize(q->s_alt);
 	for (auto p : q->h_stage) if (p) (void)hipHostFree(p);
 	for (auto p : q->d_stage) if (p) (void)hipFree(p);
 	for (auto p : q->d_raw) if (p) (void)hipFree(p);
@@ -2199,12 +2202,14 @@ extern "C" SMHV_API void smhv_ingest_destroy(smhv_ingest *q) {
 	if (q->d_x_wg) (void)hipFree(q->d_x_wg);
 	if (q->d_slab) (void)hipFree(q->d_slab);
 	if (q->s) (void)hipStreamDestroy(q->s);
+	if (q->s_alt) (void)hipStreamDestroy(q->s_alt);
 	ctx_release(q->ctx);
 	delete q;
 }
 
 static int ingest_setup(smhv_ingest *q) {
 	HIPCHK(hipStreamCreateWithFlags(&q->s, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&q->s_alt, hipStreamNonBlocking));
 	q->h_stage.assign(q->slots, nullptr); q->d_stage.assign(q->slots, nullptr); q->d_raw.assign(q->slots, nullptr); q->done.assign(q->slots, nullptr);
 	for (uint32_t i = 0; i < q->slots; ++i) {
 		HIPCHK(hipHostMalloc((void **)&q->h_stage[i], q->frame_bytes, hipHostMallocDefault));
@@ -2237,7 +2242,11 @@ static int ingest_setup(smhv_ingest *q) {
 		// one worker per staging slot, within half the cores the process may actually use: a container's CPU quota (cgroup
 		// cpu.max) counts, not the host's thread count -- 32 hashing threads under a 16-core quota get throttled by the
 		// scheduler in 100 ms periods, and the queue's rate with them (6.7-10.7 k frames/s from run to run)
-		const uint32_t nthreads = std::min<uint32_t>(q->slots, std::max(2u, usable_cores() / 2u));
+		// (with the 512-bit CRC loop a worker is bound by what one core reads from memory, ~8 GB/s of a staging buffer that has
+		// left the caches: the cores are what scales -- all but two of the quota, the producer thread and the runtime's own keep those)
+		// (measured with the 512-bit CRC loop, a 16-core quota, the queue alone: 4 / 8 / 12 / 14 / 16 / 24 workers: 9.4 / 10.9 / 10.6 /
+		// 8.5 / 9.4 / 9.4 k frames/s -- past eight the hashing is not what bounds the queue, PCIe and the producer's own calls are)
+		const uint32_t nthreads = std::min<uint32_t>(q->slots, q->workers_opt ? q->workers_opt : std::max(2u, usable_cores() / 2u));
 		for (uint32_t i = 0; i < nthreads; ++i) q->workers.emplace_back(ingest_worker, q);
 	}
 	return SMHV_OK;
@@ -2248,7 +2257,7 @@ extern "C" SMHV_API int smhv_ingest_create(smhv_ctx *c, uint32_t w, uint32_t h, 
 }
 
 extern "C" SMHV_API int smhv_ingest_create_ex(smhv_ctx *c, uint32_t w, uint32_t h, uint32_t slots, uint32_t capacity, uint32_t flags, smhv_ingest **out) {
-	if (!c || !out || w == 0 || h == 0 || slots < 2 || slots > 64 || capacity == 0 || (flags & ~SMHV_INGEST_ROI_UPLOAD)) return fail(SMHV_E_INVALID, "ingest_create: bad arguments");
+	if (!c || !out || w == 0 || h == 0 || slots < 2 || slots > 64 || capacity == 0 || (flags & ~(SMHV_INGEST_ROI_UPLOAD | 0xFF00u))) return fail(SMHV_E_INVALID, "ingest_create: bad arguments");
 	*out = nullptr;
 	CTX_OPEN(c);
 	Geom g;
@@ -2260,6 +2269,7 @@ extern "C" SMHV_API int smhv_ingest_create_ex(smhv_ctx *c, uint32_t w, uint32_t 
 	c->refs.fetch_add(1, std::memory_order_relaxed);
 	q->ctx = c; q->W = w; q->H = h; q->slots = slots; q->capacity = capacity; q->frame_bytes = (size_t)w * h * 4;
 	q->roi = (flags & SMHV_INGEST_ROI_UPLOAD) != 0u; q->g = g;
+	q->workers_opt = (flags >> 8) & 0xFFu;
 	rc = ingest_setup(q);
 	if (rc) { smhv_ingest_destroy(q); return rc; }
 	*out = q;
@@ -2288,9 +2298,12 @@ static int ingest_resolve_one(smhv_ingest *q) {
 		q->last_crc = crc;
 		const Geom &g = q->g;
 		uint8_t *dst = q->d_slab + (size_t)q->count * q->frame_bytes;
-		HIPCHK(hipMemcpyAsync(q->d_pack[slot], q->h_pack[slot], q->pack_bytes, hipMemcpyHostToDevice, q->s));
-		HIPCHK(launch_unpack_rows(q->d_pack[slot], dst, g.W, g.m_ax, g.ry, (uint32_t)(q->roi_row_bytes / 4), g.rh, g.bx, g.by, g.bw, g.bh, q->s));
-		HIPCHK(hipEventRecord(q->done[slot], q->s));             // the slot's pack buffers are free again when this has passed
+		// (frames are independent appends to the slab: consecutive ones take two streams in turn, so that one frame's 3.3 MB cross PCIe
+		// while the previous frame's are still on their way -- one stream of such copies reaches 25 GB/s of the link's 50)
+		const hipStream_t st = (q->tail & 1ull) ? q->s_alt : q->s;
+		HIPCHK(hipMemcpyAsync(q->d_pack[slot], q->h_pack[slot], q->pack_bytes, hipMemcpyHostToDevice, st));
+		HIPCHK(launch_unpack_rows(q->d_pack[slot], dst, g.W, g.m_ax, g.ry, (uint32_t)(q->roi_row_bytes / 4), g.rh, g.bx, g.by, g.bw, g.bh, st));
+		HIPCHK(hipEventRecord(q->done[slot], st));               // the slot's pack buffers are free again when this has passed
 		{ std::lock_guard<std::mutex> lk(q->mu); q->crc_state[slot] = 0; }
 		q->tail++; q->count++; q->n_new++;
 		return SMHV_OK;
@@ -2397,6 +2410,7 @@ extern "C" SMHV_API int smhv_ingest_batch(smhv_ingest *q, const void **d_frames,
 		if (rc) return rc;
 	}
 	HIPCHK(wait_stream(q->s));                                // slab appends done: any stream may read it now
+	if (q->roi) HIPCHK(wait_stream(q->s_alt));
 	*d_frames = q->d_slab; *n = q->count;
 	if (last_crc) *last_crc = q->last_crc;
 	return SMHV_OK;

@@ -32,15 +32,16 @@ PIXEL_LAYOUTS = {"bgra": (0, 4), "rgba": (1, 4), "rgb": (2, 3), "l": (3, 1), "la
 class IngestQueue:
     """`slots` pinned staging buffers + one device slab of `capacity` frames of w x h BGRA."""
 
-    def __init__(self, vision, w, h, slots=4, capacity=256, roi_upload=False):
-        """roi_upload: hash on the host, upload only the map ROI's and the button's rows (SMHV_INGEST_ROI_UPLOAD)."""
+    def __init__(self, vision, w, h, slots=4, capacity=256, roi_upload=False, workers=0):
+        """roi_upload: hash on the host, upload only the map ROI's and the button's rows (SMHV_INGEST_ROI_UPLOAD); workers: hashing
+        threads (diagnostic; 0 = the library's choice)."""
         self._lib = _lib.load()
         self._q = C.c_void_p()
         self.w, self.h, self.capacity = int(w), int(h), int(capacity)
         self.frame_bytes = self.w * self.h * 4
         self._vision = vision                                   # keeps the context alive
         self._views = {}
-        check(self._lib.smhv_ingest_create_ex(vision._ctx, self.w, self.h, int(slots), self.capacity, 1 if roi_upload else 0, C.byref(self._q)))
+        check(self._lib.smhv_ingest_create_ex(vision._ctx, self.w, self.h, int(slots), self.capacity, (1 if roi_upload else 0) | ((int(workers) & 0xFF) << 8), C.byref(self._q)))
 
     def close(self):
         if self._q:
