@@ -236,40 +236,41 @@ def records_equal_oracle(np, rec, ref):
 
 
 class DeviceWatch:
-    """Shader clock, temperature and power of the device while a region runs (sysfs hwmon of the amdgpu card, sampled by a thread
-    every 50 ms; best effort: None where the box does not show them).  A 513 k vs 551 k spread between boxes is attributable
-    only with these beside the value."""
+    """Shader clock, temperature and power of the device while a region runs (sysfs hwmon of the amdgpu cards, sampled by a thread
+    every 50 ms; best effort: None where the box does not show them).  A box shows every GPU of its host, whichever one the
+    process was given: all of them are sampled and the one that drew the most power in the region -- the one under load -- is
+    reported.  A 513 k vs 551 k spread between boxes is attributable only with these beside the value."""
 
-    def __init__(self, pci_bus_id=None):
+    def __init__(self):
         import glob
-        self.files = {}
+        self.cards = []
         for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             try:
                 if open(os.path.join(card, "vendor")).read().strip() != "0x1002":
                     continue
-                if pci_bus_id and pci_bus_id.lower() not in os.path.realpath(card).lower():
-                    continue
             except OSError:
                 continue
+            files = {}
             for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
                 for key, names in (("sclk_mhz", ("freq1_input",)), ("temp_c", ("temp2_input", "temp1_input")), ("power_w", ("power1_average", "power1_input"))):
                     for nm in names:
                         fpath = os.path.join(hw, nm)
-                        if key not in self.files and os.path.exists(fpath):
-                            self.files[key] = fpath
-            if self.files:
-                break
-        self.samples = {k: [] for k in self.files}
+                        if key not in files and os.path.exists(fpath):
+                            files[key] = fpath
+            if files:
+                self.cards.append((os.path.basename(os.path.realpath(card)), files, {k: [] for k in files}))
+        self.files = bool(self.cards)
         self._stop = None
         self._thr = None
 
     def _read(self):
         scale = {"sclk_mhz": 1e-6, "temp_c": 1e-3, "power_w": 1e-6}
-        for k, f in self.files.items():
-            try:
-                self.samples[k].append(float(open(f).read().strip()) * scale[k])
-            except (OSError, ValueError):
-                pass
+        for _, files, samples in self.cards:
+            for k, f in files.items():
+                try:
+                    samples[k].append(float(open(f).read().strip()) * scale[k])
+                except (OSError, ValueError):
+                    pass
 
     def __enter__(self):
         import threading
@@ -288,11 +289,18 @@ class DeviceWatch:
         self._thr.join(timeout=1.0)
 
     def summary(self):
-        out = {}
-        for k, v in self.samples.items():
+        best = None
+        for name, _, samples in self.cards:
+            load = samples.get("power_w") or samples.get("sclk_mhz") or []
+            if load and (best is None or sum(load) / len(load) > best[0]):
+                best = (sum(load) / len(load), name, samples)
+        if best is None:
+            return None
+        out = {"card": best[1], "cards_sampled": len(self.cards)}
+        for k, v in best[2].items():
             if v:
                 out[k] = {"min": min(v), "max": max(v), "mean": sum(v) / len(v), "samples": len(v)}
-        return out or None
+        return out
 
 
 def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, probe_wgs, passes=300):
@@ -845,8 +853,7 @@ def main():
         for b in pipe.slots:
             b.enable_timing(True)
     try:
-        pr = torch.cuda.get_device_properties(local_rank)
-        watch = DeviceWatch("%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id) if hasattr(pr, "pci_bus_id") and world > 1 else None)
+        watch = DeviceWatch()
     except Exception:  # noqa: BLE001  (diagnostic only)
         watch = None
     if watch is not None and watch.files:

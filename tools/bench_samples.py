@@ -46,10 +46,11 @@ def main():
     # warm: a GPU that comes out of idle needs a few hundred milliseconds to reach its clocks (40 cold steps measured 107 k
     # frames/s where the same pipeline runs at 190 k once warm)
     t_w = time.perf_counter()
+    # (no drain inside the warm-up: a pipeline with SMHV_SEARCH_AUTO measures its two searches over windows of submissions here)
     while time.perf_counter() - t_w < float(os.environ.get("SAMPLES_WARM_S", "1.0")):
         for i in range(2 * depth):
             pipe.submit(d.data_ptr(), n, stages=STAGES, max_gap=15)
-        pipe.wait()
+    pipe.wait()
     steps = int(os.environ.get("SAMPLES_STEPS", "400"))
     t0 = time.perf_counter()
     stamps = []

@@ -54,6 +54,10 @@ def main():
         if src:
             shutil.copy(src, os.path.join(OUT, f"{tag}_kernel_stats_depth{d[1:]}.csv" if cfg == "c2" else f"{tag}_{cfg}_kernel_stats_depth{d[1:]}.csv"))
     pre = "" if cfg == "c2" else cfg + "_"
+    if cfg == "c2":                                          # the per-call (trait) path's kernels (tools/trait_profile.py)
+        src = find(tag, "trait", "*kernel_stats.csv")
+        if src:
+            shutil.copy(src, os.path.join(OUT, f"{tag}_trait_kernel_stats.csv"))
     fetch = counter_means(find(tag, pre + "fetch", "*counter_collection.csv"), "FETCH_SIZE")
     write = counter_means(find(tag, pre + "write", "*counter_collection.csv"), "WRITE_SIZE")
     lines = [f"{tag}: bench.py --config {cfg[1]} --pipeline-depth 1, {FRAMES} x {W}x{H} frames resident in HBM",

@@ -11,10 +11,15 @@ bash tools/profile_sq.sh $TAG > /dev/null 2>&1
 PDEPTH=4 bash tools/profile_sq.sh ${TAG}_d4 > /dev/null 2>&1
 bash tools/profile_sq_service.sh $TAG > /dev/null 2>&1
 for C in 0 4; do timeout 900 python bench.py --config $C 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_config$C.json; done
-for D in 4 12; do
+for D in 4 12 20; do
   timeout 600 python tools/bench_samples.py 128 $D 2>&1 | grep -v amdgpu.ids | tail -5 > gpurun_out/${TAG}_samples_d$D.txt
   tail -1 gpurun_out/${TAG}_samples_d$D.txt > gpurun_out/${TAG}_samples_d$D.json
 done
+for S in frame batch; do SAMPLES_STEPS=2000 SAMPLES_SEARCH=$S timeout 600 python tools/bench_samples.py 128 12 2>&1 | tail -1 > gpurun_out/${TAG}_samples_d12_$S.json; done
+SAMPLES_STEPS=2000 SAMPLES_SEARCH=frame SAMPLES_FLAGS=8 timeout 600 python tools/bench_samples.py 128 12 2>&1 | tail -1 > gpurun_out/${TAG}_samples_d12_frame_no_remote_help.json
+timeout 300 python tools/side_probe.py 2>&1 | tail -1 > gpurun_out/${TAG}_side_probe_no_room.json
+SIDE_SVC_WGS=224 timeout 300 python tools/side_probe.py 2>&1 | tail -1 > gpurun_out/${TAG}_side_probe_room.json
+timeout 300 python tools/latency_trait.py > gpurun_out/${TAG}_latency_trait.txt 2>&1
 for D in 4 12 16; do
   T=$(find gpurun_out/prof_${TAG}_d$D -name "*kernel_trace.csv" | head -1)
   [ -n "$T" ] && python tools/trace_overlap.py $T > gpurun_out/${TAG}_trace_overlap_depth$D.txt 2>&1

@@ -12,7 +12,7 @@ R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back --no-real-samples"   # profiled runs: only warm-up, timed and isolated passes
+B="python3 $R/bench.py --cpu-sample 0 --ingest-frames 0 --no-depth1 --no-back-to-back --no-real-samples --side-probe 0"   # profiled runs: only warm-up, timed and isolated passes
 for C in 2 3; do
   P=""; [ $C = 3 ] && P="c3_"
   for D in 1 4 12 16; do
@@ -23,6 +23,8 @@ for C in 2 3; do
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_${P}fetch -- $B --config $C --steps 1 --warmup 1 --rounds-per-step 2 --pipeline-depth 1 > /dev/null 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_${P}write -- $B --config $C --steps 1 --warmup 1 --rounds-per-step 2 --pipeline-depth 1 > /dev/null 2>&1
 done
+# the per-call (trait) path: VisionState.process on one 1080p frame, 200 times
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_trait -- python3 $R/tools/trait_profile.py > $OUT/${TAG}_trait_profiled.txt 2>/dev/null
 cd $R
 python tools/pmc_summary.py "$TAG" c2
 python tools/pmc_summary.py "$TAG" c3

@@ -12,6 +12,13 @@ for r in rows:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k, r.get("Queue_Id")))
 ev.sort()
 maps = [e for e in ev if e[2] == "map"]
+# (bench.py's later legs -- the per-call path -- launch k_map_pass long after the timed region: with the fused pass in the trace, the
+# region is the fused pass's)
+fused = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_map_brq" in r["Kernel_Name"]}
+if fused:
+    t_last = max(e for _, e in fused)
+    ev = [e for e in ev if e[0] <= t_last]
+    maps = [e for e in maps if (e[0], e[1]) in fused]
 skip = max(0, len(maps) // 4)                       # leave the warm-up out
 t0 = maps[skip][0]
 t1 = max(e[1] for e in ev if e[2] == "map")
@@ -23,15 +30,28 @@ for s, e, k, q in ev:
     pts.append((s, 1, k)); pts.append((e, -1, k))
 pts.sort()
 act, last, occ = collections.Counter(), t0, collections.Counter()
+idle_gaps = []                                      # every interval in which NO kernel of the pipeline runs
 for t, d, k in pts:
     key = ("map%d" % act["map"] if act["map"] else "") + (" search%d" % act["search"] if act["search"] else "") + (" service" if act["service"] else "")
     occ[key or "nothing"] += t - last
+    if not key and t > last:
+        idle_gaps.append(t - last)
     last = t
     act[k] += d
 tot = sum(occ.values())
 print("region %.2f ms, %d streaming passes -> %.3f ms per pass" % ((t1 - t0) / 1e6, len([e for e in ev if e[2] == "map"]), (t1 - t0) / 1e6 / max(1, len([e for e in ev if e[2] == "map"]))))
 for k, v in occ.most_common(10):
     print("  %-18s %5.1f %%" % (k, 100 * v / tot))
+# where the "nothing" is: bench.py brackets its timed steps with barrier + synchronize (five sub-regions, the warm-up, the two
+# searches an adaptive pipeline measures): the pipeline DRAINS there and the search kernel is launched again (it copies 41 KB of
+# tables into LDS per workgroup first).  Those are the long gaps; what is left between them is the steady state.
+long_gaps = [g for g in idle_gaps if g > 500e3]
+short = sum(g for g in idle_gaps if g <= 500e3)
+if idle_gaps:
+    steady = tot - sum(long_gaps)
+    print("  nothing: %d gaps longer than 0.5 ms = %.1f ms (drains at bench.py's barriers and relaunches of the search kernel: %s ms), %d shorter ones = %.1f ms -> steady state: nothing %.1f %% of %.1f ms, %.3f ms per pass"
+          % (len(long_gaps), sum(long_gaps) / 1e6, " ".join("%.1f" % (g / 1e6) for g in sorted(long_gaps, reverse=True)[:10]), len(idle_gaps) - len(long_gaps), short / 1e6,
+             100.0 * short / max(steady, 1), steady / 1e6, steady / 1e6 / max(1, len([e for e in ev if e[2] == "map"]))))
 for k in ("map", "search", "service", "button", "publish", "record"):
     d = [(e[1] - e[0]) / 1e3 for e in ev if e[2] == k]
     if d:
