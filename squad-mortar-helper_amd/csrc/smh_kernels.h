@@ -262,11 +262,13 @@ struct SvcParams {
 	uint32_t remote_after;              // rounds a frame works (with its workgroup's help) before it asks the other workgroups
 	uint32_t remote_tickets;            // helpers it asks for
 	uint32_t remote_last_div;           // ... once it is among the last 1 / remote_last_div of its submission's frames still at work
+	uint32_t compact;                   // the waves' tile stores sit behind the compact index (LSD_MODE_TILEC): decided by svc_waves_for for the frame size
 	// (flags & 16: frames ask, and waves take tickets, whether or not frames are waiting for a wave -- A/B)
 };
 // waves per service workgroup and LDS per workgroup for this frame size (0 waves: the frame size does not fit -> no service)
-uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes);
-uint32_t svc_store_words_for(const Geom &g, uint32_t tile_cap);   // words of a frame's tile store (tiles + index), rounded up to whole 16-byte quads
+// (*compact <- whether the tile stores use the compact index: where that lets one more wave fit)
+uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes, uint32_t *compact = nullptr);
+uint32_t svc_store_words_for(const Geom &g, uint32_t tile_cap, uint32_t compact);   // words of a frame's tile store (tiles + index), rounded up to whole 16-byte quads
 hipError_t svc_probe_host_atomics(SvcHost *h, SvcHost *d_h, bool *ok);   // pipeline creation: do device-side system-scope atomics reach mapped host memory?
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s);
 hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s);

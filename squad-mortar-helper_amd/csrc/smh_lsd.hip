@@ -102,6 +102,16 @@ struct Win {
 	const LdsWord *t_tiles;
 	uint32_t t_pitch;
 	bool tiled;
+	// LSD_MODE_TILEC only (the search service above 1080p): the same tiles behind a COMPACT index -- per tile row and group of 64
+	// tile columns one 16-byte entry {occupancy mask (64 bits), number of the non-empty tiles before the group's first, 0}: tile
+	// (row, column c of the group) is entry.base + popcount(mask below c) + 1 when bit c is set, the empty tile 0 otherwise
+	// (tiles are numbered in raster order).  2.2 KB for a 1440p ROI where the 16-bit table takes 12.8 KB -- a quarter of what a
+	// wave of the service may hold there -- for a handful of integer instructions per look-up.  tc_rows points at the entry of
+	// (tile row 0, group 0); tile row -1 and the row behind the last are all-empty entries; column index = word column + 2 (the
+	// same two padding columns as t_idx).
+	const LdsWord *tc_rows;
+	uint32_t tc_groups;
+	bool compact;
 	// LSD_MODE_WIN2 only (k_lsd_tile): the candidate's own window of the mask -- whole words, LSD_W2_PITCH words per row,
 	// zero outside the image -- addressed directly: w2 is the byte address of (word 0, row 0) of the IMAGE, so the word of
 	// pixel (x, y) sits at w2 + y * 4 LSD_W2_PITCH + 4 (x >> 5) for every (x, y) inside the window.
@@ -124,7 +134,8 @@ struct Win {
 //   WIN2   (k_lsd_tile only) the first 64 steps of every ray of a candidate stay within 67 px of its pixel: the candidate's
 //          neighbourhood is copied once (from the tile store) into a small window with a fixed pitch, and those steps --
 //          most of all samples -- read it with one LDS access and no index look-up.
-enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2, LSD_MODE_TILE = 3, LSD_MODE_WIN2 = 4 };
+//   TILEC  (k_lsd_service above 1080p) TILE with the compact index (Win::tc_rows)
+enum { LSD_MODE_ROWS = 0, LSD_MODE_XWIN = 1, LSD_MODE_GLOBAL = 2, LSD_MODE_TILE = 3, LSD_MODE_WIN2 = 4, LSD_MODE_TILEC = 5 };
 
 // One sample.  Coordinates below/left of the window wrap to huge unsigned values and clamp to the far
 // (zero) border just like coordinates beyond it, so each axis costs one v_min_u32.  24-bit multiply:
@@ -144,6 +155,48 @@ __device__ __forceinline__ uint32_t win_raw(const Win &m, int xi, int yi) {   //
 __device__ __forceinline__ uint32_t tile_word(const Win &m, int wq, int yi) {
 	const uint32_t t = m.t_idx[__mul24(yi >> 3, (int)m.t_pitch) + wq];
 	return m.t_tiles[(t << 3) + ((uint32_t)yi & 7u)];
+}
+// LSD_MODE_TILEC: the tile number of (word column wq, tile row ty) through the compact index; -2 <= wq < t_pitch - 2, -1 <= ty <= rows
+typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t tilec_number(const Win &m, int wq, int ty) {
+	const uint32_t col = (uint32_t)(wq + 2);
+	const lds_u32x4 e = *(const __attribute__((address_space(3))) lds_u32x4 *)(m.tc_rows + (__mul24(ty, (int)m.tc_groups) + (int)(col >> 6)) * 4);
+	const uint32_t c = col & 63u;
+	// bits below c of the 64-bit mask, as two halves
+	const uint32_t lo_m = c >= 32u ? 0xFFFFFFFFu : ((1u << c) - 1u), hi_m = c > 32u ? ((1u << (c - 32u)) - 1u) : 0u;
+	const uint32_t bit = ((c >= 32u ? e.y >> (c - 32u) : e.x >> c) & 1u);
+	const uint32_t before = (uint32_t)__builtin_popcount(e.x & lo_m) + (uint32_t)__builtin_popcount(e.y & hi_m);
+	return bit ? e.z + before + 1u : 0u;
+}
+__device__ __forceinline__ uint32_t tilec_word(const Win &m, int wq, int yi) {
+	return m.t_tiles[(tilec_number(m, wq, yi >> 3) << 3) + ((uint32_t)yi & 7u)];
+}
+__device__ __forceinline__ uint32_t tilec_raw(const Win &m, float x, float y) {
+	const int yi = (int)__builtin_amdgcn_fmed3f(y, -1.0f, m.hf);
+	const int xi = (int)x;
+	return tilec_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u);
+}
+// (eight samples of a ray, as tile_raw8 -- in two halves: four 16-byte index entries in flight at a time are what the register
+// budget of the service's wave has room for)
+__device__ __forceinline__ void tilec_raw8(const Win &m, float xs, float ys, float dx, float dy, float &xo, float &yo, float &x, float &y, uint32_t &Wm) {
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		int yi[4], xi[4];
+		uint32_t t[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			x = xo + xs; y = yo + ys;
+			yi[j] = (int)__builtin_amdgcn_fmed3f(y, -1.0f, m.hf);
+			xi[j] = (int)x;
+			xo += dx; yo += dy;
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) t[j] = tilec_number(m, xi[j] >> 5, yi[j] >> 3);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) t[j] = m.t_tiles[(t[j] << 3) + ((uint32_t)yi[j] & 7u)];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) Wm = __builtin_amdgcn_alignbit(t[j] >> ((uint32_t)xi[j] & 31u), Wm, 1);
+	}
 }
 // LSD_MODE_TILE sample straight from the float position (bit 0 = the pixel): rows clamped onto the zero rows -1 and h in
 // the float domain; x needs no clamp (a batch never strays more than 33 px from the image: two padding columns)
@@ -186,14 +239,14 @@ __device__ __forceinline__ uint32_t win2_bit(const Win &m, int xi, int yi) { ret
 
 // (not on the hot path: the cache test is a run-time one here)
 __device__ __forceinline__ uint32_t win_bit(const Win &m, int xi, int yi) {
-	if (m.tiled) return (tile_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u)) & 1u;      // callers pass in-image coordinates
+	if (m.tiled) return ((m.compact ? tilec_word(m, xi >> 5, yi) : tile_word(m, xi >> 5, yi)) >> ((uint32_t)xi & 31u)) & 1u;      // callers pass in-image coordinates
 	return (m.c_rows ? win_raw<true>(m, xi, yi) : win_raw<false>(m, xi, yi)) & 1u;
 }
 
 // The 32 mask bits of word `wq` (in the view's own bit coordinate B = x + xbias) of image row yi; 0 outside the
 // window / image.  Works for all three residency modes (ROWS: xbias = 0).
 __device__ __forceinline__ uint32_t win_word(const Win &m, int wq, int yi) {
-	if (m.tiled) return ((uint32_t)yi < m.h && (uint32_t)(wq + 2) < m.t_pitch) ? tile_word(m, wq, yi) : 0u;
+	if (m.tiled) return ((uint32_t)yi < m.h && (uint32_t)(wq + 2) < m.t_pitch) ? (m.compact ? tilec_word(m, wq, yi) : tile_word(m, wq, yi)) : 0u;
 	const uint32_t ry = (uint32_t)(yi - m.y_lo), rc = (uint32_t)wq;
 	uint32_t v = 0;
 	if (ry <= m.rows_hi && rc <= m.cols_hi) {
@@ -260,7 +313,7 @@ enum { RAY_CONTINUE = 0, RAY_ABORTED = 1, RAY_LEFT_IMAGE = 2 };
 // G: samples whose LDS reads are in flight together (8, 16 or 32).
 template <int MODE, int G = 8>
 __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float dx, float dy, uint32_t T, RayState &s, uint32_t &steps) {
-	static_assert((G == 8 || G == 16 || G == 32) && (MODE != LSD_MODE_TILE || G == 8), "group size");
+	static_assert((G == 8 || G == 16 || G == 32) && ((MODE != LSD_MODE_TILE && MODE != LSD_MODE_TILEC) || G == 8), "group size");
 	float xo = s.bxo, yo = s.byo, x = 0.0f, y = 0.0f;
 	uint32_t Wm = 0;
 	// 4 x 8 samples: eight LDS reads in flight per wave keep the register footprint small enough for
@@ -271,6 +324,7 @@ __device__ __forceinline__ int ray_batch(const Win &m, float xs, float ys, float
 #pragma unroll 1
 	for (int jj = 0; jj < 32 / G; ++jj) {
 		if constexpr (MODE == LSD_MODE_TILE) tile_raw8(m, xs, ys, dx, dy, xo, yo, x, y, Wm);
+		else if constexpr (MODE == LSD_MODE_TILEC) tilec_raw8(m, xs, ys, dx, dy, xo, yo, x, y, Wm);
 		else
 #pragma unroll
 		for (int j = 0; j < G; ++j) {
@@ -735,6 +789,7 @@ __device__ __forceinline__ void frame_setup(const Geom &g, const Buffers &b, uin
 	m.rows0 = nullptr; m.ylo_f = 0.0f; m.yhi_f = 0.0f;
 	m.c_p = (const LdsWord *)smem; m.c_y0 = 0u; m.c_rows = 0u; m.c_pitch4 = 0u;
 	m.t_idx = nullptr; m.t_tiles = nullptr; m.t_pitch = 0u; m.tiled = false; m.w2 = nullptr;
+	m.tc_rows = nullptr; m.tc_groups = 0u; m.compact = false;
 	v.c_pitch = g.bits_pitch_w | 1u; v.c_cap_rows = min(g.rh, LSD_WIN_WORDS_CAP / v.c_pitch);
 	if (MODE == LSD_MODE_ROWS) {
 		const uint32_t wy0 = aux.y_min, wrows = aux.y_max - aux.y_min + 1u;
@@ -1455,20 +1510,29 @@ static uint32_t lsd_service_static_lds() {
 // Waves per service workgroup (one workgroup per CU) for this frame size: as many as fit beside two workgroups of the
 // streaming pass, at most SVC_MAX_WAVES -- one per SIMD, which leaves three 128-register wave slots per SIMD to the streaming
 // pass.  0: not even one wave fits (8K frames: the tile index alone is 106 KB) -> the pipeline keeps its batch-granular search.
-uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes) {
-	const uint32_t cap = lsd_tile_cap_of(g, tile_limit), lc = tile_list_cap_for(g);
-	const uint32_t part = (SVC_WS_WORDS + tile_mask_words(g.rw, g.rh, cap) + 2u * lc + W_WIN_STRIDE + 3u) & ~3u;
+uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes, uint32_t *compact) {
+	const uint32_t cap = lsd_tile_cap_of(g, tile_limit);
 	const uint32_t lds_cu = 160u * 1024u, beside = 2u * ((map_brq_lds_bytes(g) + 1023u) & ~1023u) + 1024u;
-	uint32_t w = SVC_MAX_WAVES;
-	while (w > 0u && lsd_service_static_lds() + w * part * 4u + beside > lds_cu) --w;
-	if (part_words) *part_words = part;
+	// The 16-bit tile table, a look-up per sample of a long ray, where SVC_MAX_WAVES waves fit with it (up to 1080p); above, the
+	// compact index (a tenth of the table's LDS at 1440p: 2.2 KB against 12.8) and half the list segment -- the scan goes on
+	// segment by segment -- where that buys another wave.
+	uint32_t best_w = 0, best_part = 0, best_lc = 0, best_c = 0;
+	for (uint32_t c = 0; c < 2u; ++c) {
+		const uint32_t lc = c ? W_LIST_CAP_MAX / 2u : tile_list_cap_for(g);
+		const uint32_t part = (SVC_WS_WORDS + (c ? tilec_mask_words(g.rw, g.rh, cap) : tile_mask_words(g.rw, g.rh, cap)) + 2u * lc + W_WIN_STRIDE + 3u) & ~3u;
+		uint32_t w = SVC_MAX_WAVES;
+		while (w > 0u && lsd_service_static_lds() + w * part * 4u + beside > lds_cu) --w;
+		if (w > best_w) { best_w = w; best_part = part; best_lc = lc; best_c = c; }
+	}
+	if (part_words) *part_words = best_part;
 	if (tile_cap) *tile_cap = cap;
-	if (list_cap) *list_cap = lc;
-	if (lds_bytes) *lds_bytes = w * part * 4u;
-	return w;
+	if (list_cap) *list_cap = best_lc;
+	if (lds_bytes) *lds_bytes = best_w * best_part * 4u;
+	if (compact) *compact = best_c;
+	return best_w;
 }
 
-uint32_t svc_store_words_for(const Geom &g, uint32_t tile_cap) { return (tile_mask_words(g.rw, g.rh, tile_cap) + 7u) & ~3u; }
+uint32_t svc_store_words_for(const Geom &g, uint32_t tile_cap, uint32_t compact) { return ((compact ? tilec_mask_words(g.rw, g.rh, tile_cap) : tile_mask_words(g.rw, g.rh, tile_cap)) + 7u) & ~3u; }
 
 // -> *ok: a device-side 64-bit system-scope compare-and-swap on the mapped host block `h` (device address d_h) took effect
 // and the host sees it (synchronous; pipeline creation)

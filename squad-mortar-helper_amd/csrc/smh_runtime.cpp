@@ -921,6 +921,7 @@ struct smhv_pipeline {
 	// stream[] then holds svc_streams streams that the submissions' streaming sides take in turn, s_search carries the
 	// service kernel (a stream with its own hardware queue: nothing else may queue behind a kernel that lives for seconds)
 	bool svc = false;
+	uint32_t svc_compact = 0;           // the service's tile stores use the compact index (svc_waves_for)
 	uint32_t svc_streams = 0, svc_waves = 0, svc_part_words = 0, svc_tile_cap = 0, svc_list_cap = 0, svc_lds = 0, svc_wgs = 0, svc_ring_log2 = 0;
 	SvcCtl *d_svc_ctl = nullptr;
 	unsigned long long *d_svc_ring = nullptr;
@@ -1060,7 +1061,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 	p->ctx = c; p->depth = depth; p->opt = opt;
 	// Frame-granular search (smh_kernels.h): depth >= 3 and a frame size whose tile store fits beside the streaming pass
 	if (opt.search != SMHV_SEARCH_BATCH && depth >= 3 && (opt.search == SMHV_SEARCH_FRAME || depth >= SMH_SVC_AUTO_DEPTH) && max_frames < (1u << 24)) {
-		p->svc_waves = svc_waves_for(g0, SMH_SVC_TILE_LIMIT(g0), &p->svc_part_words, &p->svc_tile_cap, &p->svc_list_cap, &p->svc_lds);
+		p->svc_waves = svc_waves_for(g0, SMH_SVC_TILE_LIMIT(g0), &p->svc_part_words, &p->svc_tile_cap, &p->svc_list_cap, &p->svc_lds, &p->svc_compact);
 		p->svc = p->svc_waves > 0u;
 	}
 	if (opt.search == SMHV_SEARCH_FRAME && !p->svc) {
@@ -1151,7 +1152,12 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		// launched once per submission beside a saturated 1080p pipeline: 224 of 256 workgroups -- every probe on the chip within
 		// 0.9 ms, the pipeline 0.3 % slower than without probes; 240 or 248 -- sometimes fine, sometimes seconds)
 		const int svc_cus = opt.room_for_others == 1u ? cus - std::max(cus / 8, 1) : cus;
-		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(p->svc_waves >= 4u ? svc_cus : std::min(cus * 5 / 8, svc_cus), 1);
+		// (above 1080p -- the frame sizes whose tile stores sit behind the compact index -- a service workgroup takes 130 KB of its CU's
+		// LDS whatever its waves: 128 x 1440p at depth 12, four waves per workgroup, 256 / 224 / 192 / 176 / 160 / 144 / 128 / 112
+		// workgroups: 212 / 225 / 245 / 255 / 263 / 271 / 267 / 243 k frames/s on the synthetic scene, 225 / 247 / 260 / 260 / 256 / 244 /
+		// 226 / 211 k on the reference's screenshots: five eighths of the CUs)
+		const bool every_cu = p->svc_waves >= 4u && !p->svc_compact;
+		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(every_cu ? svc_cus : std::min(cus * 5 / 8, svc_cus), 1);
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ctl, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMemset(p->d_svc_ctl, 0, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ring, sizeof(unsigned long long) << lg);
@@ -1161,7 +1167,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		if (!(opt.flags & (SMHV_PIPE_NO_REMOTE_HELP | SMHV_PIPE_NO_TEAM_HELP)) && (uint64_t)p->svc_wgs * p->svc_waves <= 0xFFFFu) {
 			// help across workgroups (smh_kernels.h): per wave of the launch an exchange block and room for its frame's tile store
 			const size_t owners = (size_t)p->svc_wgs * p->svc_waves;
-			p->svc_store_words = svc_store_words_for(g0, p->svc_tile_cap);
+			p->svc_store_words = svc_store_words_for(g0, p->svc_tile_cap, p->svc_compact);
 			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_remote, sizeof(SvcRemote) * owners);
 			if (e == hipSuccess) e = hipMemset(p->d_svc_remote, 0, sizeof(SvcRemote) * owners);
 			if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_store, sizeof(uint32_t) * owners * p->svc_store_words);
@@ -1226,6 +1232,7 @@ static int svc_launch(smhv_pipeline *p, uint32_t slot) {
 	sp.remote_after = p->opt.remote_after ? p->opt.remote_after : 24u;
 	sp.remote_tickets = std::min<uint32_t>(p->opt.remote_tickets ? p->opt.remote_tickets : 3u, 16u);
 	sp.remote_last_div = p->opt.remote_last ? p->opt.remote_last : 6u;
+	sp.compact = p->svc_compact;
 	__atomic_fetch_or(&p->h_svc->state, (unsigned long long)sp.epoch, __ATOMIC_ACQ_REL);   // (the low half is 0: only then is this called)
 	hipError_t e = hipStreamWaitEvent(p->s_search, p->ev_pub[slot], 0);
 	if (e == hipSuccess) e = launch_lsd_service(p->batch[slot]->g, sp, p->svc_wgs, p->svc_waves, p->svc_lds, p->s_search);

@@ -351,8 +351,9 @@ def test_sample_screenshots_through_the_search_service(vision):
 
 
 def test_search_service_1440p_geometry_with_frames_beyond_its_tile_store(vision):
-    """Above 1080p the service runs three waves per workgroup with a tile store of 272 tiles (smh_runtime.cpp,
-    SMH_SVC_TILE_LIMIT).  The reference's 1440p screenshots stay below that (<= 261 tiles); here they are run in a batch
+    """Above 1080p the service's waves keep their tile stores (272 tiles at most: smh_runtime.cpp, SMH_SVC_TILE_LIMIT) behind the
+    compact index (LSD_MODE_TILEC: an occupancy mask and a running count per tile row instead of a 16-bit table), which is what
+    lets four of them share a workgroup.  The reference's 1440p screenshots stay below that (<= 261 tiles); here they are run in a batch
     together with copies that carry a few hundred extra marker specks each -- more non-empty tiles than the store holds, so
     those frames take the service's scan on the mask in global memory while their neighbours take the tile store and ask
     for help.  Every record against the oracle, culled and exact."""
@@ -387,7 +388,7 @@ def test_search_service_1440p_geometry_with_frames_beyond_its_tile_store(vision)
     d = torch.from_numpy(frames).cuda()
     pipe = smh.Pipeline(vision, W, H, n, 12, search="frame")
     geo = pipe.peek()
-    assert geo["waves_per_workgroup"] == 3 and geo["service_workgroups"] < 256, geo
+    assert geo["waves_per_workgroup"] == 4 and geo["service_workgroups"] < 256, geo   # (the compact tile index: four waves of 24 KB instead of three of 36.6; on five eighths of the CUs)
     for exact, subs in ((0, 14), (smh.STAGE_EXACT_STATS, 3), (0, 3)):
         slots = [pipe.submit(d.data_ptr(), n, stages=smh.STAGE_MARKERS | exact, max_gap=15) for _ in range(subs)]
         pipe.wait()

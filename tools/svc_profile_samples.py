@@ -43,7 +43,11 @@ for i in first * k + np.argsort([-raw[first * k + j].rounds for j in range(k)]):
     P = np.array([r.meters[20 + j] for j in range(5)])
     print("%-24s rounds %3d lines %2d | scan %.3g cycles (%.2f ms at 2.4 GHz) = %5.0f per round | %s | units cast by the owner %4d, candidates from helpers %3d" % (
         stems[i % k][:24], r.rounds, r.n_lines, P.sum(), P.sum() / 2.4e6, P.sum() / max(r.rounds, 1), " ".join("%s %.0f%%" % (names[j], 100 * P[j] / max(P.sum(), 1)) for j in range(5)), r.meters[28], r.meters[29]), end="")
-    print(" | remote: arrivals %d taken back %d waited %d (%.0f k cycles) asked %d times, first at round %d" % (r.length_px[22], r.length_px[23], r.length_px[24], r.length_px[25] / 1e3, r.length_px[26], r.length_px[27]))
+    print(" | remote: arrivals %d taken back %d waited %d (%.0f k cycles) first asked at round %d" % (r.length_px[22], r.length_px[23], r.length_px[24], r.length_px[25] / 1e3, r.length_px[27]))
+    a = [r.angle[16 + j] for j in range(10)]
+    if a[8]:
+        print("      with the request open: %d rounds in %.2f M cycles (%.1f k per round); posts %d, cancelled free %d / taken %d, refreshes %d (%.0f k cycles), post_more %.0f k, take %.0f k, harvests %d"
+              % (a[8], a[9] / 1e6, a[9] / 1e3 / max(a[8], 1), a[0], a[1], a[2], a[3], a[5] / 1e3, a[6] / 1e3, a[7] / 1e3, a[4]))
 print("all frames of all slots: " + " ".join("%s %.0f%%" % (names[j], 100 * tot[j] / tot.sum()) for j in range(5)), "| cycles per frame %.3g" % (tot.sum() / (depth * n)))
 print(json.dumps(pipe.search_stats()))
 pipe.close()
