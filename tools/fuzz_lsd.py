@@ -26,7 +26,10 @@ def main():
     threads = min(os.cpu_count() or 1, n)
     bad = 0
     for it in range(iters):
-        W, H = [(1280, 1024), (1920, 1080), (1024, 768), (2560, 1440), (1600, 1024)][int(rng.integers(0, 5))]
+        sizes = [(1280, 1024), (1920, 1080), (1024, 768), (2560, 1440), (1600, 1024)]
+        if os.environ.get("FUZZ_SERVICE"):
+            sizes += [(2560, 1440), (3840, 2160)]               # (above 1080p the service's tile stores sit behind the compact index; 4K: two groups of tile columns per row)
+        W, H = sizes[int(rng.integers(0, len(sizes)))]
         max_gap = int(rng.choice([15, 15, 22, 9, 3, 30, 45, 49, 50, 1]))
         frames = np.stack([scene(rng, W, H, 1000 * it + i, max_gap) for i in range(n)])
         t0 = time.time()
