@@ -1227,7 +1227,7 @@ static int svc_launch(smhv_pipeline *p, uint32_t slot) {
 	sp.flags = (p->opt.flags & SMHV_PIPE_NO_TEAM_HELP) ? 8u : 0u;
 	sp.idle_long = 50000u;                                               // ~20 ms without work, nobody at work: the streaming side is stuck
 	if (p->opt.flags & SMHV_PIPE_HELP_FIRST) sp.flags |= 16u;
-	if (p->opt.flags & 32u) sp.flags |= 32u;
+
 	sp.remote = p->d_svc_remote; sp.remote_store = p->d_svc_store; sp.remote_store_words = p->svc_store_words;
 	sp.remote_after = p->opt.remote_after ? p->opt.remote_after : 24u;
 	sp.remote_tickets = std::min<uint32_t>(p->opt.remote_tickets ? p->opt.remote_tickets : 3u, 16u);

@@ -19,7 +19,7 @@ stages = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0xF
 W = int(sys.argv[5]) if len(sys.argv) > 5 else 1920
 H = int(sys.argv[6]) if len(sys.argv) > 6 else 1080
 K = min(N, int(os.environ.get("SVC_RATE_DISTINCT", "64")))
-frames, infos = synth.make_batch(W, H, K, first_idx=0)
+frames, infos = synth.make_batch(W, H, K, first_idx=0, n_lines=int(os.environ.get("RATE_LINES", "2")))
 frames = np.concatenate([frames] * ((N + K - 1) // K))[:N]
 infos = [infos[i % K] for i in range(N)]
 anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 8 else None
