@@ -1,11 +1,8 @@
 T=$1
-run() { n=$1; shift; env "$@" RATE_LINES=0 python tools/svc_rate.py 256 12 600 2>&1 | tail -1 > gpurun_out/${T}_$n.json; }
-run batch_auto RATE_SEARCH=batch
-run batch_policy_on RATE_SEARCH=batch RATE_POLICY=1
-run batch_policy_off RATE_SEARCH=batch RATE_POLICY=2
-run frame_wgs8 RATE_SEARCH=frame RATE_WGS=8
-run frame_wgs8_noprologue RATE_SEARCH=frame RATE_WGS=8 RATE_FLAGS=4
-run frame_wgs8_noprio RATE_SEARCH=frame RATE_WGS=8 RATE_FLAGS=2
-run frame_wgs8_streams1 RATE_SEARCH=frame RATE_WGS=8 RATE_STREAMS=1
-run frame_wgs8_streams8 RATE_SEARCH=frame RATE_WGS=8 RATE_STREAMS=8
-run frame_wgs32 RATE_SEARCH=frame RATE_WGS=32
+SAMPLES_STEPS=3000 SAMPLES_SEARCH=frame python tools/bench_samples.py 128 12 2>&1 | tail -1 > gpurun_out/${T}_smp_d12.json
+SAMPLES_STEPS=3000 SAMPLES_SEARCH=frame python tools/bench_samples.py 128 20 2>&1 | tail -1 > gpurun_out/${T}_smp_d20.json
+SAMPLES_STEPS=3000 SAMPLES_SEARCH=frame python tools/bench_samples.py 128 4 2>&1 | tail -1 > gpurun_out/${T}_smp_d4.json
+RATE_SEARCH=frame python tools/svc_rate.py 256 12 600 2>&1 | tail -1 > gpurun_out/${T}_syn.json
+RATE_SEARCH=frame python tools/svc_rate.py 128 12 600 15 2560 1440 2>&1 | tail -1 > gpurun_out/${T}_syn1440.json
+RATE_SEARCH=frame python tools/svc_rate.py 256 3 400 2>&1 | tail -1 > gpurun_out/${T}_syn_d3.json
+python -m pytest tests/test_gpu_configs.py -x -q -k "pipeline_object or adaptive or search_service" 2>&1 | grep -E "passed|failed|^E " | tail -3 > gpurun_out/${T}_tests.txt
