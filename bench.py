@@ -241,8 +241,9 @@ class DeviceWatch:
     process was given: all of them are sampled and the one that drew the most power in the region -- the one under load -- is
     reported.  A 513 k vs 551 k spread between boxes is attributable only with these beside the value."""
 
-    def __init__(self):
+    def __init__(self, pci=None):
         import glob
+        self.pci = pci.lower() if pci else None                 # "dddd:bb:dd" of the process's device (torch: pci_domain_id / pci_bus_id / pci_device_id)
         self.cards = []
         for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             try:
@@ -291,12 +292,16 @@ class DeviceWatch:
     def summary(self):
         best = None
         for name, _, samples in self.cards:
+            if self.pci and name.lower().startswith(self.pci):
+                best = (0.0, name, samples)
+                break
+        for name, _, samples in ([] if best else self.cards):
             load = samples.get("power_w") or samples.get("sclk_mhz") or []
             if load and (best is None or sum(load) / len(load) > best[0]):
                 best = (sum(load) / len(load), name, samples)
         if best is None:
             return None
-        out = {"card": best[1], "cards_sampled": len(self.cards)}
+        out = {"card": best[1], "cards_sampled": len(self.cards), "card_is": "the process's device (PCI address)" if self.pci and best[1].lower().startswith(self.pci) else "the card that drew the most power"}
         for k, v in best[2].items():
             if v:
                 out[k] = {"min": min(v), "max": max(v), "mean": sum(v) / len(v), "samples": len(v)}
@@ -853,7 +858,8 @@ def main():
         for b in pipe.slots:
             b.enable_timing(True)
     try:
-        watch = DeviceWatch()
+        pr = torch.cuda.get_device_properties(local_rank)
+        watch = DeviceWatch("%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id) if hasattr(pr, "pci_bus_id") else None)
     except Exception:  # noqa: BLE001  (diagnostic only)
         watch = None
     if watch is not None and watch.files:
