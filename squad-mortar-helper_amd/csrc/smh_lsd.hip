@@ -176,27 +176,23 @@ __device__ __forceinline__ uint32_t tilec_raw(const Win &m, float x, float y) {
 	const int xi = (int)x;
 	return tilec_word(m, xi >> 5, yi) >> ((uint32_t)xi & 31u);
 }
-// (eight samples of a ray, as tile_raw8 -- in two halves: four 16-byte index entries in flight at a time are what the register
-// budget of the service's wave has room for)
+// (eight samples of a ray, as tile_raw8: the eight index entries in one round trip, the eight tile words in a second)
 __device__ __forceinline__ void tilec_raw8(const Win &m, float xs, float ys, float dx, float dy, float &xo, float &yo, float &x, float &y, uint32_t &Wm) {
+	int yi[8], xi[8];
+	uint32_t t[8];
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		int yi[4], xi[4];
-		uint32_t t[4];
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			x = xo + xs; y = yo + ys;
-			yi[j] = (int)__builtin_amdgcn_fmed3f(y, -1.0f, m.hf);
-			xi[j] = (int)x;
-			xo += dx; yo += dy;
-		}
-#pragma unroll
-		for (int j = 0; j < 4; ++j) t[j] = tilec_number(m, xi[j] >> 5, yi[j] >> 3);
-#pragma unroll
-		for (int j = 0; j < 4; ++j) t[j] = m.t_tiles[(t[j] << 3) + ((uint32_t)yi[j] & 7u)];
-#pragma unroll
-		for (int j = 0; j < 4; ++j) Wm = __builtin_amdgcn_alignbit(t[j] >> ((uint32_t)xi[j] & 31u), Wm, 1);
+	for (int j = 0; j < 8; ++j) {
+		x = xo + xs; y = yo + ys;
+		yi[j] = (int)__builtin_amdgcn_fmed3f(y, -1.0f, m.hf);
+		xi[j] = (int)x;
+		xo += dx; yo += dy;
 	}
+#pragma unroll
+	for (int j = 0; j < 8; ++j) t[j] = tilec_number(m, xi[j] >> 5, yi[j] >> 3);
+#pragma unroll
+	for (int j = 0; j < 8; ++j) t[j] = m.t_tiles[(t[j] << 3) + ((uint32_t)yi[j] & 7u)];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) Wm = __builtin_amdgcn_alignbit(t[j] >> ((uint32_t)xi[j] & 31u), Wm, 1);
 }
 // LSD_MODE_TILE sample straight from the float position (bit 0 = the pixel): rows clamped onto the zero rows -1 and h in
 // the float domain; x needs no clamp (a batch never strays more than 33 px from the image: two padding columns)

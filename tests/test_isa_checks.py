@@ -39,7 +39,8 @@ def test_the_search_service_has_no_scratch_access_inside_a_loop():
     """tools/scratch_in_loops.py on the compiled search service (k_lsd_service and the two noinline bodies it calls, svc_frame and
     svc_help): spills are allowed in prologues / epilogues (loop depth 0) only.  A wave that shares its CU with the HBM-bound
     streaming pass waits microseconds for every vector-memory access; fifteen reloads in the candidate loop once made the scan
-    twice as slow.  Reading wider groups of window samples at once (SEQ_RAY_GROUP = 32) fails exactly this."""
+    twice as slow.  (Reading a whole 32-sample batch of window samples at once -- SEQ_RAY_GROUP = 32 -- failed exactly
+    this while the wave was held to 128 registers; with its budget at 168, round 5, it passes.)"""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "scratch_in_loops.py")], capture_output=True, text=True, timeout=900)
