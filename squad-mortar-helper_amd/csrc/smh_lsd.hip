@@ -1565,10 +1565,12 @@ hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgr
 	if (e != hipSuccess) return e;
 	if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
 		e = hipFuncSetAttribute((const void *)k_lsd_service, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)lsd_service_static_lds());
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lsd_service_c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)lsd_service_static_lds());
 		if (e != hipSuccess) return e;
 		if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
 	}
-	hipLaunchKernelGGL(k_lsd_service, dim3(workgroups), dim3(64u * waves), lds_bytes, s, g, p);
+	if (p.compact) hipLaunchKernelGGL(k_lsd_service_c, dim3(workgroups), dim3(64u * waves), lds_bytes, s, g, p);
+	else hipLaunchKernelGGL(k_lsd_service, dim3(workgroups), dim3(64u * waves), lds_bytes, s, g, p);
 	return hipGetLastError();
 }
 
