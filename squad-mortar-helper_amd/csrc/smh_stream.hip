@@ -524,6 +524,9 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	const bool do_ui = (flags & MAP_UI) != 0, do_mask = (flags & MAP_MASK) != 0;
 	const int base = r0 - 3;                                     // row of bit 0 of every column mask
 	const bool my_q = band_q && in_q;                            // this thread has quadrant pixels in this band
+	// (uniform per WAVE: at 1080p the first of a band's four waves has no quadrant column at all, and its share of the white /
+	// edge classification -- 70 instructions per row and quad in the lower half of the ROI -- would be thrown away)
+	const bool wave_q = band_q && __any(in_q);
 
 	// ---- the OCR neighbourhood reaches 3 rows up and 2 down: the four rows beyond the loop's halo contribute their "white"
 	// bits only, and only the threads of the quadrant's columns look at them
@@ -558,7 +561,7 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 			const uint32_t pv[4] = {px[k].x, px[k].y, px[k].z, px[k].w};
 			const bool out_row = row >= r0 && row < r1;
 			const int qrow = row - qy0;                              // quadrant row
-			const bool q_row = band_q && qrow >= 0 && qrow < (int)g.qh;   // uniform
+			const bool q_row = wave_q && qrow >= 0 && qrow < (int)g.qh;   // uniform
 			uint32_t wnib = 0, enib = 0;                             // white / edge pixels of this row (quadrant rows only)
 			if (q_row) {
 #pragma unroll
@@ -610,7 +613,7 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 				prehits |= (pre & vmask) << (4 * k);
 			}
 		}
-		if (band_q && __any((wrows | erows) != 0u)) {                // the group's four rows into the column masks
+		if (wave_q && __any((wrows | erows) != 0u)) {                // the group's four rows into the column masks
 			const int sh = r - base;
 #pragma unroll
 			for (int c = 0; c < 4; ++c) { or_w(c, (uint64_t)rows_of_col(wrows, c) << sh); or_e(c, (uint64_t)rows_of_col(erows, c) << sh); }
@@ -731,7 +734,19 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 #pragma unroll
 		for (int c = 0; c < 4; ++c) D[c] = ((vmask >> c) & 1u) ? (D[c] & rowmask) : 0ull;
 		const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
-		if (q < quads_padded) {
+		const uint64_t any = D[0] | D[1] | D[2] | D[3];
+		const uint64_t lanes_set = __ballot(any != 0ull);
+		if (q < quads_padded && !lanes_set) {
+			// no marker pixel in this wave's 256 columns of the band (most of a map): rows of zeros, nothing to extract or gather
+			uint8_t *mbase = b.mask + (size_t)f * g.mask_stride;
+			uint32_t *bbase = b.bits + (size_t)f * g.bits_stride_w;
+			const uint32_t moff = q * 4u, boff = (q >> 3) * 4u;
+			const bool bit_lane = (lane & 7u) == 0;
+			for (int row = r0; row < r1; ++row) {
+				*(uint32_t *)(mbase + (size_t)row * g.mask_pitch + moff) = 0u;
+				if (bit_lane) *(uint32_t *)((uint8_t *)bbase + (size_t)row * g.bits_pitch_w * 4u + boff) = 0u;
+			}
+		} else if (q < quads_padded) {
 			// u8 mask rows and bit-packed rows.  The column masks are walked one 32-row half at a time (32-bit bit-field
 			// extracts on a uniform bit index); eight lanes' nibbles meet in one dword through three DPP row shifts
 			// (lane l supplies bits 4 (l % 8) ..): no LDS round trip, nothing to wait for.
@@ -755,8 +770,6 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 				}
 			}
 		}
-		const uint64_t any = D[0] | D[1] | D[2] | D[3];
-		const uint64_t lanes_set = __ballot(any != 0ull);
 		if (lanes_set) {
 			const uint64_t rows_set = wave_or64(any);
 			const uint32_t cnt = wave_sum32(__popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]));
@@ -770,7 +783,7 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 			}
 		}
 	}
-	if (!(band_q && do_ocr)) return;
+	if (!(wave_q && do_ocr)) return;
 	// ---- ocr_preprocess: edge pixels with a white pixel in their 7x7 neighbourhood (see k_brq_pass) ----
 	uint64_t X[12];   // columns -4..7 relative to this quad
 #pragma unroll
