@@ -104,7 +104,8 @@ def parse_args():
     ap.add_argument("--force-device", type=int, default=None, help="testing only: put every rank on this device")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="testing only (no GPU needed): the ranks meet, reduce one number over the process group, rank 0 prints a JSON line")
-    ap.add_argument("--ingest-frames", type=int, default=2048,
+    ap.add_argument("--ingest-affinity", default="on", choices=("on", "off"), help="A/B: the ingest queue's hashing threads and the producer on the CPUs next to the GPU (on) or left to the scheduler")
+    ap.add_argument("--ingest-frames", type=int, default=8192,
                     help="frames streamed through the ingest queue for the PCIe-inclusive figure (0 = skip; rank 0, N=1, config 2 only)")
     return ap.parse_args()
 
@@ -442,7 +443,16 @@ def real_samples_leg(smh, torch, vision, depth, batch=128, steps=200):
             "records_equal_oracle": bool(ok), "note": "outside the timed region of `value`; the headline stays the synthetic configs[2] scene"}
 
 
-def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, H, n):
+def cpu_throttled():
+    """(periods, microseconds) this container's cgroup has been throttled by its CPU quota so far (cgroup v2 cpu.stat; (0, 0) when unknown)."""
+    try:
+        kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return 0, 0
+
+
+def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, H, n, affinity=True):
     """PCIe-inclusive rate (never `value`): frames travel pinned host memory -> HBM through the ingest queue and every full
     slab goes through the same pipeline; two queues alternate so the uploads of one slab overlap the compute of the other.
     The staging buffers are filled once; each frame then gets a fresh counter in pixel (0,0) (outside every ROI) so that no
@@ -450,7 +460,7 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     slot; only the map ROI's and the button's rows cross PCIe); `full_upload_frames_per_s`: the whole frame crosses and the
     device computes the CRC (the mode a device-side producer or a decoded RGB image uses), on a quarter of the frames."""
     def run(roi, slots, total):
-        qs = [smh.IngestQueue(vision, W, H, slots=slots, capacity=n, roi_upload=roi) for _ in range(2)]
+        qs = [smh.IngestQueue(vision, W, H, slots=slots, capacity=n, roi_upload=roi, affinity=affinity) for _ in range(2)]
         for q in qs:                                           # prime the staging buffers (their content persists)
             for i in range(slots):
                 q.acquire()[...] = src[i % len(src)]
@@ -460,9 +470,14 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
         slabs = max(2, (total + n - 1) // n)
         counter = 1
         pending = [None, None]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for b in range(slabs):
+        if affinity:
+            qs[0].bind_thread()                                # the producer fills staging buffers that are pinned next to the GPU: run on that socket
+        t0 = None
+        for b in range(-2, slabs):                             # (two untimed slabs first: the pipeline behind the queues starts from idle)
+            if b == 0:
+                pipe.wait()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
             q = qs[b % 2]
             if pending[b % 2] is not None:
                 pipe.wait(pending[b % 2])                      # the previous run on this queue's slab has finished
@@ -481,7 +496,11 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
 
     cores = os.cpu_count() or 8
     slots = max(4, min(32, cores // 4))
+    affinity_before = os.sched_getaffinity(0)
+    thr0 = cpu_throttled()
     qs, frames, dt = run(True, slots, frames_total)
+    thr1 = cpu_throttled()
+    local_cpus = qs[0].local_cpus()
     q = qs[0]
     q.reset()
     k = min(64, n)
@@ -499,6 +518,7 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     qs, frames_full, dt_full = run(False, 4, max(2 * n, frames_total // 4))
     for q in qs:
         q.close()
+    os.sched_setaffinity(0, affinity_before)                   # (the other legs run where they ran before)
     (_, _, rw, rh), (_, _, bw, bh) = smh.map_bounds(W, H), smh.button_bounds(W, H)
     # the host CRC alone, one thread, on frames that do not fit the cache together (what a worker does between memcpys)
     import ctypes as C
@@ -517,6 +537,8 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
             "h2d_GBps": frames * (rw * rh + bw * bh) * 4 / dt / 1e9,
             "full_upload_frames_per_s": frames_full / dt_full, "full_upload_h2d_GBps": frames_full * W * H * 4 / dt_full / 1e9,
             "push_frames_per_s": k / dt_push, "duplicates_dropped": dup,
+            "cpu_quota_throttling_during_the_timed_loop": {"periods": thr1[0] - thr0[0], "ms": (thr1[1] - thr0[1]) / 1e3},
+            "producer_and_workers_on": ("the %d CPUs next to the GPU (smhv_ingest_local_cpus)" % len(local_cpus)) if (local_cpus and affinity) else "any CPU (one NUMA node, sysfs does not say, or --ingest-affinity off)",
             "note": "PCIe-inclusive: pinned staging -> whole-frame CRC-32 on the host workers (dedupe rule of src/capture.rs:44-47) -> "
                     "packed ROI + button rows -> async H2D -> slab -> same pipeline, two slabs in flight; full_upload: whole frame H2D + "
                     "device CRC-32; push_frames_per_s adds the host memcpy from pageable memory (one thread)"}
@@ -1130,7 +1152,7 @@ def main():
                       "time_share": stages_ms["lsd"] / max(sum(stages_ms.values()), 1e-9)}
 
     if args.ingest_frames > 0 and world == 1 and args.config == 2 and not custom:
-        out["ingest"] = ingest_leg(smh, torch, vision, pipe, frames_host, anchors, stages, args.ingest_frames, W, H, n)
+        out["ingest"] = ingest_leg(smh, torch, vision, pipe, frames_host, anchors, stages, args.ingest_frames, W, H, n, affinity=args.ingest_affinity == "on")
     pipe.close()                                           # (its streams hold hardware queues the next leg's pipelines should get)
     if world == 1 and args.config == 2 and not custom and len(frames_host):
         out["trait_path"] = trait_path_leg(smh, vision, frames_host[0], infos[0]["anchors"])

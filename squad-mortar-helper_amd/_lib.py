@@ -126,6 +126,8 @@ SIGNATURES = {
     "smhv_crc32_host": (C.c_uint32, [C.c_void_p, C.c_uint64]),
     "smhv_debug_crc32_host_level": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]),
     "smhv_ingest_destroy": (None, [C.c_void_p]),
+    "smhv_ingest_local_cpus": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "smhv_ingest_bind_thread": (C.c_int, [C.c_void_p]),
     "smhv_ingest_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smhv_ingest_commit": (C.c_int, [C.c_void_p]),
     "smhv_ingest_push": (C.c_int, [C.c_void_p, C.c_void_p]),

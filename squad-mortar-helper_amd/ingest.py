@@ -32,16 +32,17 @@ PIXEL_LAYOUTS = {"bgra": (0, 4), "rgba": (1, 4), "rgb": (2, 3), "l": (3, 1), "la
 class IngestQueue:
     """`slots` pinned staging buffers + one device slab of `capacity` frames of w x h BGRA."""
 
-    def __init__(self, vision, w, h, slots=4, capacity=256, roi_upload=False, workers=0):
+    def __init__(self, vision, w, h, slots=4, capacity=256, roi_upload=False, workers=0, affinity=True):
         """roi_upload: hash on the host, upload only the map ROI's and the button's rows (SMHV_INGEST_ROI_UPLOAD); workers: hashing
-        threads (diagnostic; 0 = the library's choice)."""
+        threads (diagnostic; 0 = the library's choice); affinity: on a multi-socket host the hashing threads run on the CPUs next
+        to the GPU (False: SMHV_INGEST_NO_AFFINITY)."""
         self._lib = _lib.load()
         self._q = C.c_void_p()
         self.w, self.h, self.capacity = int(w), int(h), int(capacity)
         self.frame_bytes = self.w * self.h * 4
         self._vision = vision                                   # keeps the context alive
         self._views = {}
-        check(self._lib.smhv_ingest_create_ex(vision._ctx, self.w, self.h, int(slots), self.capacity, (1 if roi_upload else 0) | ((int(workers) & 0xFF) << 8), C.byref(self._q)))
+        check(self._lib.smhv_ingest_create_ex(vision._ctx, self.w, self.h, int(slots), self.capacity, (1 if roi_upload else 0) | (0 if affinity else 2) | ((int(workers) & 0xFF) << 8), C.byref(self._q)))
 
     def close(self):
         if self._q:
@@ -53,6 +54,23 @@ class IngestQueue:
             self.close()
         except Exception:
             pass
+
+    def local_cpus(self):
+        """The CPUs next to the queue's GPU (smhv_ingest_local_cpus) as a set; empty on a single-node host."""
+        buf = C.create_string_buffer(4096)
+        check(self._lib.smhv_ingest_local_cpus(self._q, buf, len(buf)))
+        out = set()
+        for part in buf.value.decode().split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                out |= set(range(int(a), int(b) + 1))
+            elif part.strip():
+                out.add(int(part))
+        return out
+
+    def bind_thread(self):
+        """Bind the CALLING thread -- the one that fills the staging buffers -- to those CPUs (smhv_ingest_bind_thread)."""
+        check(self._lib.smhv_ingest_bind_thread(self._q))
 
     def acquire(self):
         """Next pinned staging buffer as an (h, w, 4) uint8 array to capture into; then commit()."""

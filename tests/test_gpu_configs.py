@@ -972,6 +972,47 @@ def test_lsd_helpers_do_not_change_any_record(vision):
         fb.close()
 
 
+def test_ingest_queue_places_its_threads_next_to_the_gpu(vision):
+    """On a multi-socket host the queue reports the CPUs of the GPU's NUMA node (sysfs), runs its hashing threads there,
+    binds a producer thread to them on request, and accepts the same frames with and without the placement."""
+    import os
+    import threading
+    import zlib
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H = 1024, 768
+    fr = [synth.make_frame(W, H, 950 + i, n_lines=1)[0] for i in range(5)]
+    p = torch.cuda.get_device_properties(0)
+    sysfs = "/sys/bus/pci/devices/%04x:%02x:%02x.0/" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    expect = set()
+    try:
+        if int(open(sysfs + "numa_node").read()) >= 0 and (os.path.exists("/sys/devices/system/node/node1") or int(open(sysfs + "numa_node").read()) > 0):
+            for part in open(sysfs + "local_cpulist").read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                expect |= set(range(int(lo), int(hi or lo) + 1))
+    except OSError:
+        pass
+    crcs = []
+    for affinity in (True, False):
+        q = smh.IngestQueue(vision, W, H, slots=4, capacity=8, roi_upload=True, affinity=affinity)
+        assert q.local_cpus() == expect
+        seen = {}
+        def producer():
+            q.bind_thread()
+            seen["cpus"] = os.sched_getaffinity(0)
+            for f in fr:
+                q.push(f)
+        t = threading.Thread(target=producer)                      # (a thread of its own: the test process keeps its affinity)
+        t.start(); t.join()
+        assert (seen["cpus"] and seen["cpus"] <= expect) if expect else seen["cpus"] == os.sched_getaffinity(0)
+        ptr, n, crc = q.batch()
+        assert n == len(fr) and crc == zlib.crc32(fr[-1].tobytes())
+        crcs.append(crc)
+        q.close()
+    assert crcs[0] == crcs[1]
+
+
 # ---------------------------------------------------------------------------------------------------
 # robustness of the boundary (round-1 advisor findings)
 # ---------------------------------------------------------------------------------------------------

@@ -101,7 +101,7 @@ def test_pipeline_options_and_flags_match_the_header(built):
     assert (int(defs["SMHV_PIPE_NO_TEAM_HELP"]), int(defs["SMHV_PIPE_NO_STREAM_PRIORITY"]), int(defs["SMHV_PIPE_NO_PROLOGUE"])) == \
         (_lib.PIPE_NO_TEAM_HELP, _lib.PIPE_NO_STREAM_PRIORITY, _lib.PIPE_NO_PROLOGUE)
     assert (int(defs["SMHV_PIPE_NO_REMOTE_HELP"]), int(defs["SMHV_PIPE_HELP_FIRST"])) == (_lib.PIPE_NO_REMOTE_HELP, _lib.PIPE_HELP_FIRST)
-    assert int(defs["SMHV_INGEST_ROI_UPLOAD"]) == 1 and sorted(k for k in defs if k.startswith("SMHV_PIPE_")) == \
+    assert int(defs["SMHV_INGEST_ROI_UPLOAD"]) == 1 and int(defs["SMHV_INGEST_NO_AFFINITY"]) == 2 and sorted(k for k in defs if k.startswith("SMHV_PIPE_")) == \
         ["SMHV_PIPE_HELP_FIRST", "SMHV_PIPE_NO_PROLOGUE", "SMHV_PIPE_NO_REMOTE_HELP", "SMHV_PIPE_NO_STREAM_PRIORITY", "SMHV_PIPE_NO_TEAM_HELP"]
     src = os.path.join(os.environ.get("TMPDIR", "/tmp"), "smhv_opt_size.c")
     exe = src[:-2]
