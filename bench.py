@@ -93,6 +93,7 @@ def parse_args():
     ap.add_argument("--side-probe", type=int, default=32,
                     help="workgroups of the co-residency probe (a kernel with RCCL's footprint: 21 KB LDS, 280 VGPRs) launched once per pass beside "
                          "a pipeline with room_for_others, after the timed region (N=1, config 2; 0 = skip): `co_residency` in the JSON line")
+    ap.add_argument("--gather-probe", action="store_true", help="N = 1: also run the co-residency leg with RCCL itself (a communicator of one rank, one all_gather per pass on a side stream; RCCL prints its banner to stdout in front of the JSON line)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-real-samples", action="store_true", help="skip the leg on the reference's own 1440p screenshots (real_samples)")
@@ -309,7 +310,7 @@ class DeviceWatch:
         return out
 
 
-def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, probe_wgs, passes=300):
+def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, probe_wgs, passes=300, rccl_probe=False):
     """Can a kernel of ANOTHER owner run beside the pipeline (never `value`)?  A pipeline created with room_for_others (what every
     N > 1 run uses: its gather is an RCCL kernel) is saturated; once per pass a probe kernel with RCCL's footprint on gfx950 (21 KB
     of LDS, 280 VGPRs per 256-thread workgroup; smhv_debug_side_kernel) goes onto a stream of its own.  -> the pipeline's rate
@@ -347,10 +348,49 @@ def co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, 
         by_size[str(wg)] = {"frames_per_s_without_probe": base, "frames_per_s_with_probe": r1, "cost": 1.0 - r1 / base,
                             "probe_ms": {"median": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())}}
         r0 = r2
+    rccl = None
+    if rccl_probe:
+        # --gather-probe: the same with RCCL itself -- a communicator of one rank, one all_gather of a batch's records per pass on
+        # the side stream.  (With one rank RCCL has nobody to talk to: whether it still launches its kernel or copies is its
+        # business; the probe kernel above has the footprint of the kernels it launches between ranks.)
+        import socket
+        import torch.distributed as dist
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+        try:
+            rec = torch.zeros(n * 1024, dtype=torch.uint8, device="cuda")     # (a batch's records: n x sizeof(smhv_frame_result) is of this order)
+            out_t = torch.empty_like(rec)
+
+            def run_rccl():
+                for _ in range(2 * depth):
+                    pipe.submit(fptr, n, stages=stages, anchors=anchors)
+                pipe.wait()
+                evs = []
+                t0 = time.perf_counter()
+                for _ in range(passes):
+                    pipe.submit(fptr, n, stages=stages, anchors=anchors)
+                    with torch.cuda.stream(side):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(side)
+                        dist.all_gather_into_tensor(out_t, rec)
+                        e1.record(side)
+                        evs.append((e0, e1))
+                pipe.wait()
+                dt = time.perf_counter() - t0
+                side.synchronize()
+                return n * passes / dt, np.array([a_.elapsed_time(b_) for a_, b_ in evs])
+            run_rccl()
+            r1, lat = run_rccl()
+            r2, _ = run(False)
+            rccl = {"frames_per_s_with_all_gather": r1, "frames_per_s_without": r2, "cost": 1.0 - r1 / r2,
+                    "all_gather_ms": {"median": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
+                    "what": "torch.distributed (backend nccl = RCCL), world size 1: one all_gather_into_tensor of %d bytes per pass on a side stream" % rec.numel()}
+        finally:
+            dist.destroy_process_group()
     geo = pipe.peek()
     pipe.close()
     first = by_size[str(min(int(k) for k in by_size))]
-    return {"frames_per_s_without_probe": first["frames_per_s_without_probe"], "frames_per_s_with_probe": first["frames_per_s_with_probe"], "cost": first["cost"],
+    return {"rccl_world_of_one": rccl, "frames_per_s_without_probe": first["frames_per_s_without_probe"], "frames_per_s_with_probe": first["frames_per_s_with_probe"], "cost": first["cost"],
             "probe_ms": first["probe_ms"], "by_probe_workgroups": by_size,
             "probe": "8 (headline figures) and %d workgroups x 256 threads, 21 KB LDS, 280 VGPRs (RCCL's kernels on gfx950: 19.7-21.2 KB, 261-280), one launch per pass on its own stream" % probe_wgs,
             "service_workgroups": geo["service_workgroups"], "waves_per_workgroup": geo["waves_per_workgroup"], "pipeline_depth": depth, "passes": passes,
@@ -1157,7 +1197,7 @@ def main():
     if world == 1 and args.config == 2 and not custom and len(frames_host):
         out["trait_path"] = trait_path_leg(smh, vision, frames_host[0], infos[0]["anchors"])
     if args.side_probe > 0 and world == 1 and args.config == 2 and not custom and depth >= 3:
-        out["co_residency"] = co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, args.side_probe)
+        out["co_residency"] = co_residency_leg(smh, torch, vision, W, H, n, depth, fptr, anchors, stages, args.side_probe, rccl_probe=args.gather_probe)
     if not args.no_real_samples and world == 1 and args.config == 2 and not custom:
         out["real_samples"] = real_samples_leg(smh, torch, vision, depth)
 
