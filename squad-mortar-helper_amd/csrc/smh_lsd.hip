@@ -1504,8 +1504,8 @@ static uint32_t lsd_service_static_lds() {
 	return v;
 }
 // Waves per service workgroup (one workgroup per CU) for this frame size: as many as fit beside two workgroups of the
-// streaming pass, at most SVC_MAX_WAVES -- one per SIMD, which leaves three 128-register wave slots per SIMD to the streaming
-// pass.  0: not even one wave fits (8K frames: the tile index alone is 106 KB) -> the pipeline keeps its batch-granular search.
+// streaming pass, at most SVC_MAX_WAVES -- one per SIMD, which leaves two 128-register wave slots per SIMD to the streaming
+// pass (a service wave allocates 136-144 registers).  0: not even one wave fits (8K frames: the tile index alone is 106 KB) -> the pipeline keeps its batch-granular search.
 uint32_t svc_waves_for(const Geom &g, uint32_t tile_limit, uint32_t *part_words, uint32_t *tile_cap, uint32_t *list_cap, uint32_t *lds_bytes, uint32_t *compact) {
 	const uint32_t cap = lsd_tile_cap_of(g, tile_limit);
 	const uint32_t lds_cu = 160u * 1024u, beside = 2u * ((map_brq_lds_bytes(g) + 1023u) & ~1023u) + 1024u;

@@ -1185,8 +1185,9 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
 		if (p->svc && !p->adaptive) {
-			// no occupancy policy: the service's resident waves (one per SIMD, most of a CU's LDS) are what caps the streaming
-			// pass at three workgroups per CU; the streaming waves go first on their SIMD
+			// no occupancy policy: the service's resident waves (one per SIMD, 136-144 registers each) are what caps the streaming
+			// pass at two workgroups per CU (three with the service at exactly 128 registers: measured, no difference --
+			// DESIGN.md A.-1); the streaming waves go first on their SIMD
 			p->batch[i]->tune.map_prio = (opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u;
 		} else if (depth >= 3) {                                  // (an adaptive pipeline sets the tuning of a slot per submission)
 			if (opt.occupancy_policy != 2u) p->tuning = pipeline_tuning(p->batch[i]->g);
