@@ -290,6 +290,7 @@ struct LaunchTuning {
 	uint32_t lsd_tile_limit;  // k_lsd_tile keeps at most this many mask tiles in LDS (0: what fits the kernel's own budget)
 	uint32_t map_prio;        // != 0: the streaming waves run at wave priority 3 -- ahead of the search service's waves on their SIMD,
 	                          // which have slack (measured: 470 k -> 516 k frames/s at depth 12; beside the batch-granular search it cost 1-8 %)
+	uint32_t map_deep;        // != 0: three register sets of loads in flight per wave instead of two (launch_map_brq_pass)
 };
 // LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
 uint32_t map_brq_lds_bytes(const Geom &g);

@@ -459,7 +459,7 @@ typedef const __attribute__((address_space(4))) MapKernelArgs *MapKernelArgsPtr;
 #else
 typedef const MapKernelArgs *MapKernelArgsPtr;                                     // (host pass: the body is only parsed)
 #endif
-template <bool GRAY>
+template <bool GRAY, int SETS>
 __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f, uint32_t band0) {
 	constexpr int GR = 4;                                       // rows per group (the hand-placed waits count four loads per set)
 	const Geom g = ka->g;
@@ -684,26 +684,45 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 				SMH_LD128(dst[k], inside ? loff : 0u, rowp);
 			}
 		};
-		u32x4 S0[GR], S1[GR], S2[GR];
-		load4(S0, rs);
-		load4(S1, rs + 4);
-		for (int r = rs; ; r += 12) {
-			load4(S2, r + 8);
-			SMH_WAIT_SET(8, S0);
-			group(S0, r);
-			if (r + 4 > re) break;
-			load4(S0, r + 12);
-			SMH_WAIT_SET(8, S1);
-			group(S1, r + 4);
-			if (r + 8 > re) break;
-			load4(S1, r + 16);
-			SMH_WAIT_SET(8, S2);
-			group(S2, r + 8);
-			if (r + 12 > re) break;
+		if constexpr (SETS == 2) {
+			// two register sets, prefetch distance one group (4 KB per wave in flight while a group is processed): what frames above
+			// 1080p run -- one box, three interleaved rounds, 128 x 1440p at depth 12: 289 k frames/s against 279 k with three
+			// sets; 256 x 1080p: 538 against 560 k (DESIGN.md A.-1).  "At most the four younger loads outstanding" releases a set.
+			u32x4 S0[GR], S1[GR];
+			load4(S0, rs);
+			for (int r = rs; ; r += 8) {
+				load4(S1, r + 4);
+				SMH_WAIT_SET(4, S0);
+				group(S0, r);
+				if (r + 4 > re) break;
+				load4(S0, r + 8);
+				SMH_WAIT_SET(4, S1);
+				group(S1, r + 4);
+				if (r + 8 > re) break;
+			}
+			asm volatile("s_waitcnt vmcnt(0) ; smh-drain" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(S1[0]), "+v"(S1[1]), "+v"(S1[2]), "+v"(S1[3]) : : "memory");
+		} else {
+			u32x4 S0[GR], S1[GR], S2[GR];
+			load4(S0, rs);
+			load4(S1, rs + 4);
+			for (int r = rs; ; r += 12) {
+				load4(S2, r + 8);
+				SMH_WAIT_SET(8, S0);
+				group(S0, r);
+				if (r + 4 > re) break;
+				load4(S0, r + 12);
+				SMH_WAIT_SET(8, S1);
+				group(S1, r + 4);
+				if (r + 8 > re) break;
+				load4(S1, r + 16);
+				SMH_WAIT_SET(8, S2);
+				group(S2, r + 8);
+				if (r + 12 > re) break;
+			}
+			// the clamped loads of the sets nobody consumed are still in flight: their registers must not be reused before they land
+			asm volatile("s_waitcnt vmcnt(0) ; smh-drain" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(S1[0]), "+v"(S1[1]), "+v"(S1[2]), "+v"(S1[3]),
+			             "+v"(S2[0]), "+v"(S2[1]), "+v"(S2[2]), "+v"(S2[3]) : : "memory");
 		}
-		// the clamped loads of the sets nobody consumed are still in flight: their registers must not be reused before they land
-		asm volatile("s_waitcnt vmcnt(0) ; smh-drain" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S0[2]), "+v"(S0[3]), "+v"(S1[0]), "+v"(S1[1]), "+v"(S1[2]), "+v"(S1[3]),
-		             "+v"(S2[0]), "+v"(S2[1]), "+v"(S2[2]), "+v"(S2[3]) : : "memory");
 	}
 
 	// ---- lane / wave neighbours of the column masks: marker dilation (P) and the 7-row-dilated white masks (V) ----
@@ -817,7 +836,7 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 // state costs the kernel 76 bytes of scratch per lane (spilled in the prologue / epilogue of an item, never in the streaming
 // loop: tools/check_untracked_loads.py); a launch with one workgroup per item (a batch that runs alone) takes the variant
 // without the loop and without the spills.
-template <bool GRAY, bool LOOP>
+template <bool GRAY, bool LOOP, int SETS>
 __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start,
                                                        uint32_t nbands, uint32_t items) {
 #ifdef SMH_MAP_FAT
@@ -829,11 +848,11 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	if (LOOP) {
 		for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
 			const uint32_t f = item / nbands, band = item - f * nbands;
-			map_brq_item<GRAY>(ka, f, band);
+			map_brq_item<GRAY, SETS>(ka, f, band);
 			__syncthreads();                                   // the next item reuses the LDS exchange arrays
 		}
 	} else {
-		map_brq_item<GRAY>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
+		map_brq_item<GRAY, SETS>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
 	}
 }
 
@@ -857,7 +876,7 @@ hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t
 }
 
 static uint32_t map_brq_static_lds() {
-	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_map_brq_pass<true, true>) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 2048u; }();
+	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_map_brq_pass<true, true, 2>) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 2048u; }();
 	return v;
 }
 uint32_t map_brq_lds_bytes(const Geom &g) { return map_brq_static_lds() + (g.m_block / 64u) * 640u; }
@@ -875,7 +894,8 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess) return e;
 		if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
-			const void *fns[] = {(const void *)k_map_brq_pass<true, true>, (const void *)k_map_brq_pass<false, true>, (const void *)k_map_brq_pass<true, false>, (const void *)k_map_brq_pass<false, false>};
+			const void *fns[] = {(const void *)k_map_brq_pass<true, true, 2>, (const void *)k_map_brq_pass<false, true, 2>, (const void *)k_map_brq_pass<true, false, 2>, (const void *)k_map_brq_pass<false, false, 2>,
+			                     (const void *)k_map_brq_pass<true, false, 3>, (const void *)k_map_brq_pass<false, false, 3>};
 			for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 			if (e != hipSuccess) return e;
 			if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
@@ -883,13 +903,22 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 	}
 	if (tune && tune->map_prio) flags |= MAP_PRIO;
 	const uint32_t cap = tune ? tune->map_grid_cap : 0u;
+	// Loads in flight per wave: two register sets of four rows (one group ahead), or three (two groups ahead) where the launch
+	// says so -- the frame-granular pipeline up to 1080p, whose service workgroup on every CU leaves the pass two workgroups
+	// per CU.  Measured on one box, two sets / three sets: that pipeline 538 / 560 k frames/s; everything else is faster with
+	// two -- 128 x 1440p frame-granular 289 / 279 k, batch-granular 260 / 251 k, 256 x 1080p batch-granular at depth 4 458 / 445 k,
+	// 4K 128 / 126 k, the reference's screenshots 308 / 302 k; a launch alone takes the same time (DESIGN.md A.-1).
+	const bool deep = tune && tune->map_deep && !(cap && cap < items);
+#define SMH_LAUNCH_MAPQ(GRAYV, LOOPV, SETSV, GRID) \
+	hipLaunchKernelGGL((k_map_brq_pass<GRAYV, LOOPV, SETSV>), GRID, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items)
 	if (cap && cap < items) {
-		if (grayscale) hipLaunchKernelGGL((k_map_brq_pass<true, true>), dim3(cap), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
-		else hipLaunchKernelGGL((k_map_brq_pass<false, true>), dim3(cap), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+		if (grayscale) SMH_LAUNCH_MAPQ(true, true, 2, dim3(cap)); else SMH_LAUNCH_MAPQ(false, true, 2, dim3(cap));
+	} else if (deep) {
+		if (grayscale) SMH_LAUNCH_MAPQ(true, false, 3, dim3(nbands, n)); else SMH_LAUNCH_MAPQ(false, false, 3, dim3(nbands, n));
 	} else {
-		if (grayscale) hipLaunchKernelGGL((k_map_brq_pass<true, false>), dim3(nbands, n), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
-		else hipLaunchKernelGGL((k_map_brq_pass<false, false>), dim3(nbands, n), dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items);
+		if (grayscale) SMH_LAUNCH_MAPQ(true, false, 2, dim3(nbands, n)); else SMH_LAUNCH_MAPQ(false, false, 2, dim3(nbands, n));
 	}
+#undef SMH_LAUNCH_MAPQ
 	return hipGetLastError();
 }
 
