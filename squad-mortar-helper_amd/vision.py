@@ -302,6 +302,7 @@ class VisionState:
                         if job is None:
                             return
                         job()
+                        job = None                              # (the closure holds the VisionState: a worker that kept it while it waits would keep the state -- and itself -- alive for ever)
                         q_out.put(True)
                 t = threading.Thread(target=loop, daemon=True)
                 t.start()

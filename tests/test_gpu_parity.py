@@ -967,3 +967,26 @@ def test_load_frame_view_is_load_frame_of_the_repacked_rectangle(vision):
     import squad_mortar_helper_amd as smh
     with pytest.raises(smh.VisionError):
         vision.load_frame_view(parent, W, 0, 100, 100)
+
+
+def test_vision_state_gives_its_branch_threads_back(vision):
+    """A VisionState that goes out of scope takes its two branch threads with it (they must not hold on to the state through
+    the last job they ran)."""
+    import gc
+    import os
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    frame, info = synth.make_frame(1280, 1024, 5, n_lines=1)
+
+    def threads():
+        return len(os.listdir("/proc/self/task"))
+    st = smh.VisionState()
+    st.process(vision, frame, ocr_labels=info["anchors"])
+    base = threads() - 2                                         # (the first state's two workers are alive now)
+    for _ in range(4):
+        st = smh.VisionState()                                     # the previous one is dropped here
+        st.process(vision, frame, ocr_labels=info["anchors"])
+        gc.collect()
+    assert threads() <= base + 2, (threads(), base)
+    st.close()
+    assert threads() <= base
