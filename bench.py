@@ -511,7 +511,10 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
         counter = 1
         pending = [None, None]
         if affinity:
-            qs[0].bind_thread()                                # the producer fills staging buffers that are pinned next to the GPU: run on that socket
+            try:
+                qs[0].bind_thread()                            # the producer fills staging buffers that are pinned next to the GPU: run on that socket
+            except smh.VisionError as e:                       # (a cpuset that excludes those CPUs: the leg still runs, wherever the scheduler puts it)
+                print("bench.py: ingest producer not bound to the GPU's CPUs: %s" % e, file=sys.stderr)
         t0 = None
         for b in range(-2, slabs):                             # (two untimed slabs first: the pipeline behind the queues starts from idle)
             if b == 0:
