@@ -401,25 +401,39 @@ def trait_path_leg(smh, vision, frame, labels, reps=40):
     """The per-call (drop-in) path on one frame of the workload (never `value`): VisionState.process -- load_frame, crop_to_map,
     find_minimap, then the markers branch and the scales branch on two threads -- `reps` times; wall time per frame and the
     library's own per-call table (smhv_trait_times: the reference wraps every trait call in a Timeshares entry,
-    vision-common/src/debug.rs:3-30, src/vision/mod.rs:54-66)."""
-    state = smh.VisionState()
-    for _ in range(5):
-        state.process(vision, frame, ocr_labels=labels)
-    vision.trait_times(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        res = state.process(vision, frame, ocr_labels=labels)
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    tt = vision.trait_times(reset=True)
-    state.close()
-    per = {k: v[0] / max(v[1], 1) for k, v in tt.items() if v[1]}
-    crit = per.get("load_frame", 0.0) + per.get("crop_to_map", 0.0) + per.get("find_minimap", 0.0) + max(
-        per.get("isolate_map_markers", 0.0) + per.get("mask_marker_lines", 0.0) + per.get("find_marker_lines", 0.0),
-        per.get("ocr_preprocess", 0.0) + per.get("find_scales_preprocess", 0.0) + per.get("calc_meters_to_px_ratio", 0.0))
-    return {"ms_per_frame": ms, "per_call_ms": per, "critical_path_ms": crit, "frames": reps, "lines": int(len(res.markers)),
-            "what": "VisionState.process through the C ABI's trait functions (host frame in pageable memory -> results on the host), one frame at a time; "
+    vision-common/src/debug.rs:3-30, src/vision/mod.rs:54-66).  Two sequences: the one the trait allows (the drop-in latency) and the
+    one with the lazy ui_map."""
+    import numpy as np
+
+    def run(state):
+        for _ in range(5):
+            state.process(vision, frame, ocr_labels=labels)
+        vision.trait_times(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = state.process(vision, frame, ocr_labels=labels)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        tt = vision.trait_times(reset=True)
+        state.close()
+        per = {k: v[0] / max(v[1], 1) for k, v in tt.items() if v[1]}
+        crit = per.get("load_frame", 0.0) + per.get("crop_to_map", 0.0) + per.get("find_minimap", 0.0) + max(
+            per.get("isolate_map_markers", 0.0) + per.get("mask_marker_lines", 0.0) + per.get("find_marker_lines", 0.0),
+            per.get("ocr_preprocess", 0.0) + per.get("find_scales_preprocess", 0.0) + per.get("calc_meters_to_px_ratio", 0.0))
+        return ms, per, crit, res
+    # the sequence the trait allows and rust/smh-vision-hip issues: crop_to_map returns the ui_map BY VALUE
+    # (vision-common/src/lib.rs:47; the CUDA back-end copies and synchronises inside the call, vision-gpu/src/lib.rs:291-297)
+    e_ms, e_per, e_crit, e_res = run(smh.VisionState(lazy_map=False))
+    # a host written for this library: crop_to_map returns at the button test, smhv_ui_map hands the image out of pinned memory
+    ms, per, crit, res = run(smh.VisionState(lazy_map=True, copy_map=False))
+    return {"eager_ms_per_frame": e_ms, "eager_per_call_ms": e_per, "eager_critical_path_ms": e_crit,
+            "ms_per_frame": ms, "per_call_ms": per, "critical_path_ms": crit, "frames": reps, "lines": int(len(res.markers)),
+            "same_results": bool(np.array_equal(res.markers, e_res.markers) and np.array_equal(res.map, e_res.map) and res.meters_to_px_ratio == e_res.meters_to_px_ratio),
+            "what": "VisionState.process through the C ABI's trait functions (host frame in pageable memory -> results on the host), one frame at a time. "
+                    "eager_* = THE DROP-IN LATENCY: the sequence the reference's host issues through the Rust shim -- smhv_crop_to_map(ctx, gray, &open, roi, ui) "
+                    "returns the ui_map by value as the trait demands. ms_per_frame = the same with crop_to_map(ui = NULL) + smhv_ui_map (the image travels to "
+                    "pinned memory while the branches run): needs a host that asks for the image later, i.e. a change to src/vision/mod.rs. "
                     "per_call_ms = the library's wall-clock table per trait call; critical_path_ms = load_frame + crop_to_map + find_minimap + the longer branch; "
-                    "the rest of ms_per_frame is the Python caller (thread hand-over, ctypes)"}
+                    "the rest is the Python caller (thread hand-over, ctypes)"}
 
 
 def real_samples_leg(smh, torch, vision, depth, batch=128, steps=200):
@@ -648,7 +662,7 @@ def config0(args):
              ("synthetic 1920x1080 (frame 0 of the bench generator)", frame_y, info_y["anchors"], info_y["scales_start_y"])]
     have_gpu = torch.cuda.is_available()
     vision = smh.HipVision.init(0) if have_gpu else None
-    state = smh.VisionState() if have_gpu else None
+    state = smh.VisionState(lazy_map=False) if have_gpu else None   # (the trait-shaped sequence: crop_to_map returns the image)
     out_cases = []
     for name, frame, labels, start_y in cases:
         H, W = frame.shape[:2]

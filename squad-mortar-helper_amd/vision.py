@@ -278,13 +278,21 @@ class VisionState:
     then the markers branch and the scales branch CONCURRENTLY on two threads, each calling
     thread_ctx() first.  OCR (Tesseract) is outside this path: its label anchors are an input."""
 
-    def __init__(self, grayscale_map=True, detect_markers=True, max_gap=15, heightmap_selected=True):
+    def __init__(self, grayscale_map=True, detect_markers=True, max_gap=15, heightmap_is_set=False, lazy_map=True, copy_map=True):
         self.grayscale_map = grayscale_map
         self.detect_markers = detect_markers
         self.max_gap = max_gap
-        # src/vision/mod.rs:121: the scales branch only runs while a heightmap is selected (`heightmaps::is_set()`): without one
-        # nobody asks how many meters a pixel is
-        self.heightmap_selected = heightmap_selected
+        # src/vision/mod.rs:121-124: `if squadex::heightmaps::is_set() { None } else { Some(closure) }` -- with a heightmap
+        # selected the meters come from the heightmap, the scales branch does NOT run, meters_to_px_ratio is None and the markers
+        # closure runs on the calling thread (mod.rs:219-223); without one (the default) both branches run side by side
+        self.heightmap_is_set = heightmap_is_set
+        # lazy_map: crop_to_map returns when the button test is known and the ui_map arrives through pinned memory while the
+        # branches run (a host written for this library).  lazy_map=False is the sequence the trait allows -- crop_to_map
+        # returns the image BY VALUE (vision-common/src/lib.rs:47), as rust/smh-vision-hip/src/lib.rs issues it
+        self.lazy_map = lazy_map
+        # copy_map: VisionResults.map is an array of the caller's own (the reference returns an owned RgbaImage); False hands
+        # out a view of the context's pinned buffer, valid until the second crop_to_map after this frame's
+        self.copy_map = copy_map
         # the two branches run on two long-lived threads (the reference: rayon::join on its pool, mod.rs:103-218) -- starting a
         # thread per branch and frame costs more than a branch takes
         self._workers = None
@@ -301,9 +309,11 @@ class VisionState:
                         job = q_in.get()
                         if job is None:
                             return
-                        job()
-                        job = None                              # (the closure holds the VisionState: a worker that kept it while it waits would keep the state -- and itself -- alive for ever)
-                        q_out.put(True)
+                        try:
+                            job()
+                        finally:
+                            job = None                          # (the closure holds the VisionState: a worker that kept it while it waits would keep the state -- and itself -- alive for ever)
+                            q_out.put(True)                     # (also when the job raised: the caller's get() must return)
                 t = threading.Thread(target=loop, daemon=True)
                 t.start()
                 self._workers.append((t, q_in, q_out))
@@ -328,11 +338,11 @@ class VisionState:
         (text/left/right/bottom) that plays the part of the reference's Tesseract call (`ocr::read`, mod.rs:169);
         its hits go through parse_ocr_labels exactly like the reference filters them."""
         vision.load_frame(frame)
-        cropped = vision.crop_to_map(self.grayscale_map, lazy=True)
+        cropped = vision.crop_to_map(self.grayscale_map, lazy=self.lazy_map)
         if cropped is None:
             return None
         res = VisionResults()
-        _, res.roi = cropped
+        res.map, res.roi = cropped
         res.minimap_bounds = vision.find_minimap()           # src/vision/mod.rs:85
         out, err = {}, []
 
@@ -348,8 +358,6 @@ class VisionState:
 
         def scales():
             try:
-                if not self.heightmap_selected:                 # mod.rs:121
-                    return
                 vision.thread_ctx()
                 out["ocr"] = vision.ocr_preprocess()
                 if ocr is not None:
@@ -367,10 +375,23 @@ class VisionState:
             except Exception as e:  # noqa: BLE001
                 err.append(e)
 
-        (_, qa_in, qa_out), (_, qb_in, qb_out) = self._pool()
-        qa_in.put(markers); qb_in.put(scales)
-        res.map = vision.ui_map()                            # (the image arrives while the branches run)
-        qa_out.get(); qb_out.get()
+        if self.heightmap_is_set:                            # mod.rs:121-124, 219-223: `(markers(), Ok(None))`
+            if self.lazy_map:
+                try:
+                    res.map = vision.ui_map(copy=self.copy_map)
+                except Exception as e:  # noqa: BLE001
+                    err.append(e)
+            markers()
+        else:                                                # `self.threads.join(markers, meters_to_px_ratio)`
+            (_, qa_in, qa_out), (_, qb_in, qb_out) = self._pool()
+            qa_in.put(markers); qb_in.put(scales)
+            try:
+                if self.lazy_map:
+                    res.map = vision.ui_map(copy=self.copy_map)  # (the image arrives while the branches run)
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+            finally:
+                qa_out.get(); qb_out.get()                   # (always: a token left behind would release the NEXT frame's wait early)
         if err:
             raise err[0]
         res.markers = out.get("markers", res.markers)

@@ -125,7 +125,9 @@ def test_button_threshold_edge(vision):
 def test_lazy_ui_map_heightmap_switch_and_per_call_times(vision):
     """crop_to_map without a destination returns once the button test is known; smhv_ui_map hands out the image from pinned
     memory -- the same bytes as the eager form, still readable while the NEXT frame is processed (two buffers take turns).
-    VisionState without a selected heightmap skips the scales branch (src/vision/mod.rs:121).  Every trait call leaves its wall
+    VisionState follows src/vision/mod.rs:121-124,219-223: WITHOUT a heightmap (`heightmaps::is_set()` false, the default) both
+    branches run; WITH one the scales branch is skipped, meters_to_px_ratio is None and the markers closure runs on the calling
+    thread.  lazy_map=False is the sequence the trait allows (the image by value from crop_to_map).  Every trait call leaves its wall
     time in the context's table (the reference's Timeshares entry per call, mod.rs:54-66)."""
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import synth
@@ -158,16 +160,32 @@ def test_lazy_ui_map_heightmap_switch_and_per_call_times(vision):
         vision.ui_map()
     # the caller contract with and without a heightmap
     vision.trait_times(reset=True)
-    st = smh.VisionState()
+    st = smh.VisionState()                                           # no heightmap: both branches (mod.rs:124 `Some(closure)`)
+    assert st.heightmap_is_set is False
     res = st.process(vision, f0, ocr_labels=i0["anchors"])
     assert np.array_equal(res.map, r0["ui_map"]) and np.array_equal(res.markers, r0["lines"]) and res.meters_to_px_ratio == r0["mpx"]
+    assert res.meters_to_px_ratio is not None
     tt = vision.trait_times()
     for k in ("load_frame", "crop_to_map", "find_minimap", "find_marker_lines", "ocr_preprocess", "find_scales_preprocess", "calc_meters_to_px_ratio", "ui_map"):
         assert tt[k][1] == 1 and tt[k][0] > 0.0, (k, tt[k])
-    st2 = smh.VisionState(heightmap_selected=False)
+    st2 = smh.VisionState(heightmap_is_set=True)                     # a heightmap is selected: `None` => (markers(), Ok(None))
     res2 = st2.process(vision, f0, ocr_labels=i0["anchors"])
-    assert np.array_equal(res2.markers, r0["lines"]) and res2.meters_to_px_ratio is None
-    assert vision.trait_times()["ocr_preprocess"][1] == 1            # (not called again)
+    assert np.array_equal(res2.map, r0["ui_map"]) and np.array_equal(res2.markers, r0["lines"]) and res2.meters_to_px_ratio is None
+    tt = vision.trait_times()
+    assert tt["ocr_preprocess"][1] == 1 and tt["find_scales_preprocess"][1] == 1 and tt["calc_meters_to_px_ratio"][1] == 1   # (not called again)
+    assert tt["find_marker_lines"][1] == 2
+    assert st2._workers is None                                      # (no join: the markers closure ran on this thread)
+    # the trait-shaped sequence: crop_to_map hands the image over by value, smhv_ui_map is never called
+    st3 = smh.VisionState(lazy_map=False)
+    res3 = st3.process(vision, f1, ocr_labels=i1["anchors"])
+    assert np.array_equal(res3.map, r1["ui_map"]) and np.array_equal(res3.markers, r1["lines"]) and res3.meters_to_px_ratio == r1["mpx"]
+    assert vision.trait_times()["ui_map"][1] == 2
+    # VisionResults.map is the caller's own: the next frames do not touch it
+    keep = res.map
+    for f in (f1, f0, f1):
+        st.process(vision, f, ocr_labels=i1["anchors"])
+    assert np.array_equal(keep, r0["ui_map"])
+    st3.close()
     st.close(); st2.close()
 
 

@@ -272,3 +272,79 @@ def test_header_is_plain_c_and_the_c_example_links(built, tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), src, "-L", os.path.join(root, "squad-mortar-helper_amd"),
                            "-l:libsmh_vision_hip.so", "-Wl,-rpath," + os.path.join(root, "squad-mortar-helper_amd"), "-o", exe])
     assert os.path.exists(exe)
+
+
+class _RecordingVision:
+    """Stands in for a Vision back-end: records the trait calls VisionState.process issues (no GPU)."""
+
+    def __init__(self, fail_ui_map=False):
+        import threading
+        self.calls, self.threads, self.fail_ui_map, self._lock = [], {}, fail_ui_map, threading.Lock()
+
+    def _rec(self, name):
+        import threading
+        with self._lock:
+            self.calls.append(name)
+            self.threads[name] = threading.get_ident()
+
+    def load_frame(self, f): self._rec("load_frame")
+    def crop_to_map(self, gray, lazy=False):
+        self._rec("crop_to_map_lazy" if lazy else "crop_to_map_eager")
+        return (None if lazy else np.full((2, 2, 4), 7, np.uint8)), [1, 2, 3, 4]
+    def ui_map(self, copy=False):
+        self._rec("ui_map")
+        if self.fail_ui_map:
+            raise RuntimeError("ui_map failed")
+        return np.full((2, 2, 4), 9, np.uint8)
+    def find_minimap(self): self._rec("find_minimap"); return None
+    def thread_ctx(self): self._rec("thread_ctx")
+    def isolate_map_markers(self): self._rec("isolate_map_markers")
+    def mask_marker_lines(self): self._rec("mask_marker_lines")
+    def find_marker_lines(self, gap): self._rec("find_marker_lines"); return np.ones((1, 4), np.float32)
+    def ocr_preprocess(self): self._rec("ocr_preprocess"); return np.zeros((4, 4), np.uint8)
+    def find_scales_preprocess(self, y): self._rec("find_scales_preprocess")
+    def calc_meters_to_px_ratio(self, labels): self._rec("calc_meters_to_px_ratio"); return 0.5
+    def get_debug_view(self, c): self._rec("get_debug_view"); return None
+
+
+def test_vision_state_follows_the_reference_call_contract(built):
+    """src/vision/mod.rs:121-124, 219-223: `heightmaps::is_set()` => no scales closure, `(markers(), Ok(None))` on the calling
+    thread; otherwise `threads.join(markers, scales)`.  Also: a failing ui_map leaves no completion token behind."""
+    import threading
+    import squad_mortar_helper_amd as smh
+    me = threading.get_ident()
+    frame = np.zeros((4, 4, 4), np.uint8)
+    labels = [(100, 1, 1)]
+    # no heightmap (default): both branches, on two threads other than the caller's
+    v, st = _RecordingVision(), smh.VisionState()
+    res = st.process(v, frame, ocr_labels=labels)
+    assert res.meters_to_px_ratio == 0.5 and len(res.markers) == 1 and res.map[0, 0, 0] == 9
+    assert {"ocr_preprocess", "find_scales_preprocess", "calc_meters_to_px_ratio", "find_marker_lines"} <= set(v.calls)
+    assert v.threads["find_marker_lines"] != me and v.threads["ocr_preprocess"] != me and v.threads["find_marker_lines"] != v.threads["ocr_preprocess"]
+    assert v.calls[:3] == ["load_frame", "crop_to_map_lazy", "find_minimap"] and v.calls[-1] == "get_debug_view"
+    # heightmap selected: the scales branch is not there at all
+    v2, st2 = _RecordingVision(), smh.VisionState(heightmap_is_set=True)
+    res2 = st2.process(v2, frame, ocr_labels=labels)
+    assert res2.meters_to_px_ratio is None and len(res2.markers) == 1
+    assert not {"ocr_preprocess", "find_scales_preprocess", "calc_meters_to_px_ratio"} & set(v2.calls)
+    assert v2.threads["find_marker_lines"] == me
+    # the trait-shaped sequence: the image comes back from crop_to_map, ui_map is never asked for
+    v3, st3 = _RecordingVision(), smh.VisionState(lazy_map=False)
+    res3 = st3.process(v3, frame, ocr_labels=labels)
+    assert "crop_to_map_eager" in v3.calls and "ui_map" not in v3.calls and res3.map[0, 0, 0] == 7 and res3.meters_to_px_ratio == 0.5
+    # detect_markers off: Default::default()
+    v4 = _RecordingVision()
+    res4 = smh.VisionState(detect_markers=False).process(v4, frame, ocr_labels=labels)
+    assert "find_marker_lines" not in v4.calls and res4.markers.shape == (0, 4) and res4.meters_to_px_ratio == 0.5
+    # ui_map raising: the error surfaces, both branches are waited for, and the NEXT frame waits for its own branches
+    bad = _RecordingVision(fail_ui_map=True)
+    with pytest.raises(RuntimeError):
+        st.process(bad, frame, ocr_labels=labels)
+    assert "find_marker_lines" in bad.calls and "calc_meters_to_px_ratio" in bad.calls
+    for _, _, q_out in st._workers:
+        assert q_out.empty()
+    v5 = _RecordingVision()
+    res5 = st.process(v5, frame, ocr_labels=labels)
+    assert res5.meters_to_px_ratio == 0.5 and len(res5.markers) == 1
+    for s in (st, st2, st3):
+        s.close()

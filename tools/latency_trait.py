@@ -15,7 +15,8 @@ from oracle import oracle as orc   # CPU timing only
 
 def main():
     vision = smh.HipVision.init(0)
-    state = smh.VisionState()
+    state = smh.VisionState(lazy_map=True, copy_map=False)   # a host written for this library (crop_to_map(ui = NULL) + smhv_ui_map)
+    eager = smh.VisionState(lazy_map=False)                  # the sequence the trait allows: the image by value from crop_to_map (the Rust shim)
     rows = []
     from squad_mortar_helper_amd import synth
     for stem in ("synthetic_1080p", "point_intersect_png", "points_intersect_png", "snowpoints_png", "fullmap_jpg", "whiteout_png"):
@@ -34,13 +35,22 @@ def main():
         gpu_ms = (time.perf_counter() - t0) / n * 1e3
         tt = vision.trait_times(reset=True)
         print("  %-22s per call (ms): %s" % (stem, "  ".join("%s %.3f" % (k, v[0] / max(v[1], 1)) for k, v in tt.items() if v[1])))
+        for _ in range(3):
+            eager.process(vision, frame, ocr_labels=labels)
+        vision.trait_times(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            res_e = eager.process(vision, frame, ocr_labels=labels)
+        eager_ms = (time.perf_counter() - t0) / n * 1e3
+        tt = vision.trait_times(reset=True)
+        print("  %-22s eager    (ms): %s" % (stem, "  ".join("%s %.3f" % (k, v[0] / max(v[1], 1)) for k, v in tt.items() if v[1])))
         t0 = time.perf_counter()
         ref = orc.process_frame(frame, stages=0xF, anchors=labels, scales_start_y=min(a[2] for a in labels))
         cpu_ms = (time.perf_counter() - t0) * 1e3
-        same = res is not None and np.array_equal(res.markers, ref["lines"])
-        rows.append((stem, frame.shape[1], frame.shape[0], ref["rounds"], ref["n_lines"], gpu_ms, cpu_ms, same))
+        same = res is not None and np.array_equal(res.markers, ref["lines"]) and np.array_equal(res_e.markers, ref["lines"]) and np.array_equal(res.map, res_e.map)
+        rows.append((stem, frame.shape[1], frame.shape[0], ref["rounds"], ref["n_lines"], eager_ms, gpu_ms, cpu_ms, same))
     for r in rows:
-        print("%-22s %dx%d rounds %4d lines %2d  trait path %.2f ms/frame  C oracle (1 thread) %.1f ms  lines equal: %s" % r)
+        print("%-22s %dx%d rounds %4d lines %2d  trait path (eager, drop-in) %.2f ms/frame, lazy ui_map %.2f  C oracle (1 thread) %.1f ms  lines equal: %s" % r)
 
 
 if __name__ == "__main__":
