@@ -343,6 +343,8 @@ SMHV_API int smhv_pipeline_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t fram
 #define SMHV_PIPE_NO_STREAM_PRIORITY 2u /*   ... without wave priority for the streaming pass */
 #define SMHV_PIPE_NO_PROLOGUE 4u        /*   ... button test and anchor upload on the streaming streams instead of a stream of their own */
 #define SMHV_PIPE_NO_REMOTE_HELP 8u     /*   ... a heavy frame is helped by the waves of its own workgroup only, not by idle waves of other workgroups */
+#define SMHV_PIPE_WALK_BIT_ROWS 32u     /*   ... the service builds a frame's tile store by walking the bit rows' bounding box (rounds 2-5) instead of from the pass's tile-major mask */
+#define SMHV_PIPE_THREE_LOAD_SETS 64u   /*   ... the streaming pass of a frame-granular pipeline with three register sets of loads in flight (128 registers: two workgroups per CU beside the service; round 5's form up to 1080p) instead of two (112: three) */
 #define SMHV_PIPE_HELP_FIRST 16u        /*   ... frames ask other workgroups, and waves answer, even while frames are waiting for a wave (default: only then not) */
 typedef struct {
 	uint32_t size;

@@ -126,6 +126,10 @@ struct Buffers {
 	const uint8_t *frames;   // n * frame_bytes
 	uint8_t *ui, *mask, *ocr, *scales;
 	uint32_t *bits;
+	// the same mask tile-major, and which tiles hold a set bit (written by the streaming passes, read by the search service's
+	// tile-store builder: tiled_* / occ_* below)
+	uint32_t *tiled;
+	uint8_t *occ;
 	FrameAux *aux;
 	smhv_frame_result *results;
 	const smhv_anchors *anchors;   // device copy, may be null
@@ -139,6 +143,24 @@ struct Buffers {
 	const float *ray_off;
 	LsdCoopBufs co;
 };
+// ---- the mask as the streaming passes leave it for the line search (round 6) -------------------------------------------------
+// A marker mask is 1-4 % non-empty, and what the search keeps in LDS is its non-empty 32 x 8 px tiles.  Finding them in the
+// row-major bit rows meant walking the bounding box of the set bits: (tile rows x tile columns) x 16 strided dword loads, ~68 KB
+// and ~19 dependent round trips per 1080p frame, from one wave, while the streaming pass saturates the memory system.  The
+// pass knows which tiles are empty when it writes them, so it also leaves
+//   tiled  the bit rows tile-major: tile (ty, wx) = rows 8 ty .. 8 ty + 7 of word column wx of the bit-packed rows (Geom::bits_pitch_w
+//          word columns; bit 0 of word column 0 is the ROI's quad-aligned x, m_xoff bits left of pixel 0), 8 consecutive words.
+//          Only tiles with a set bit are written (by the wave that owns the word column in that band).
+//   occ    one byte per (tile row, wave of the pass): bit j = tile (ty, 8 wave + j) holds a set bit.  Every band of an open frame
+//          writes the bytes of its tile rows (zeros too), so nothing stale is ever read.
+// The builder reads the occupancy bytes of the bounding box's tile rows (one coalesced load) and then exactly the non-empty
+// tiles (32 contiguous bytes each, all in flight together): 2-3 round trips and 4-9 KB.  Bands are a multiple of 8 rows tall
+// for this (56 instead of 58: still 15 bands at 1080p).
+__host__ __device__ inline uint32_t tiled_rows(const Geom &g) { return (g.rh + 7u) >> 3; }
+__host__ __device__ inline uint64_t tiled_stride_w(const Geom &g) { return (uint64_t)tiled_rows(g) * g.bits_pitch_w * 8u; }
+__host__ __device__ inline uint32_t occ_pitch(const Geom &g) { return ((g.m_block >> 6) + 3u) & ~3u; }
+__host__ __device__ inline uint64_t occ_stride(const Geom &g) { return (uint64_t)tiled_rows(g) * occ_pitch(g); }
+
 #define SMH_RAY_OFF_BATCHES 168u     // 5376 steps: longer than the diagonal of the largest supported ROI (4096 x 3300)
 
 // Sector culling table as k_build_sector_table writes it: (2R+1)^2 entries, entry (oy+R)*(2R+1) + (ox+R) = bit mask of the
@@ -255,6 +277,7 @@ struct SvcParams {
 	uint32_t epoch;                     // of this launch (> 0)
 	uint32_t idle_short, idle_long;     // in units of 1024 cycles
 	uint32_t flags;                     // experiments (SMH_SVC_FLAGS; results may be WRONG): 1 = no cache invalidation per item, 2 = no write-back per frame, 4 = s_setprio 3, 8 = no helping among the waves of a workgroup
+	                                    // 32 = the tile store is built by walking the bit rows' bounding box (rounds 2-5) instead of from the pass's tile-major mask (A/B)
 	// help across workgroups (null / 0: none)
 	SvcRemote *remote;                  // one per wave of the launch
 	uint32_t *remote_store;             // owner o's tile store: remote_store + o * remote_store_words

@@ -181,7 +181,8 @@ struct smhv_batch {
 	Geom g{};
 	uint32_t max_frames = 0;
 	uint8_t *d_ui = nullptr, *d_mask = nullptr, *d_ocr = nullptr, *d_scales = nullptr;
-	uint32_t *d_bits = nullptr, *d_bars = nullptr;
+	uint32_t *d_bits = nullptr, *d_bars = nullptr, *d_tiled = nullptr;
+	uint8_t *d_occ = nullptr;
 	FrameAux *d_aux = nullptr;
 	smhv_frame_result *d_results = nullptr;   // max_frames (+3 spare records for the per-frame trait path)
 	smhv_anchors *d_anchors = nullptr;
@@ -352,6 +353,7 @@ static Buffers make_buffers(smhv_batch *b, const uint8_t *frames, uint32_t resul
 	bf.frames = frames;
 	bf.ui = b->d_ui; bf.mask = b->d_mask; bf.ocr = b->d_ocr; bf.scales = b->d_scales;
 	bf.bits = b->d_bits; bf.aux = b->d_aux;
+	bf.tiled = b->d_tiled; bf.occ = b->d_occ;
 	bf.results = b->d_results + result_slot;
 	bf.anchors = b->d_anchors;
 	bf.co.ctl = nullptr;                                     // k_lsd cooperation is opt-in: smhv_batch_run sets it for SMHV_STAGE_LSD_HELPERS
@@ -541,6 +543,8 @@ extern "C" SMHV_API int smhv_batch_create(smhv_ctx *c, uint32_t W, uint32_t H, u
 	ALLOC0(b->d_ui, g.ui_stride * n);
 	ALLOC0(b->d_mask, g.mask_stride * n);
 	ALLOC0(b->d_bits, g.bits_stride_w * 4 * n);
+	ALLOC0(b->d_tiled, tiled_stride_w(g) * 4 * n);
+	ALLOC0(b->d_occ, occ_stride(g) * n);
 	ALLOC0(b->d_ocr, g.ocr_stride * n);
 	ALLOC0(b->d_scales, g.ocr_stride * n);      // zero-initialised like GrayImage::new (lib.rs:86)
 	ALLOC0(b->d_aux, sizeof(FrameAux) * n);
@@ -576,7 +580,7 @@ extern "C" SMHV_API void smhv_batch_destroy(smhv_batch *b) {
 	if (!b) return;
 	if (b->ctx) (void)hipSetDevice(b->ctx->device);
 	(void)hipDeviceSynchronize();
-	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars, b->d_farm,
+	void *ptrs[] = {b->d_ui, b->d_mask, b->d_bits, b->d_tiled, b->d_occ, b->d_ocr, b->d_scales, b->d_aux, b->d_results, b->d_anchors, b->d_bars, b->d_farm,
 	                b->d_lsd_ctl, b->d_lsd_req, b->d_lsd_cache};
 	for (void *p : ptrs)
 		if (p) (void)hipFree(p);
@@ -1189,7 +1193,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 			// pass at two workgroups per CU (three with the service at exactly 128 registers: measured, no difference --
 			// DESIGN.md A.-1); the streaming waves go first on their SIMD
 			p->batch[i]->tune.map_prio = (opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u;
-			p->batch[i]->tune.map_deep = (p->svc_waves >= 4u && !p->svc_compact) ? 1u : 0u;   // (a service workgroup on every CU: launch_map_brq_pass)
+			p->batch[i]->tune.map_deep = (opt.flags & SMHV_PIPE_THREE_LOAD_SETS) ? 1u : 0u;   // (a service workgroup on every CU: launch_map_brq_pass)
 		} else if (depth >= 3) {                                  // (an adaptive pipeline sets the tuning of a slot per submission)
 			if (opt.occupancy_policy != 2u) p->tuning = pipeline_tuning(p->batch[i]->g);
 			p->batch[i]->tune = p->tuning;
@@ -1231,6 +1235,7 @@ static int svc_launch(smhv_pipeline *p, uint32_t slot) {
 	sp.flags = (p->opt.flags & SMHV_PIPE_NO_TEAM_HELP) ? 8u : 0u;
 	sp.idle_long = 50000u;                                               // ~20 ms without work, nobody at work: the streaming side is stuck
 	if (p->opt.flags & SMHV_PIPE_HELP_FIRST) sp.flags |= 16u;
+	if (p->opt.flags & SMHV_PIPE_WALK_BIT_ROWS) sp.flags |= 32u;
 
 	sp.remote = p->d_svc_remote; sp.remote_store = p->d_svc_store; sp.remote_store_words = p->svc_store_words;
 	sp.remote_after = p->opt.remote_after ? p->opt.remote_after : 24u;
@@ -1292,7 +1297,7 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	if (rc) return rc;
 	if (batch_check_errors(b, "pipeline_submit (the slot's previous submission, never waited for)") != SMHV_OK) logf(p->ctx, 2, "%s", t_last_error.c_str());
 	hipStream_t st = p->svc_stream[p->submitted % p->svc_streams];
-	if (p->adaptive) { b->tune = LaunchTuning{0u, 0u, 0u, (p->opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u, (p->svc_waves >= 4u && !p->svc_compact) ? 1u : 0u}; b->probe = false; b->lsd_late_kc = 0u; }
+	if (p->adaptive) { b->tune = LaunchTuning{0u, 0u, 0u, (p->opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u, (p->opt.flags & SMHV_PIPE_THREE_LOAD_SETS) ? 1u : 0u}; b->probe = false; b->lsd_late_kc = 0u; }
 	// the sector table of this gap threshold is a launch parameter of the service: a submission with another one waits for
 	// the service to finish what it has and close (a host that alternates thresholds pays a drain per change)
 	Buffers probe{};

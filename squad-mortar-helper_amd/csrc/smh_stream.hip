@@ -17,6 +17,34 @@
 namespace smh {
 
 // ------------------------------------------------------------------------------------------------
+// Tile outputs of one wave of a band (smh_kernels.h, "the mask as the streaming passes leave it for the line search").
+// rows_any: the lane's dilated column masks OR-ed together, bit 0 = the band's first row.  Writes the wave's occupancy bytes
+// of the band's `ntr` tile rows and returns, in the lanes 8 j that store the bit-packed words, which of the band's (up to
+// seven) tiles of their word column hold a set bit (bit t = tile row t of the band); 0 in every other lane.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tile_occupancy(uint64_t rows_any, uint32_t lane, uint32_t ntr, uint8_t *occp, uint32_t pitch) {
+	uint32_t alo = (uint32_t)rows_any, ahi = (uint32_t)(rows_any >> 32);
+	alo |= SMH_DPP(alo, 0x101); ahi |= SMH_DPP(ahi, 0x101);         // row_shl:1 -- lane l reads lane l + 1 (0 beyond the 16-lane row)
+	alo |= SMH_DPP(alo, 0x102); ahi |= SMH_DPP(ahi, 0x102);
+	alo |= SMH_DPP(alo, 0x104); ahi |= SMH_DPP(ahi, 0x104);         // lane 8 j: the rows set anywhere in its eight quads = its word column
+	uint32_t occ = 0;
+#pragma unroll
+	for (int t = 0; t < 4; ++t) occ |= (((alo >> (8 * t)) & 255u) ? 1u : 0u) << t;
+#pragma unroll
+	for (int t = 0; t < 3; ++t) occ |= (((ahi >> (8 * t)) & 255u) ? 1u : 0u) << (4 + t);
+	if (lane & 7u) occ = 0u;
+	uint32_t mine = 0;
+#pragma unroll
+	for (int t = 0; t < 7; ++t) {
+		const uint64_t bal = __ballot((occ >> t) & 1u) & 0x0101010101010101ull;     // lanes 0, 8, .., 56
+		const uint32_t byte = (uint32_t)((bal * 0x0102040810204080ull) >> 56);      // lane 8 j -> bit j
+		if (lane == (uint32_t)t) mine = byte;
+	}
+	if (lane < ntr) occp[(size_t)lane * pitch] = (uint8_t)mine;
+	return occ;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_button: one workgroup per frame.  Also resets the per-frame scratch for the later passes.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_open) {
@@ -75,7 +103,9 @@ __global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_ope
 // instructions per band instead of a second pass over an intermediate image.  ui_map is written
 // straight from the loaded registers; the frame is read exactly once (+2 halo rows per band).
 // ------------------------------------------------------------------------------------------------
-#define MAP_RB_MAX 62
+// (rows per band: a multiple of 8, so that a band is a whole number of the line search's tile rows -- the pass writes the mask
+// tile-major as well, smh_kernels.h; the column masks would hold 62)
+#define MAP_RB_MAX 56
 
 template <bool GRAY>
 __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t flags, uint32_t RB) {
@@ -218,9 +248,21 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 
 	// ---- outputs: u8 mask rows and bit-packed rows ----
 	const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
+	const uint64_t any = D[0] | D[1] | D[2] | D[3];
+	const uint64_t lanes_set = __ballot(any != 0ull);
+	// the tile-major mask and its occupancy bytes (bands of whole tile rows: launch_map_pass)
+	uint32_t occ7 = 0;
+	const bool tiles_out = b.tiled != nullptr && (RB & 7u) == 0u;
+	if (tiles_out) {
+		const uint32_t ntr = ((uint32_t)nrows + 7u) >> 3, op = occ_pitch(g);
+		uint8_t *occp = b.occ + (size_t)f * occ_stride(g) + (size_t)((uint32_t)r0 >> 3) * op + wave;
+		if (lanes_set) occ7 = tile_occupancy(any >> 1, lane, ntr, occp, op);
+		else if (lane < ntr) occp[(size_t)lane * op] = 0;
+	}
 	if (q < quads_padded) {
 		uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
 		uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
+		uint32_t *tp = b.tiled + (size_t)f * tiled_stride_w(g) + ((size_t)((uint32_t)r0 >> 3) * g.bits_pitch_w + (q >> 3)) * 8u;
 		for (int row = r0; row < r1; ++row) {
 			const int bit = row - r0 + 1;
 			const uint32_t nib = (uint32_t)((D[0] >> bit) & 1ull) | ((uint32_t)((D[1] >> bit) & 1ull) << 1) |
@@ -232,11 +274,11 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 			v |= __shfl_down(v, 2) << 8;
 			v |= __shfl_down(v, 4) << 16;
 			if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
+			const uint32_t i = (uint32_t)(row - r0);
+			if ((occ7 >> (i >> 3)) & 1u) tp[(size_t)(i >> 3) * g.bits_pitch_w * 8u + (i & 7u)] = v;      // (occ7 is 0 outside the lanes 8 j)
 		}
 	}
 	// ---- bounding box + population count of the set bits (drives the LDS window of k_lsd) ----
-	const uint64_t any = D[0] | D[1] | D[2] | D[3];
-	const uint64_t lanes_set = __ballot(any != 0ull);
 	if (lanes_set) {
 		const uint64_t rows_set = wave_or64(any);
 		const uint32_t cnt = wave_sum32(__popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]));
@@ -392,9 +434,16 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 // find_scales_preprocess on the pixels it has already loaded for ui_map and the marker mask: the quadrant is not read a
 // second time (k_brq_pass re-read 2 x 126 MB per 256 frames) and one launch and the branch stream go away.
 // Column masks are indexed from row r0 - 3 (the OCR neighbourhood reaches 3 rows up; the marker dilation 1), so a band
-// holds at most 58 output rows: 3 + 58 + 3 = 64 bits.
+// holds at most 58 output rows: 3 + 58 + 3 = 64 bits -- 56 of them are used: whole tile rows of the line search (the pass
+// writes the mask tile-major as well, smh_kernels.h).  1080p: 15 bands either way; 1440p: 20 instead of 19.
 // ------------------------------------------------------------------------------------------------
-#define MAPQ_RB_MAX 58
+#define MAPQ_RB_MAX 56
+// fewer frames than fill the chip: shorter bands, still whole tile rows
+static inline uint32_t band_rows_for(uint32_t rh, uint32_t n, uint32_t rb_max) {
+	uint32_t RB = rb_max;
+	while (RB > 8 && (uint64_t)((rh + RB - 1) / RB) * n < 512) RB = RB > 32 ? 32 : RB / 2;
+	return RB;
+}
 
 // ---- small pieces of the fused pass ----
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -755,6 +804,22 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 		const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
 		const uint64_t any = D[0] | D[1] | D[2] | D[3];
 		const uint64_t lanes_set = __ballot(any != 0ull);
+		// the tile-major mask and its occupancy bytes for the search service's tile-store builder (smh_kernels.h; bands of whole
+		// tile rows: launch_map_brq_pass).  A wave without a marker pixel -- most of them -- stores its (up to seven) zero bytes.
+		// (their two pointers are fetched HERE, through a copy of the argument pointer the compiler cannot see through: held in
+		// scalar registers across the streaming loop they cost it 84 more spill reloads per iteration of the three-set form)
+		MapKernelArgsPtr kb = ka;
+		asm volatile("" : "+s"(kb));
+		uint32_t *const tiled_out = kb->b.tiled;
+		uint8_t *const occ_out = kb->b.occ;
+		uint32_t occ7 = 0;
+		const bool tiles_out = tiled_out != nullptr && (RB & 7u) == 0u;
+		if (tiles_out) {
+			const uint32_t ntr = ((uint32_t)nrows + 7u) >> 3, opitch = occ_pitch(g);
+			uint8_t *occp = occ_out + (size_t)f * occ_stride(g) + (size_t)((uint32_t)r0 >> 3) * opitch + wave;
+			if (lanes_set) occ7 = tile_occupancy(any >> 3, lane, ntr, occp, opitch);
+			else if (lane < ntr) occp[(size_t)lane * opitch] = 0;
+		}
 		if (q < quads_padded && !lanes_set) {
 			// no marker pixel in this wave's 256 columns of the band (most of a map): rows of zeros, nothing to extract or gather
 			uint8_t *mbase = b.mask + (size_t)f * g.mask_stride;
@@ -773,6 +838,8 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 			uint32_t *bbase = b.bits + (size_t)f * g.bits_stride_w;
 			const uint32_t moff = q * 4u, boff = (q >> 3) * 4u;
 			const bool bit_lane = (lane & 7u) == 0;
+			uint32_t *tp = tiled_out + (size_t)f * tiled_stride_w(g) + ((size_t)((uint32_t)r0 >> 3) * g.bits_pitch_w + (q >> 3)) * 8u;
+			const uint32_t tpitch = g.bits_pitch_w * 8u;
 #pragma unroll
 			for (int half = 0; half < 2; ++half) {
 				const uint32_t d0 = (uint32_t)(D[0] >> (32 * half)), d1 = (uint32_t)(D[1] >> (32 * half)), d2 = (uint32_t)(D[2] >> (32 * half)), d3 = (uint32_t)(D[3] >> (32 * half));
@@ -786,6 +853,8 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 					v |= SMH_DPP(v, 0x102) << 8;
 					v |= SMH_DPP(v, 0x104) << 16;
 					if (bit_lane) *(uint32_t *)((uint8_t *)bbase + (size_t)row * g.bits_pitch_w * 4u + boff) = v;
+					const uint32_t i = (uint32_t)(row - r0);
+					if ((occ7 >> (i >> 3)) & 1u) tp[(size_t)(i >> 3) * tpitch + (i & 7u)] = v;     // (occ7 is 0 outside the lanes 8 j)
 				}
 			}
 		}
@@ -866,8 +935,7 @@ hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_
 
 hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s) {
 	// Few frames: shorter bands so a single frame still spreads over the chip.
-	uint32_t RB = MAP_RB_MAX;
-	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
+	const uint32_t RB = band_rows_for(g.rh, n, MAP_RB_MAX);
 	const dim3 grid((g.rh + RB - 1) / RB, n);
 	const unsigned lds = (g.m_block / 64u) * 640u;             // 64 x (pixel, verdict, id) per wave
 	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, RB);
@@ -883,8 +951,7 @@ uint32_t map_brq_lds_bytes(const Geom &g) { return map_brq_static_lds() + (g.m_b
 
 hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
                                const LaunchTuning *tune) {
-	uint32_t RB = MAPQ_RB_MAX;
-	while (RB > 8 && (uint64_t)((g.rh + RB - 1) / RB) * n < 512) RB = (RB + 1) / 2;
+	const uint32_t RB = band_rows_for(g.rh, n, MAPQ_RB_MAX);
 	const uint32_t nbands = (g.rh + RB - 1) / RB, items = nbands * n;
 	unsigned lds = (g.m_block / 64u) * 640u;                 // 64 x (pixel, verdict, id) per wave
 	if (tune && tune->map_lds_total > map_brq_lds_bytes(g)) lds = tune->map_lds_total - map_brq_static_lds();
