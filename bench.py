@@ -95,6 +95,7 @@ def parse_args():
                          "a pipeline with room_for_others, after the timed region (N=1, config 2; 0 = skip): `co_residency` in the JSON line")
     ap.add_argument("--gather-probe", action="store_true", help="N = 1: also run the co-residency leg with RCCL itself (a communicator of one rank, one all_gather per pass on a side stream; RCCL prints its banner to stdout in front of the JSON line)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--timed-regions", type=int, default=1, help="cut the K timed steps into this many regions, each bracketed by barrier + synchronize (value = median; default 1 = the contract's one region)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-real-samples", action="store_true", help="skip the leg on the reference's own 1440p screenshots (real_samples)")
     ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
@@ -634,8 +635,11 @@ def upload_synthetic(torch, synth, W, H, n, first, lines, distinct, device, keep
     return d, infos, host, h2d
 
 
-def sub_regions(steps):
-    k = min(5, steps)
+def sub_regions(steps, regions=1):
+    """The K timed steps as `regions` regions (default ONE: exactly K steps between two barrier + synchronize brackets, as the
+    driver's contract words it; rounds 1-5 cut them into five and reported the median -- every inner barrier drains the pipeline
+    once, 5 ms of each 170 ms region).  --timed-regions N keeps the old form for a min / max."""
+    k = max(1, min(regions, steps))
     return [steps * (i + 1) // k - steps * i // k for i in range(k)]
 
 
@@ -749,7 +753,7 @@ def node_main(args, cfg, n, W, H, stages, rounds, custom):
     for _ in range(args.warmup):
         step()
     dts = []
-    for k in sub_regions(args.steps):
+    for k in sub_regions(args.steps, args.timed_regions):
         t0 = time.perf_counter()
         for _ in range(k):
             step()
@@ -904,9 +908,9 @@ def main():
         torch.cuda.synchronize()           # all streams of the device
 
     def timed(p, steps):
-        """`steps` steps as up to five sub-regions, each bracketed by barrier + synchronize on both sides -> per-region
+        """`steps` steps as --timed-regions regions (default one), each bracketed by barrier + synchronize on both sides -> per-region
         (seconds MAX over ranks, steps)."""
-        parts = sub_regions(steps)
+        parts = sub_regions(steps, args.timed_regions)
         barrier()
         dts = []
         for k in parts:
@@ -1069,7 +1073,8 @@ def main():
                    "schedule": ("smhv_pipeline, frame-granular line search (k_lsd_service: one long-lived kernel pulls (slot, frame) items from a device ring)"
                                 if svc_stats and svc_stats.get("mode") == "frame-granular" else "smhv_pipeline, batch-granular line search (one launch per batch)") +
                                ("; chosen by the pipeline's own measurement of both on this workload" if svc_stats and svc_stats.get("adaptive") else "")},
-        "value_is": "median of %d sub-regions of the %d timed steps (each bracketed by barrier + synchronize)" % (len(regions), args.steps),
+        "value_is": ("the %d timed steps as ONE region bracketed by barrier + synchronize" % args.steps if len(regions) == 1 else
+                     "median of %d sub-regions of the %d timed steps (each bracketed by barrier + synchronize)" % (len(regions), args.steps)),
         "value_min": min(rates), "value_max": max(rates), "value_whole_region": frames_per_step * args.steps / dt_total,
         "timed_seconds": dt_total,
         "ms_per_pass": frames_per_step / value * 1e3 / rounds,

@@ -432,14 +432,16 @@ SMHV_API int smhv_ingest_create(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_
  * frames then hold exactly those two rectangles (zero elsewhere), which is all smhv_batch_run / the pipelines read.  BGRA8
  * commits only. */
 #define SMHV_INGEST_ROI_UPLOAD 1u
-#define SMHV_INGEST_WORKERS(n) (((n) & 0xFFu) << 8)   /* diagnostic, with SMHV_INGEST_ROI_UPLOAD: hashing threads (0 = the library's choice: all but two of the cores the process may use) */
+#define SMHV_INGEST_WORKERS(n) (((n) & 0xFFu) << 8)   /* diagnostic, with SMHV_INGEST_ROI_UPLOAD: hashing threads (0 = the library's choice: one per staging slot, at most half the cores the process may use -- the cgroup CPU quota counts -- and at least two) */
 #define SMHV_INGEST_NO_AFFINITY 2u   /* the hashing threads are left to the scheduler (default: on a multi-socket host they run on the CPUs next to the GPU) */
 SMHV_API int smhv_ingest_create_ex(smhv_ctx *ctx, uint32_t frame_w, uint32_t frame_h, uint32_t slots, uint32_t capacity, uint32_t flags, smhv_ingest **out);
 SMHV_API void smhv_ingest_destroy(smhv_ingest *q);
 /* The CPUs next to the queue's GPU (the NUMA node of its PCI device, from sysfs) as a Linux cpulist, e.g. "64-127,192-255"; "" on a
    single-node host or where sysfs does not say.  The queue's hashing threads run there.  The staging buffers are pinned next to
    the GPU, so the thread that FILLS them (the capture thread: `src/capture.rs`) does well to run there too --
-   smhv_ingest_bind_thread binds the calling thread to them (SMHV_OK and nothing done when the list is empty).  Measured on a
+   smhv_ingest_bind_thread binds the calling thread to those of them its affinity mask already allows (SMHV_OK and nothing done when
+   the list is empty or fewer than two of its CPUs are allowed; the binding stays until the caller changes it).  The hashing threads
+   are bound the same way, and only when the allowed CPUs on the GPU's side are at least as many as the threads.  Measured on a
    two-socket MI355X host, 1080p frames, the queue alone: 11.8 k frames/s from the GPU's socket, 7.3 k from the other, 9.4-11.5 k
    when the scheduler chooses. */
 SMHV_API int smhv_ingest_local_cpus(smhv_ingest *q, char *buf, size_t cap);

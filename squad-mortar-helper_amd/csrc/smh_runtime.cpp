@@ -1161,9 +1161,11 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		// (above 1080p -- the frame sizes whose tile stores sit behind the compact index -- a service workgroup takes 130 KB of its CU's
 		// LDS whatever its waves: 128 x 1440p at depth 12, four waves per workgroup, 256 / 224 / 192 / 176 / 160 / 144 / 128 / 112
 		// workgroups: 212 / 225 / 245 / 255 / 263 / 271 / 267 / 243 k frames/s on the synthetic scene, 225 / 247 / 260 / 260 / 256 / 244 /
-		// 226 / 211 k on the reference's screenshots: five eighths of the CUs)
+		// 226 / 211 k on the reference's screenshots in round 5.  Round 6 -- the tile store built from the pass's tile-major mask, a
+		// frame 20 % cheaper -- 192 / 160 / 144 / 128 / 112 / 96 workgroups: - / 269 / 275 / 282 / 293 / 262 k synthetic, 261 / 276 / 273 / 253 /
+		// 231 / - k on the screenshots: nine sixteenths of the CUs)
 		const bool every_cu = p->svc_waves >= 4u && !p->svc_compact;
-		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(every_cu ? svc_cus : std::min(cus * 5 / 8, svc_cus), 1);
+		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(every_cu ? svc_cus : std::min(cus * 9 / 16, svc_cus), 1);
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ctl, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMemset(p->d_svc_ctl, 0, sizeof(SvcCtl));
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ring, sizeof(unsigned long long) << lg);
@@ -1189,9 +1191,12 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		p->batch[i]->lsd_bs = depth >= 2 ? 512u : 1024u;
 		p->batch[i]->lsd_prefer_classic = depth == 2 && lsd_rows_only(p->batch[i]->g);
 		if (p->svc && !p->adaptive) {
-			// no occupancy policy: the service's resident waves (one per SIMD, 136-144 registers each) are what caps the streaming
-			// pass at two workgroups per CU (three with the service at exactly 128 registers: measured, no difference --
-			// DESIGN.md A.-1); the streaming waves go first on their SIMD
+			// no occupancy policy: the service's resident waves (one per SIMD, 136-168 registers each) are what caps the streaming
+			// pass beside them -- at three workgroups per CU in its two-set form (112 registers), two in the three-set form (128).
+			// Round 5 ran the three-set form up to 1080p (the third workgroup cost the search more than it gave the pass); since the
+			// service builds its tile stores from the pass's tile-major mask it has the slack, and two sets are ahead everywhere
+			// (256 x 1080p, one box: 571-579 against 529-530 k frames/s).  SMHV_PIPE_THREE_LOAD_SETS: the old form, for A/B.
+			// The streaming waves go first on their SIMD
 			p->batch[i]->tune.map_prio = (opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u;
 			p->batch[i]->tune.map_deep = (opt.flags & SMHV_PIPE_THREE_LOAD_SETS) ? 1u : 0u;   // (a service workgroup on every CU: launch_map_brq_pass)
 		} else if (depth >= 3) {                                  // (an adaptive pipeline sets the tuning of a slot per submission)
@@ -2091,6 +2096,7 @@ struct smhv_ingest {
 	std::vector<int> crc_state;                              // 0 idle, 1 queued / being hashed, 2 done  (guarded by mu)
 	std::vector<std::thread> workers;
 	std::string local_cpus;                                  // the CPUs next to the GPU as a Linux cpulist ("": one node, or sysfs does not say)
+	size_t n_workers = 0;                                    // hashing threads (set before they start)
 	bool pin_workers = false;                                // the hashing threads run on them (unless SMHV_INGEST_NO_AFFINITY)
 	std::mutex mu;
 	std::condition_variable cv_job, cv_done;
@@ -2154,10 +2160,22 @@ static bool parse_cpulist(const std::string &text, cpu_set_t *set) {
 	return any;
 }
 
+// The GPU's CPUs this thread may actually run on: the list intersected with the thread's current affinity mask (a cpuset that
+// overlaps the GPU's node in one or two CPUs would otherwise collect every hashing thread on those).  -> CPUs in *set
+static int local_cpus_allowed(const std::string &local, cpu_set_t *set) {
+	cpu_set_t want, have;
+	if (!parse_cpulist(local, &want)) return 0;
+	CPU_ZERO(&have);
+	if (pthread_getaffinity_np(pthread_self(), sizeof have, &have) != 0) return 0;
+	CPU_AND(set, &want, &have);
+	return CPU_COUNT(set);
+}
+
 static void ingest_worker(smhv_ingest *q) {
 	if (q->pin_workers) {
 		cpu_set_t set;
-		if (parse_cpulist(q->local_cpus, &set)) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (best effort: a cpuset cgroup may say no)
+		// (only when the GPU's side has a CPU per hashing thread for us: fewer, and the threads are better off wherever the scheduler puts them)
+		if (local_cpus_allowed(q->local_cpus, &set) >= (int)std::max<size_t>(q->n_workers, 1)) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 	}
 	for (;;) {
 		uint32_t slot;
@@ -2303,11 +2321,10 @@ static int ingest_setup(smhv_ingest *q) {
 		// one worker per staging slot, within half the cores the process may actually use: a container's CPU quota (cgroup
 		// cpu.max) counts, not the host's thread count -- 32 hashing threads under a 16-core quota get throttled by the
 		// scheduler in 100 ms periods, and the queue's rate with them (6.7-10.7 k frames/s from run to run)
-		// (with the 512-bit CRC loop a worker is bound by what one core reads from memory, ~8 GB/s of a staging buffer that has
-		// left the caches: the cores are what scales -- all but two of the quota, the producer thread and the runtime's own keep those)
 		// (measured with the 512-bit CRC loop, a 16-core quota, the queue alone: 4 / 8 / 12 / 14 / 16 / 24 workers: 9.4 / 10.9 / 10.6 /
 		// 8.5 / 9.4 / 9.4 k frames/s -- past eight the hashing is not what bounds the queue, PCIe and the producer's own calls are)
 		const uint32_t nthreads = std::min<uint32_t>(q->slots, q->workers_opt ? q->workers_opt : std::max(2u, usable_cores() / 2u));
+		q->n_workers = nthreads;
 		for (uint32_t i = 0; i < nthreads; ++i) q->workers.emplace_back(ingest_worker, q);
 	}
 	return SMHV_OK;
@@ -2349,7 +2366,7 @@ extern "C" SMHV_API int smhv_ingest_local_cpus(smhv_ingest *q, char *buf, size_t
 extern "C" SMHV_API int smhv_ingest_bind_thread(smhv_ingest *q) {
 	if (!q) return fail(SMHV_E_INVALID, "ingest_bind_thread: no queue");
 	cpu_set_t set;
-	if (!parse_cpulist(q->local_cpus, &set)) return SMHV_OK;    // one node, or unknown: nothing to do
+	if (local_cpus_allowed(q->local_cpus, &set) < 2) return SMHV_OK;    // one node, unknown, or (nearly) nothing of the GPU's side in this thread's mask: left alone
 	const int e = pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 	if (e != 0) return fail(SMHV_E_STATE, "ingest_bind_thread: pthread_setaffinity_np: %s", strerror(e));
 	return SMHV_OK;

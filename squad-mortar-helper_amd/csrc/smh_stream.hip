@@ -970,11 +970,10 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 	}
 	if (tune && tune->map_prio) flags |= MAP_PRIO;
 	const uint32_t cap = tune ? tune->map_grid_cap : 0u;
-	// Loads in flight per wave: two register sets of four rows (one group ahead), or three (two groups ahead) where the launch
-	// says so -- the frame-granular pipeline up to 1080p, whose service workgroup on every CU leaves the pass two workgroups
-	// per CU.  Measured on one box, two sets / three sets: that pipeline 538 / 560 k frames/s; everything else is faster with
-	// two -- 128 x 1440p frame-granular 289 / 279 k, batch-granular 260 / 251 k, 256 x 1080p batch-granular at depth 4 458 / 445 k,
-	// 4K 128 / 126 k, the reference's screenshots 308 / 302 k; a launch alone takes the same time (DESIGN.md A.-1).
+	// Loads in flight per wave: two register sets of four rows (one group ahead: 107 registers, three workgroups per CU beside a
+	// search-service workgroup), or three (two groups ahead: 123 registers, two workgroups) where the launch asks for it
+	// (LaunchTuning::map_deep: SMHV_PIPE_THREE_LOAD_SETS, round 5's choice for frame-granular pipelines up to 1080p; since round 6
+	// two sets are ahead there too).  A launch alone takes the same time either way.
 	const bool deep = tune && tune->map_deep && !(cap && cap < items);
 #define SMH_LAUNCH_MAPQ(GRAYV, LOOPV, SETSV, GRID) \
 	hipLaunchKernelGGL((k_map_brq_pass<GRAYV, LOOPV, SETSV>), GRID, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items)
