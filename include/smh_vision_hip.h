@@ -233,6 +233,17 @@ SMHV_API int smhv_batch_run(smhv_batch *b, const void *d_frames, uint32_t n, uin
                             const smhv_anchors *anchors, void *stream);
 /* device pointers of the batch outputs (valid for the life of the batch) */
 SMHV_API int smhv_batch_device_ptrs(smhv_batch *b, void **d_results, void **d_ui, void **d_mask, void **d_ocr, void **d_scales, void **d_bits);
+/* The marker mask a third time, as the streaming passes leave it for the line search (and for any host kernel that wants the
+ * marker pixels without scanning a 1-4 % full image): TILE-MAJOR, 32 x 8 px tiles of the bit-packed rows -- tile (ty, wx) = rows
+ * 8 ty .. 8 ty + 7 of word column wx (bits_pitch_words word columns, bit (x + bits_xoff) of a row = pixel x), eight consecutive
+ * 32-bit words at d_tiled[frame * tile_rows * word_columns * 8 + (ty * word_columns + wx) * 8] -- written ONLY for tiles that hold a
+ * set bit, and one occupancy byte per (tile row, group of eight word columns) saying which: bit j of
+ * d_occ[frame * tile_rows * occ_pitch + ty * occ_pitch + g] = tile (ty, 8 g + j) is non-empty (every byte of an open frame's tile rows
+ * is written by every run with the markers stage).  Rows of the last tile row beyond the image are undefined.
+ * geometry[4] <- {tile_rows, word_columns, occ_pitch, bits_xoff}. */
+SMHV_API int smhv_batch_tile_mask(smhv_batch *b, void **d_tiled, void **d_occ, uint32_t geometry[4]);
+/* synchronising host copies of one frame's tile-major mask, occupancy bytes and bit-packed rows (any of them may be NULL) */
+SMHV_API int smhv_batch_read_tile_mask(smhv_batch *b, uint32_t frame, uint32_t *tiled, uint8_t *occ, uint32_t *bits);
 /* synchronising host copies (tightly packed) */
 SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, uint32_t n, smhv_frame_result *out);
 SMHV_API int smhv_batch_read_image(smhv_batch *b, int which /* SMHV_VIEW_* or 100 = ui_map RGBA */, uint32_t frame, uint8_t *out);

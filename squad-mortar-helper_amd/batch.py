@@ -109,6 +109,18 @@ class FrameBatch:
         L.check(self._lib.smhv_batch_device_ptrs(self._b, *[C.byref(x) for x in p]))
         return dict(zip(("results", "ui", "mask", "ocr", "scales", "bits"), [x.value for x in p]))
 
+    def tile_mask(self, frame=0):
+        """The marker mask of one frame as the streaming passes leave it for the line search: (tiled uint32[tile_rows, word_columns, 8],
+        occ uint8[tile_rows, occ_pitch], bits uint32[rows, word_columns], bits_xoff) -- include/smh_vision_hip.h, smhv_batch_tile_mask."""
+        geo = (C.c_uint32 * 4)()
+        L.check(self._lib.smhv_batch_tile_mask(self._b, None, None, geo))
+        trows, wcols, opitch, xoff = [int(v) for v in geo]
+        tiled = np.zeros((trows, wcols, 8), np.uint32)
+        occ = np.zeros((trows, opitch), np.uint8)
+        bits = np.zeros((self.roi[3], wcols), np.uint32)
+        L.check(self._lib.smhv_batch_read_tile_mask(self._b, frame, tiled.ctypes.data, occ.ctypes.data, bits.ctypes.data))
+        return tiled, occ, bits, xoff
+
     def read_results(self, first=0, n=None, check=True):
         """Synchronising host copy of the records.  A frame the library gave up (status != 0 in its record) makes the call
         raise VisionError(E_STATE) -- the reference drops a frame on any Err (src/vision/mod.rs:272-276); check=False returns

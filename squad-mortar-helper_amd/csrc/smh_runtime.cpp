@@ -846,6 +846,25 @@ extern "C" SMHV_API int smhv_batch_device_ptrs(smhv_batch *b, void **r, void **u
 	return SMHV_OK;
 }
 
+extern "C" SMHV_API int smhv_batch_tile_mask(smhv_batch *b, void **d_tiled, void **d_occ, uint32_t geometry[4]) {
+	if (!b) return fail(SMHV_E_INVALID, "null batch");
+	if (d_tiled) *d_tiled = b->d_tiled;
+	if (d_occ) *d_occ = b->d_occ;
+	if (geometry) { geometry[0] = tiled_rows(b->g); geometry[1] = b->g.bits_pitch_w; geometry[2] = occ_pitch(b->g); geometry[3] = b->g.m_xoff; }
+	return SMHV_OK;
+}
+
+extern "C" SMHV_API int smhv_batch_read_tile_mask(smhv_batch *b, uint32_t frame, uint32_t *tiled, uint8_t *occ, uint32_t *bits) {
+	if (!b || frame >= b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
+	HIPCHK(hipSetDevice(b->ctx->device));
+	HIPCHK(hipDeviceSynchronize());
+	const Geom &g = b->g;
+	if (tiled) HIPCHK(hipMemcpy(tiled, b->d_tiled + (size_t)frame * tiled_stride_w(g), tiled_stride_w(g) * 4, hipMemcpyDeviceToHost));
+	if (occ) HIPCHK(hipMemcpy(occ, b->d_occ + (size_t)frame * occ_stride(g), occ_stride(g), hipMemcpyDeviceToHost));
+	if (bits) HIPCHK(hipMemcpy(bits, b->d_bits + (size_t)frame * g.bits_stride_w, g.bits_stride_w * 4, hipMemcpyDeviceToHost));
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, uint32_t n, smhv_frame_result *out) {
 	if (!b || !out || (uint64_t)first + n > b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
 	HIPCHK(hipSetDevice(b->ctx->device));

@@ -402,6 +402,60 @@ def test_search_service_1440p_geometry_with_frames_beyond_its_tile_store(vision)
     pipe.close()
 
 
+@pytest.mark.parametrize("size", [(1920, 1080), (2560, 1440), (1024, 768), (1280, 1024), (1600, 1024), (3840, 2160)])
+def test_tile_major_mask_of_the_streaming_passes(vision, size):
+    """What the streaming passes leave for the line search (include/smh_vision_hip.h, smhv_batch_tile_mask): the occupancy bytes name
+    exactly the non-empty 32 x 8 tiles of the bit-packed rows, and every such tile holds those rows' words -- for the fused pass
+    (all stages) and the plain one (markers only), with few frames (bands of 8 rows) and with enough of them for full-height bands;
+    and the bit rows themselves are the oracle's dilated mask."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    W, H = size
+    x, y, rw, rh = smh.map_bounds(W, H)
+    for n in (1, 40):
+        host = torch.empty((n, H, W, 4), dtype=torch.uint8, pin_memory=True)
+        frames = host.numpy()
+        _, infos = synth.make_batch(W, H, n, first_idx=7000 + n, n_lines=3, out=frames)
+        # marker pixels on the ROI's first and last columns and rows, and across a tile-row / band boundary
+        frames[0, y:y + 3, x:x + 70] = GREEN
+        frames[0, y + rh - 2:y + rh, x + rw - 40:x + rw] = GREEN
+        frames[0, y + 50:y + 62, x:x + 2] = PURPLE
+        frames[0, y + 100:y + 130, x + rw - 1:x + rw] = PURPLE
+        if n > 1:
+            frames[n - 1], infos[n - 1] = synth.make_frame(W, H, 7999, n_lines=0)       # an open frame without a marker pixel
+        anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
+        d = host.cuda()
+        fb = smh.FrameBatch(vision, W, H, n)
+        s = torch.cuda.current_stream().cuda_stream
+        want_mask = {f: o.process_frame(frames[f], stages=0x1, want_images=True)["lsd"] for f in sorted({0, n // 2, n - 1})}
+        for stages, anc in ((smh.STAGE_ALL, anchors), (smh.STAGE_MARKERS, None)):
+            fb.run(d.data_ptr(), n, stages=stages, anchors=anc, stream=s)
+            for f in sorted(want_mask):
+                tiled, occ, bits, xoff = fb.tile_mask(f)
+                trows, wcols, _ = tiled.shape
+                assert trows == (rh + 7) // 8 and bits.shape == (rh, wcols)
+                # the bit rows are the oracle's mask (bit x + xoff of row y = pixel x)
+                px = np.zeros((rh, wcols * 32), np.uint8)
+                px[:, xoff:xoff + rw] = want_mask[f] != 0
+                want_bits = np.packbits(px.reshape(rh, wcols, 32), axis=2, bitorder="little").view(np.uint32).reshape(rh, wcols)
+                assert np.array_equal(bits, want_bits), (size, n, stages, f)
+                # occupancy == non-empty tiles of those rows; the tiles' words == the rows' words
+                padded = np.zeros((trows * 8, wcols), np.uint32)
+                padded[:rh] = bits
+                by_tile = padded.reshape(trows, 8, wcols).transpose(0, 2, 1)            # [ty, wx, r]
+                nonempty = by_tile.any(axis=2)
+                got_occ = np.unpackbits(occ, axis=1, bitorder="little")[:, :wcols].astype(bool)
+                assert np.array_equal(got_occ, nonempty), (size, n, stages, f, int(nonempty.sum()), int(got_occ.sum()))
+                tail = rh - (trows - 1) * 8                                               # rows of the last tile row inside the image
+                a, b_ = tiled[nonempty], by_tile[nonempty]
+                last = np.repeat(np.arange(trows)[:, None], wcols, axis=1)[nonempty] == trows - 1
+                assert np.array_equal(a[~last], b_[~last]) and np.array_equal(a[last][:, :tail], b_[last][:, :tail]), (size, n, stages, f)
+            if n > 1:
+                assert not fb.tile_mask(n - 1)[1].any()                                   # no marker pixel: every occupancy byte written, all zero
+        fb.close()
+
+
 def test_8k_frames_take_the_large_tile_index(vision):
     """7680x4320: the 16-bit tile index of the map ROI alone is 106 KB, so k_lsd_tile runs one workgroup per CU with 140 KB of
     dynamic LDS instead of two with 60 KB each.  Two synthetic frames, both line-search kernels, against the oracle."""
