@@ -149,7 +149,7 @@ class PipelineOptions(C.Structure):
 
 
 SEARCH_AUTO, SEARCH_BATCH, SEARCH_FRAME = 0, 1, 2
-PIPE_NO_TEAM_HELP, PIPE_NO_STREAM_PRIORITY, PIPE_NO_PROLOGUE, PIPE_NO_REMOTE_HELP, PIPE_HELP_FIRST = 1, 2, 4, 8, 16
+PIPE_NO_TEAM_HELP, PIPE_NO_STREAM_PRIORITY, PIPE_NO_PROLOGUE, PIPE_NO_REMOTE_HELP, PIPE_HELP_FIRST, PIPE_WALK_BIT_ROWS, PIPE_THREE_LOAD_SETS = 1, 2, 4, 8, 16, 32, 64
 
 
 class VisionError(RuntimeError):

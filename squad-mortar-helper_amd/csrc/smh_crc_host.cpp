@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "../../include/smh_vision_hip.h"
+#include "../../include/smh_vision_hip_debug.h"
 
 namespace {
 

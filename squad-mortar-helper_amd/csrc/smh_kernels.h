@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/smh_vision_hip.h"
+#include "../../include/smh_vision_hip_debug.h"
 
 namespace smh {
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/smh_vision_hip.h"
+#include "../../include/smh_vision_hip_debug.h"
 
 extern "C" int smhv_internal_fail(int code, const char *fmt, ...);          // smh_runtime.cpp: sets smhv_last_error
 

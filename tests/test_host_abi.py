@@ -1,4 +1,4 @@
-"""CPU tests (no GPU): the C-ABI library loads, exports every symbol include/smh_vision_hip.h declares,
+"""CPU tests (no GPU): the C-ABI library loads, exports every symbol include/*.h declares,
 its host-side logic (bounds arithmetic, error reporting, record layout) is right, and the
 multi-process gather path works (gloo, world_size 2)."""
 import ctypes as C
@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "smh_vision_hip.h")).read()
+    # the boundary (smh_vision_hip.h) and the diagnostics beside it (smh_vision_hip_debug.h): everything include/*.h declares
+    txt = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.endswith(".h"))
     return sorted(set(re.findall(r"SMHV_API\s+[\w\s\*]+?\b(smhv_\w+)\s*\(", txt)))
 
 
@@ -102,7 +103,9 @@ def test_pipeline_options_and_flags_match_the_header(built):
         (_lib.PIPE_NO_TEAM_HELP, _lib.PIPE_NO_STREAM_PRIORITY, _lib.PIPE_NO_PROLOGUE)
     assert (int(defs["SMHV_PIPE_NO_REMOTE_HELP"]), int(defs["SMHV_PIPE_HELP_FIRST"])) == (_lib.PIPE_NO_REMOTE_HELP, _lib.PIPE_HELP_FIRST)
     assert int(defs["SMHV_INGEST_ROI_UPLOAD"]) == 1 and int(defs["SMHV_INGEST_NO_AFFINITY"]) == 2 and sorted(k for k in defs if k.startswith("SMHV_PIPE_")) == \
-        ["SMHV_PIPE_HELP_FIRST", "SMHV_PIPE_NO_PROLOGUE", "SMHV_PIPE_NO_REMOTE_HELP", "SMHV_PIPE_NO_STREAM_PRIORITY", "SMHV_PIPE_NO_TEAM_HELP"]
+        ["SMHV_PIPE_HELP_FIRST", "SMHV_PIPE_NO_PROLOGUE", "SMHV_PIPE_NO_REMOTE_HELP", "SMHV_PIPE_NO_STREAM_PRIORITY", "SMHV_PIPE_NO_TEAM_HELP", "SMHV_PIPE_THREE_LOAD_SETS",
+         "SMHV_PIPE_WALK_BIT_ROWS"]
+    assert (int(defs["SMHV_PIPE_WALK_BIT_ROWS"]), int(defs["SMHV_PIPE_THREE_LOAD_SETS"])) == (_lib.PIPE_WALK_BIT_ROWS, _lib.PIPE_THREE_LOAD_SETS)
     src = os.path.join(os.environ.get("TMPDIR", "/tmp"), "smhv_opt_size.c")
     exe = src[:-2]
     with open(src, "w") as f:
