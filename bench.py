@@ -514,7 +514,7 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     CRC repeats.  `frames_per_s`: region-of-interest upload (whole-frame CRC-32 on the host cores, one worker per staging
     slot; only the map ROI's and the button's rows cross PCIe); `full_upload_frames_per_s`: the whole frame crosses and the
     device computes the CRC (the mode a device-side producer or a decoded RGB image uses), on a quarter of the frames."""
-    def run(roi, slots, total):
+    def run(roi, slots, total, native=True):
         qs = [smh.IngestQueue(vision, W, H, slots=slots, capacity=n, roi_upload=roi, affinity=affinity) for _ in range(2)]
         for q in qs:                                           # prime the staging buffers (their content persists)
             for i in range(slots):
@@ -540,11 +540,14 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
             if pending[b % 2] is not None:
                 pipe.wait(pending[b % 2])                      # the previous run on this queue's slab has finished
             q.reset()
-            for _ in range(n):
-                buf = q.acquire()
-                buf[0, 0, :] = (counter & 255, (counter >> 8) & 255, (counter >> 16) & 255, 255)
-                counter += 1
-                q.commit()
+            if native:
+                counter = q.feed(n, counter)                   # the capture loop in native code, as the reference's is (src/capture.rs)
+            else:
+                for _ in range(n):
+                    buf = q.acquire()
+                    buf[0, 0, :] = (counter & 255, (counter >> 8) & 255, (counter >> 16) & 255, 255)
+                    counter += 1
+                    q.commit()
             ptr, cnt, _ = q.batch()
             assert cnt == n, "ingest dropped frames: %d of %d" % (cnt, n)
             pending[b % 2] = pipe.submit(ptr, cnt, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
@@ -558,6 +561,9 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     thr0 = cpu_throttled()
     qs, frames, dt = run(True, slots, frames_total)
     thr1 = cpu_throttled()
+    for q in qs:
+        q.close()
+    qs, frames_py, dt_py = run(True, slots, max(2 * n, frames_total // 4), native=False)   # the same with a Python capture loop (three ctypes calls per frame)
     local_cpus = qs[0].local_cpus()
     q = qs[0]
     q.reset()
@@ -589,7 +595,41 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
         for b_ in bufs:
             lib.smhv_crc32_host(C.c_void_p(b_.ctypes.data), b_.nbytes)
     crc_one = 3 * sum(b_.nbytes for b_ in bufs) / (time.perf_counter() - t1) / 1e9
+    # what THIS box's link gives pinned host memory -> HBM, for the figure above to be read against: copies of the packed size
+    # (3.3 MB at 1080p) round robin on three streams (what the queue does), and one 256 MB copy (the link's best case)
+    ceil_GBps = ceil_big_GBps = None
+    try:
+        pack = (rw * rh + bw * bh) * 4
+        hsrc = torch.empty(pack * 24, dtype=torch.uint8, pin_memory=True)
+        ddst = torch.empty(pack * 24, dtype=torch.uint8, device="cuda")
+        sts = [torch.cuda.Stream() for _ in range(3)]
+        for timed_round in (False, True):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 20 if timed_round else 2
+            for r_ in range(reps):
+                for i in range(24):
+                    with torch.cuda.stream(sts[i % 3]):
+                        ddst[i * pack:(i + 1) * pack].copy_(hsrc[i * pack:(i + 1) * pack], non_blocking=True)
+            torch.cuda.synchronize()
+            ceil_GBps = reps * 24 * pack / (time.perf_counter() - t1) / 1e9
+        big = torch.empty(256 << 20, dtype=torch.uint8, pin_memory=True)
+        dbig = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        for timed_round in (False, True):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(4):
+                dbig.copy_(big, non_blocking=True)
+            torch.cuda.synchronize()
+            ceil_big_GBps = 4 * (256 << 20) / (time.perf_counter() - t1) / 1e9
+        del hsrc, ddst, big, dbig
+    except Exception as e:  # noqa: BLE001  (calibration only)
+        print("bench.py: H2D ceiling not measured: %s" % e, file=sys.stderr)
     return {"frames_per_s": frames / dt, "frames": frames, "mode": "roi_upload", "staging_slots": slots, "host_cores": cores,
+            "producer": "native capture loop (smhv_debug_ingest_feed: acquire, stamp pixel (0,0), commit -- the reference's capture thread is native code, src/capture.rs)",
+            "python_producer_frames_per_s": frames_py / dt_py,
+            "h2d_ceiling_GBps": {"packed_copies_three_streams": ceil_GBps, "one_256MB_copy": ceil_big_GBps,
+                                 "what": "pinned host memory -> HBM on this box, measured here: copies of the queue's packed size round robin on three streams / one large copy"},
             "host_crc_GBps": frames * W * H * 4 / dt / 1e9, "host_crc_loop": {2: "VPCLMULQDQ (512-bit folding)", 1: "PCLMULQDQ", 0: "tables"}.get(crc_level, "?"),
             "host_crc_GBps_one_thread": crc_one, "uploaded_fraction": round((rw * rh + bw * bh) / float(W * H), 3),
             "h2d_GBps": frames * (rw * rh + bw * bh) * 4 / dt / 1e9,

@@ -75,6 +75,12 @@ SMHV_API int smhv_debug_marker_table(smhv_ctx *ctx, uint32_t *bits);
  * 1: PCLMULQDQ (128-bit lanes), 0: slicing-by-8 tables; a loop the machine lacks falls back to the next lower one.  Returns the
  * machine's level (what smhv_crc32_host and the ingest workers use); level < 0 (data may be NULL) only reports it. */
 SMHV_API int smhv_debug_crc32_host_level(const void *data, uint64_t nbytes, int level, uint32_t *crc);
+/* benchmark driver: a NATIVE capture loop for the ingest queue (the reference's capture thread is native code, src/capture.rs) --
+ * n times: smhv_ingest_acquire, stamp the 24-bit value (*counter)++ into pixel (0, 0) of the staging buffer (whose other
+ * pixels keep what they last held; (0, 0) lies outside every region the path reads, so every frame hashes differently and
+ * computes the same), smhv_ingest_commit.  What a Python loop spends per frame on three ctypes calls (~90 us: 11 k frames/s)
+ * is the interpreter's, not the queue's. */
+SMHV_API int smhv_debug_ingest_feed(smhv_ingest *q, uint32_t n, uint32_t *counter);
 
 #ifdef __cplusplus
 }

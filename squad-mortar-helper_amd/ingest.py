@@ -85,6 +85,13 @@ class IngestQueue:
     def commit(self):
         check(self._lib.smhv_ingest_commit(self._q))
 
+    def feed(self, n, counter):
+        """Benchmark driver (smhv_debug_ingest_feed): a native capture loop -- n x (acquire, stamp a fresh 24-bit counter into pixel
+        (0, 0), commit) without the interpreter between the frames.  -> the counter after the last frame."""
+        c = C.c_uint32(int(counter) & 0xFFFFFFFF)
+        check(self._lib.smhv_debug_ingest_feed(self._q, int(n), C.byref(c)))
+        return int(c.value)
+
     def push(self, frame):
         """Frame in ordinary host memory: one extra host copy into the staging buffer."""
         a = np.ascontiguousarray(frame, dtype=np.uint8)

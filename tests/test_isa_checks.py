@@ -37,7 +37,7 @@ def test_build_falls_back_to_tracked_loads_when_the_check_fails(tmp_path):
 
 def test_the_search_service_has_no_scratch_access_inside_a_loop():
     """tools/scratch_in_loops.py on the compiled search service (k_lsd_service and the two noinline bodies it calls, svc_frame and
-    svc_help): spills are allowed in prologues / epilogues (loop depth 0) only.  A wave that shares its CU with the HBM-bound
+    svc_help): spills are allowed in prologues / epilogues (loop depth 0) only -- and once per frame around the call of the frame's body.  A wave that shares its CU with the HBM-bound
     streaming pass waits microseconds for every vector-memory access; fifteen reloads in the candidate loop once made the scan
     twice as slow.  (Reading a whole 32-sample batch of window samples at once -- SEQ_RAY_GROUP = 32 -- failed exactly
     this while the wave was held to 128 registers; with its budget at 168, round 5, it passes.)"""
@@ -49,6 +49,11 @@ def test_the_search_service_has_no_scratch_access_inside_a_loop():
     names = " ".join(rows)
     assert "k_lsd_service" in names and "svc_frame" in names, p.stdout
     for ln in rows:
-        depths = [int(d) for d in re.findall(r"(\d+): \[", ln.split("by loop depth:")[1])]
-        assert all(d == 0 for d in depths), ln
+        by = {int(d): (int(a), int(b)) for d, a, b in re.findall(r"(\d+): \[(\d+), (\d+)\]", ln.split("by loop depth:")[1])}
+        if "k_lsd_service" in ln.split()[0]:
+            # the kernel's own outermost loop takes one FRAME per iteration: the register that holds its spilled scalars may be
+            # saved around the call of the frame's body there (one store, one reload per frame) -- nothing deeper, nothing more
+            assert all(d <= 1 for d in by) and by.get(1, (0, 0)) <= (1, 1), ln
+        else:
+            assert all(d == 0 for d in by), ln
 

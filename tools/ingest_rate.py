@@ -11,7 +11,19 @@ src, _ = synth.make_batch(W, H, 16, first_idx=0)
 vision = smh.HipVision.init(0)
 for workers in [int(a) for a in sys.argv[1:]] or [0]:
     for slots in (32,):
-        q = smh.IngestQueue(vision, W, H, slots=slots, capacity=n, roi_upload=True, workers=workers)
+        # INGEST_CREATE_ON=far|near: where the CREATING thread sits while the queue allocates its pinned staging buffers (experiment: does their
+        # NUMA placement follow the creator?); INGEST_AFFINITY=0: the library neither binds its hashing threads nor allocates on the GPU's side
+        want = os.environ.get("INGEST_CREATE_ON")
+        if want:
+            probe = smh.IngestQueue(vision, W, H, slots=2, capacity=2, roi_upload=True)
+            local = set(probe.local_cpus()); probe.close()
+            allcpu = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, (allcpu - local) if want == "far" else (allcpu & local))
+        q = smh.IngestQueue(vision, W, H, slots=slots, capacity=n, roi_upload=True, workers=workers, affinity=os.environ.get("INGEST_AFFINITY", "1") != "0")
+        if want:
+            os.sched_setaffinity(0, allcpu)
+        if not os.environ.get("INGEST_NO_BIND"):
+            q.bind_thread()                                # the producer on the GPU's socket, as bench.py's leg does (7 k against 11 k frames/s from the other one)
         for i in range(slots):
             q.acquire()[...] = src[i % len(src)]
             q.commit()
@@ -20,11 +32,14 @@ for workers in [int(a) for a in sys.argv[1:]] or [0]:
         t0 = time.perf_counter()
         for b in range(6):
             q.reset()
-            for _ in range(n):
-                buf = q.acquire()
-                buf[0, 0, :] = (counter & 255, (counter >> 8) & 255, (counter >> 16) & 255, 255)
-                counter += 1
-                q.commit()
+            if os.environ.get("INGEST_PYTHON_LOOP"):
+                for _ in range(n):
+                    buf = q.acquire()
+                    buf[0, 0, :] = (counter & 255, (counter >> 8) & 255, (counter >> 16) & 255, 255)
+                    counter += 1
+                    q.commit()
+            else:
+                counter = q.feed(n, counter)                  # native capture loop (smhv_debug_ingest_feed)
             ptr, cnt, _ = q.batch()
             total += cnt
         torch.cuda.synchronize()
