@@ -28,7 +28,7 @@ def main():
     for it in range(iters):
         sizes = [(1280, 1024), (1920, 1080), (1024, 768), (2560, 1440), (1600, 1024)]
         if os.environ.get("FUZZ_SERVICE"):
-            sizes += [(2560, 1440), (3840, 2160)]               # (above 1080p the service's tile stores sit behind the compact index; 4K: two groups of tile columns per row)
+            sizes += [(2560, 1440), (3840, 2160), (5120, 1440), (800, 600), (1366, 768)]   # (round 6: sixteen waves of the pass per row = four occupancy dwords per tile row; bit rows that start ON pixel 0 (m_xoff 0); above 1080p the service's tile stores sit behind the compact index; 4K: two groups of tile columns per row)
         W, H = sizes[int(rng.integers(0, len(sizes)))]
         max_gap = int(rng.choice([15, 15, 22, 9, 3, 30, 45, 49, 50, 1]))
         frames = np.stack([scene(rng, W, H, 1000 * it + i, max_gap) for i in range(n)])
