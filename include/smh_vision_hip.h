@@ -239,11 +239,14 @@ SMHV_API int smhv_batch_device_ptrs(smhv_batch *b, void **d_results, void **d_ui
  * 32-bit words at d_tiled[frame * tile_rows * word_columns * 8 + (ty * word_columns + wx) * 8] -- written ONLY for tiles that hold a
  * set bit, and one occupancy byte per (tile row, group of eight word columns) saying which: bit j of
  * d_occ[frame * tile_rows * occ_pitch + ty * occ_pitch + g] = tile (ty, 8 g + j) is non-empty (every byte of an open frame's tile rows
- * is written by every run with the markers stage).  Rows of the last tile row beyond the image are undefined.
+ * is written).  Rows of the last tile row beyond the image are undefined.  A run writes them when its bands are whole tile rows --
+ * the library takes such bands where they cost the streaming pass nothing or pay (ROIs up to 900 rows, i.e. frames up to 1080p, and
+ * every size whose band count does not grow by it); smhv_batch_read_tile_mask reports per frame whether the last run did.
  * geometry[4] <- {tile_rows, word_columns, occ_pitch, bits_xoff}. */
 SMHV_API int smhv_batch_tile_mask(smhv_batch *b, void **d_tiled, void **d_occ, uint32_t geometry[4]);
-/* synchronising host copies of one frame's tile-major mask, occupancy bytes and bit-packed rows (any of them may be NULL) */
-SMHV_API int smhv_batch_read_tile_mask(smhv_batch *b, uint32_t frame, uint32_t *tiled, uint8_t *occ, uint32_t *bits);
+/* synchronising host copies of one frame's tile-major mask, occupancy bytes and bit-packed rows (any of them may be NULL);
+ * *written <- 1 when the last run over that frame wrote the tile-major mask and the occupancy bytes, 0 when it wrote the bit rows only */
+SMHV_API int smhv_batch_read_tile_mask(smhv_batch *b, uint32_t frame, uint32_t *tiled, uint8_t *occ, uint32_t *bits, int *written);
 /* synchronising host copies (tightly packed) */
 SMHV_API int smhv_batch_read_results(smhv_batch *b, uint32_t first, uint32_t n, smhv_frame_result *out);
 SMHV_API int smhv_batch_read_image(smhv_batch *b, int which /* SMHV_VIEW_* or 100 = ui_map RGBA */, uint32_t frame, uint8_t *out);

@@ -88,7 +88,7 @@ SIGNATURES = {
     "smhv_batch_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
     "smhv_batch_device_ptrs": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_void_p)] * 6),
     "smhv_batch_tile_mask": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
-    "smhv_batch_read_tile_mask": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smhv_batch_read_tile_mask": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "smhv_batch_read_results": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(FrameResult)]),
     "smhv_batch_read_image": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
     "smhv_batch_set_scales_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

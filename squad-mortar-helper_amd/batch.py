@@ -111,15 +111,17 @@ class FrameBatch:
 
     def tile_mask(self, frame=0):
         """The marker mask of one frame as the streaming passes leave it for the line search: (tiled uint32[tile_rows, word_columns, 8],
-        occ uint8[tile_rows, occ_pitch], bits uint32[rows, word_columns], bits_xoff) -- include/smh_vision_hip.h, smhv_batch_tile_mask."""
+        occ uint8[tile_rows, occ_pitch], bits uint32[rows, word_columns], bits_xoff) -- include/smh_vision_hip.h, smhv_batch_tile_mask.
+        tiled and occ are None when the last run wrote the bit rows only (bands that are not whole tile rows)."""
         geo = (C.c_uint32 * 4)()
         L.check(self._lib.smhv_batch_tile_mask(self._b, None, None, geo))
         trows, wcols, opitch, xoff = [int(v) for v in geo]
         tiled = np.zeros((trows, wcols, 8), np.uint32)
         occ = np.zeros((trows, opitch), np.uint8)
         bits = np.zeros((self.roi[3], wcols), np.uint32)
-        L.check(self._lib.smhv_batch_read_tile_mask(self._b, frame, tiled.ctypes.data, occ.ctypes.data, bits.ctypes.data))
-        return tiled, occ, bits, xoff
+        written = C.c_int(0)
+        L.check(self._lib.smhv_batch_read_tile_mask(self._b, frame, tiled.ctypes.data, occ.ctypes.data, bits.ctypes.data, C.byref(written)))
+        return (tiled if written.value else None), (occ if written.value else None), bits, xoff
 
     def read_results(self, first=0, n=None, check=True):
         """Synchronising host copy of the records.  A frame the library gave up (status != 0 in its record) makes the call

@@ -36,7 +36,7 @@ struct FrameAux {
 	uint32_t red;         // red pixel count
 	uint32_t n_mask_px;   // popcount of the dilated mask
 	uint32_t y_min, y_max, w_min, w_max;  // bounding box of set bits: rows, and words of the bit-packed rows
-	uint32_t pad;
+	uint32_t tiles;       // 1: the pass that wrote this frame's mask also wrote it tile-major with occupancy bytes (bands of whole tile rows)
 };
 
 // ---- cooperation between the workgroups of one k_lsd launch (smh_lsd.hip) ---------------------------------------
@@ -155,8 +155,9 @@ struct Buffers {
 //   occ    one byte per (tile row, wave of the pass): bit j = tile (ty, 8 wave + j) holds a set bit.  Every band of an open frame
 //          writes the bytes of its tile rows (zeros too), so nothing stale is ever read.
 // The builder reads the occupancy bytes of the bounding box's tile rows (one coalesced load) and then exactly the non-empty
-// tiles (32 contiguous bytes each, all in flight together): 2-3 round trips and 4-9 KB.  Bands are a multiple of 8 rows tall
-// for this (56 instead of 58: still 15 bands at 1080p).
+// tiles (32 contiguous bytes each, all in flight together): 2-3 round trips and 4-9 KB.  Bands have to be a multiple of 8 rows tall
+// for this (56 instead of 58: still 15 bands at 1080p, but 20 instead of 19 at 1440p): a launch takes them where they are free or
+// pay (band_rows_for, smh_stream.hip) and says so per frame in FrameAux::tiles; otherwise the search walks the bit rows as before.
 __host__ __device__ inline uint32_t tiled_rows(const Geom &g) { return (g.rh + 7u) >> 3; }
 __host__ __device__ inline uint64_t tiled_stride_w(const Geom &g) { return (uint64_t)tiled_rows(g) * g.bits_pitch_w * 8u; }
 __host__ __device__ inline uint32_t occ_pitch(const Geom &g) { return ((g.m_block >> 6) + 3u) & ~3u; }
@@ -301,7 +302,8 @@ enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u, MAP_PRIO = 0x100u };
 enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
-hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s);
+// tiles_wanted: the batch path (the mask also tile-major where the bands allow it: band_rows_for); the per-call path leaves it
+hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s, bool tiles_wanted = false);
 // map pass + quadrant pass in one (the quadrant pixels are read once); flags: MAP_*, qflags: BRQ_*
 // Occupancy policy of a pipelined batch (smhv_pipeline_create).  A streaming workgroup beyond the two per
 // CU that saturate HBM only waits in the memory queues -- while holding wave slots and registers the other batches' line

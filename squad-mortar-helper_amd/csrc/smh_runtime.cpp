@@ -724,7 +724,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[0], s));
 	STAGE_BEGIN(1, s);
 	if (mflags && qflags) HIPCHK(launch_map_brq_pass(g, bf, n, mflags, qflags, grayscale, 0, 1, s, &b->tune));
-	else if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s));
+	else if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s, true));
 	STAGE_END(1, s);
 	STAGE_BEGIN(2, s);
 	if (qflags && !mflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));
@@ -854,7 +854,7 @@ extern "C" SMHV_API int smhv_batch_tile_mask(smhv_batch *b, void **d_tiled, void
 	return SMHV_OK;
 }
 
-extern "C" SMHV_API int smhv_batch_read_tile_mask(smhv_batch *b, uint32_t frame, uint32_t *tiled, uint8_t *occ, uint32_t *bits) {
+extern "C" SMHV_API int smhv_batch_read_tile_mask(smhv_batch *b, uint32_t frame, uint32_t *tiled, uint8_t *occ, uint32_t *bits, int *written) {
 	if (!b || frame >= b->max_frames) return fail(SMHV_E_INVALID, "bad arguments");
 	HIPCHK(hipSetDevice(b->ctx->device));
 	HIPCHK(hipDeviceSynchronize());
@@ -862,6 +862,11 @@ extern "C" SMHV_API int smhv_batch_read_tile_mask(smhv_batch *b, uint32_t frame,
 	if (tiled) HIPCHK(hipMemcpy(tiled, b->d_tiled + (size_t)frame * tiled_stride_w(g), tiled_stride_w(g) * 4, hipMemcpyDeviceToHost));
 	if (occ) HIPCHK(hipMemcpy(occ, b->d_occ + (size_t)frame * occ_stride(g), occ_stride(g), hipMemcpyDeviceToHost));
 	if (bits) HIPCHK(hipMemcpy(bits, b->d_bits + (size_t)frame * g.bits_stride_w, g.bits_stride_w * 4, hipMemcpyDeviceToHost));
+	if (written) {
+		FrameAux a;
+		HIPCHK(hipMemcpy(&a, b->d_aux + frame, sizeof a, hipMemcpyDeviceToHost));
+		*written = a.tiles ? 1 : 0;
+	}
 	return SMHV_OK;
 }
 
@@ -1182,7 +1187,9 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		// workgroups: 212 / 225 / 245 / 255 / 263 / 271 / 267 / 243 k frames/s on the synthetic scene, 225 / 247 / 260 / 260 / 256 / 244 /
 		// 226 / 211 k on the reference's screenshots in round 5.  Round 6 -- the tile store built from the pass's tile-major mask, a
 		// frame 20 % cheaper -- 192 / 160 / 144 / 128 / 112 / 96 workgroups: - / 269 / 275 / 282 / 293 / 262 k synthetic, 261 / 276 / 273 / 253 /
-		// 231 / - k on the screenshots: nine sixteenths of the CUs)
+		// 231 / - k on the screenshots; and with the walk over the bit rows (those frame sizes keep it: the 56-row bands of the tile-major mask
+		// would cost the pass a band, band_rows_for) 144 against 160 workgroups: 296-297 against 287-288 k synthetic, 272-274 against 276 k on the
+		// screenshots: nine sixteenths of the CUs)
 		const bool every_cu = p->svc_waves >= 4u && !p->svc_compact;
 		p->svc_wgs = opt.service_workgroups ? opt.service_workgroups : (uint32_t)std::max(every_cu ? svc_cus : std::min(cus * 9 / 16, svc_cus), 1);
 		if (e == hipSuccess) e = hipMalloc((void **)&p->d_svc_ctl, sizeof(SvcCtl));

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_ope
 		FrameAux a;
 		a.open = (force_open || !(ratio < SMH_BUTTON_RED_PIXEL_THRESHOLD)) ? 1u : 0u;
 		a.red = red; a.n_mask_px = 0;
-		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.pad = 0;
+		a.y_min = 0xFFFFFFFFu; a.y_max = 0; a.w_min = 0xFFFFFFFFu; a.w_max = 0; a.tiles = 0;
 		b.aux[f] = a;
 	}
 }
@@ -103,11 +103,11 @@ __global__ void __launch_bounds__(256) k_button(Geom g, Buffers b, int force_ope
 // instructions per band instead of a second pass over an intermediate image.  ui_map is written
 // straight from the loaded registers; the frame is read exactly once (+2 halo rows per band).
 // ------------------------------------------------------------------------------------------------
-// (rows per band: a multiple of 8, so that a band is a whole number of the line search's tile rows -- the pass writes the mask
-// tile-major as well, smh_kernels.h; the column masks would hold 62)
-#define MAP_RB_MAX 56
+// (rows per band: the column masks hold 1 + 62 + 1; band_rows_for takes 56 -- whole tile rows of the line search: the pass then
+// writes the mask tile-major as well, smh_kernels.h -- where that does not cost the launch a band)
+#define MAP_RB_MAX 62
 
-template <bool GRAY>
+template <bool GRAY, bool TILES>
 __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t flags, uint32_t RB) {
 	const uint32_t f = blockIdx.y;
 	if (!b.aux[f].open) return;
@@ -250,19 +250,21 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 	const uint32_t quads_padded = (g.m_quads + 15u) & ~15u;
 	const uint64_t any = D[0] | D[1] | D[2] | D[3];
 	const uint64_t lanes_set = __ballot(any != 0ull);
-	// the tile-major mask and its occupancy bytes (bands of whole tile rows: launch_map_pass)
+	// the tile-major mask and its occupancy bytes (TILES: bands of whole tile rows, launch_map_pass; a launch without them runs the
+	// instantiation that has no trace of this)
 	uint32_t occ7 = 0;
-	const bool tiles_out = b.tiled != nullptr && (RB & 7u) == 0u;
-	if (tiles_out) {
+	if constexpr (TILES) {
 		const uint32_t ntr = ((uint32_t)nrows + 7u) >> 3, op = occ_pitch(g);
 		uint8_t *occp = b.occ + (size_t)f * occ_stride(g) + (size_t)((uint32_t)r0 >> 3) * op + wave;
 		if (lanes_set) occ7 = tile_occupancy(any >> 1, lane, ntr, occp, op);
 		else if (lane < ntr) occp[(size_t)lane * op] = 0;
+		if (blockIdx.x == 0 && q == 0) b.aux[f].tiles = 1u;           // (k_button cleared it: this frame's tile-major mask is being written)
 	}
 	if (q < quads_padded) {
 		uint8_t *mp = b.mask + (size_t)f * g.mask_stride + (size_t)q * 4;
 		uint32_t *bp = b.bits + (size_t)f * g.bits_stride_w + (q >> 3);
-		uint32_t *tp = b.tiled + (size_t)f * tiled_stride_w(g) + ((size_t)((uint32_t)r0 >> 3) * g.bits_pitch_w + (q >> 3)) * 8u;
+		uint32_t *tp = nullptr;
+		if constexpr (TILES) tp = b.tiled + (size_t)f * tiled_stride_w(g) + ((size_t)((uint32_t)r0 >> 3) * g.bits_pitch_w + (q >> 3)) * 8u;
 		for (int row = r0; row < r1; ++row) {
 			const int bit = row - r0 + 1;
 			const uint32_t nib = (uint32_t)((D[0] >> bit) & 1ull) | ((uint32_t)((D[1] >> bit) & 1ull) << 1) |
@@ -274,8 +276,10 @@ __global__ void __launch_bounds__(1024) k_map_pass(Geom g, Buffers b, uint32_t f
 			v |= __shfl_down(v, 2) << 8;
 			v |= __shfl_down(v, 4) << 16;
 			if ((lane & 7u) == 0) bp[(size_t)row * g.bits_pitch_w] = v;
-			const uint32_t i = (uint32_t)(row - r0);
-			if ((occ7 >> (i >> 3)) & 1u) tp[(size_t)(i >> 3) * g.bits_pitch_w * 8u + (i & 7u)] = v;      // (occ7 is 0 outside the lanes 8 j)
+			if constexpr (TILES) {
+				const uint32_t i = (uint32_t)(row - r0);
+				if ((occ7 >> (i >> 3)) & 1u) tp[(size_t)(i >> 3) * g.bits_pitch_w * 8u + (i & 7u)] = v;    // (occ7 is 0 outside the lanes 8 j)
+			}
 		}
 	}
 	// ---- bounding box + population count of the set bits (drives the LDS window of k_lsd) ----
@@ -434,14 +438,20 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 // find_scales_preprocess on the pixels it has already loaded for ui_map and the marker mask: the quadrant is not read a
 // second time (k_brq_pass re-read 2 x 126 MB per 256 frames) and one launch and the branch stream go away.
 // Column masks are indexed from row r0 - 3 (the OCR neighbourhood reaches 3 rows up; the marker dilation 1), so a band
-// holds at most 58 output rows: 3 + 58 + 3 = 64 bits -- 56 of them are used: whole tile rows of the line search (the pass
-// writes the mask tile-major as well, smh_kernels.h).  1080p: 15 bands either way; 1440p: 20 instead of 19.
+// holds at most 58 output rows: 3 + 58 + 3 = 64 bits.  band_rows_for takes 56 of them -- whole tile rows of the line search: the
+// pass then writes the mask tile-major as well (smh_kernels.h) -- where that costs no band (1080p: 15 bands either way) or the
+// frame is small enough for the search service to sit on every CU (ROI up to 900 rows: there the cheaper tile-store build buys the
+// pass a third workgroup per CU, +8 %); elsewhere 58 (1440p: 19 bands instead of 20 -- measured, same box, 128 x 1440p at depth 12:
+// 272-280 k frames/s with 58-row bands and the walk over the bit rows against 265-272 k with 56-row bands and the tile-major mask).
 // ------------------------------------------------------------------------------------------------
-#define MAPQ_RB_MAX 56
-// fewer frames than fill the chip: shorter bands, still whole tile rows
-static inline uint32_t band_rows_for(uint32_t rh, uint32_t n, uint32_t rb_max) {
-	uint32_t RB = rb_max;
-	while (RB > 8 && (uint64_t)((rh + RB - 1) / RB) * n < 512) RB = RB > 32 ? 32 : RB / 2;
+#define MAPQ_RB_MAX 58
+// rows per band of a launch over n frames of an ROI rh rows tall, for column masks that hold rb_cap rows.  A multiple of 8 means
+// "this launch writes the tile-major mask" (the kernels tell the search through FrameAux::tiles).
+// Fewer frames than fill the chip: shorter bands.
+static inline uint32_t band_rows_for(uint32_t rh, uint32_t n, uint32_t rb_cap, bool tiles_wanted = true) {
+	const uint32_t rb8 = rb_cap & ~7u;
+	uint32_t RB = (tiles_wanted && ((rh + rb8 - 1) / rb8 == (rh + rb_cap - 1) / rb_cap || rh <= 900u)) ? rb8 : rb_cap;
+	while (RB > 8 && (uint64_t)((rh + RB - 1) / RB) * n < 512) RB = (RB & 7u) ? (RB + 1) / 2 : (RB > 32 ? 32 : RB / 2);
 	return RB;
 }
 
@@ -508,7 +518,10 @@ typedef const __attribute__((address_space(4))) MapKernelArgs *MapKernelArgsPtr;
 #else
 typedef const MapKernelArgs *MapKernelArgsPtr;                                     // (host pass: the body is only parsed)
 #endif
-template <bool GRAY, int SETS>
+// TILES: this launch also writes the mask tile-major with occupancy bytes (bands of whole tile rows; launch_map_brq_pass).  A
+// launch that does not runs the instantiation without a trace of it: the same code as before round 6 (measured: the extra
+// epilogue code alone cost the 1440p pipeline 2.4 % and the three-set form 6 %, whether or not it was executed).
+template <bool GRAY, int SETS, bool TILES>
 __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f, uint32_t band0) {
 	constexpr int GR = 4;                                       // rows per group (the hand-placed waits count four loads per set)
 	const Geom g = ka->g;
@@ -808,17 +821,18 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 		// tile rows: launch_map_brq_pass).  A wave without a marker pixel -- most of them -- stores its (up to seven) zero bytes.
 		// (their two pointers are fetched HERE, through a copy of the argument pointer the compiler cannot see through: held in
 		// scalar registers across the streaming loop they cost it 84 more spill reloads per iteration of the three-set form)
-		MapKernelArgsPtr kb = ka;
-		asm volatile("" : "+s"(kb));
-		uint32_t *const tiled_out = kb->b.tiled;
-		uint8_t *const occ_out = kb->b.occ;
 		uint32_t occ7 = 0;
-		const bool tiles_out = tiled_out != nullptr && (RB & 7u) == 0u;
-		if (tiles_out) {
+		uint32_t *tiled_out = nullptr;
+		if constexpr (TILES) {
+			MapKernelArgsPtr kb = ka;
+			asm volatile("" : "+s"(kb));
+			tiled_out = kb->b.tiled;
+			uint8_t *const occ_out = kb->b.occ;
 			const uint32_t ntr = ((uint32_t)nrows + 7u) >> 3, opitch = occ_pitch(g);
 			uint8_t *occp = occ_out + (size_t)f * occ_stride(g) + (size_t)((uint32_t)r0 >> 3) * opitch + wave;
 			if (lanes_set) occ7 = tile_occupancy(any >> 3, lane, ntr, occp, opitch);
 			else if (lane < ntr) occp[(size_t)lane * opitch] = 0;
+			if (band == 0u && q == 0u) b.aux[f].tiles = 1u;             // (k_button cleared it: this frame's tile-major mask is being written)
 		}
 		if (q < quads_padded && !lanes_set) {
 			// no marker pixel in this wave's 256 columns of the band (most of a map): rows of zeros, nothing to extract or gather
@@ -838,8 +852,9 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 			uint32_t *bbase = b.bits + (size_t)f * g.bits_stride_w;
 			const uint32_t moff = q * 4u, boff = (q >> 3) * 4u;
 			const bool bit_lane = (lane & 7u) == 0;
-			uint32_t *tp = tiled_out + (size_t)f * tiled_stride_w(g) + ((size_t)((uint32_t)r0 >> 3) * g.bits_pitch_w + (q >> 3)) * 8u;
-			const uint32_t tpitch = g.bits_pitch_w * 8u;
+			uint32_t *tp = nullptr;
+			uint32_t tpitch = 0;
+			if constexpr (TILES) { tp = tiled_out + (size_t)f * tiled_stride_w(g) + ((size_t)((uint32_t)r0 >> 3) * g.bits_pitch_w + (q >> 3)) * 8u; tpitch = g.bits_pitch_w * 8u; }
 #pragma unroll
 			for (int half = 0; half < 2; ++half) {
 				const uint32_t d0 = (uint32_t)(D[0] >> (32 * half)), d1 = (uint32_t)(D[1] >> (32 * half)), d2 = (uint32_t)(D[2] >> (32 * half)), d3 = (uint32_t)(D[3] >> (32 * half));
@@ -853,8 +868,10 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 					v |= SMH_DPP(v, 0x102) << 8;
 					v |= SMH_DPP(v, 0x104) << 16;
 					if (bit_lane) *(uint32_t *)((uint8_t *)bbase + (size_t)row * g.bits_pitch_w * 4u + boff) = v;
-					const uint32_t i = (uint32_t)(row - r0);
-					if ((occ7 >> (i >> 3)) & 1u) tp[(size_t)(i >> 3) * tpitch + (i & 7u)] = v;     // (occ7 is 0 outside the lanes 8 j)
+					if constexpr (TILES) {
+						const uint32_t i = (uint32_t)(row - r0);
+						if ((occ7 >> (i >> 3)) & 1u) tp[(size_t)(i >> 3) * tpitch + (i & 7u)] = v;   // (occ7 is 0 outside the lanes 8 j)
+					}
 				}
 			}
 		}
@@ -905,7 +922,7 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 // state costs the kernel 76 bytes of scratch per lane (spilled in the prologue / epilogue of an item, never in the streaming
 // loop: tools/check_untracked_loads.py); a launch with one workgroup per item (a batch that runs alone) takes the variant
 // without the loop and without the spills.
-template <bool GRAY, bool LOOP, int SETS>
+template <bool GRAY, bool LOOP, int SETS, bool TILES>
 __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32_t flags, uint32_t qflags, uint32_t RB, uint32_t fixed_start_y, int use_anchor_start,
                                                        uint32_t nbands, uint32_t items) {
 #ifdef SMH_MAP_FAT
@@ -917,11 +934,11 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 	if (LOOP) {
 		for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
 			const uint32_t f = item / nbands, band = item - f * nbands;
-			map_brq_item<GRAY, SETS>(ka, f, band);
+			map_brq_item<GRAY, SETS, TILES>(ka, f, band);
 			__syncthreads();                                   // the next item reuses the LDS exchange arrays
 		}
 	} else {
-		map_brq_item<GRAY, SETS>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
+		map_brq_item<GRAY, SETS, TILES>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
 	}
 }
 
@@ -933,25 +950,35 @@ hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_
 	return hipGetLastError();
 }
 
-hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s) {
+hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s, bool tiles_wanted) {
 	// Few frames: shorter bands so a single frame still spreads over the chip.
-	const uint32_t RB = band_rows_for(g.rh, n, MAP_RB_MAX);
+	const uint32_t RB = band_rows_for(g.rh, n, MAP_RB_MAX, tiles_wanted && b.tiled != nullptr);
 	const dim3 grid((g.rh + RB - 1) / RB, n);
 	const unsigned lds = (g.m_block / 64u) * 640u;             // 64 x (pixel, verdict, id) per wave
-	if (grayscale) hipLaunchKernelGGL(k_map_pass<true>, grid, dim3(g.m_block), lds, s, g, b, flags, RB);
-	else hipLaunchKernelGGL(k_map_pass<false>, grid, dim3(g.m_block), lds, s, g, b, flags, RB);
+	const bool tiles = tiles_wanted && b.tiled != nullptr && (RB & 7u) == 0u;
+	if (tiles) {
+		if (grayscale) hipLaunchKernelGGL((k_map_pass<true, true>), grid, dim3(g.m_block), lds, s, g, b, flags, RB);
+		else hipLaunchKernelGGL((k_map_pass<false, true>), grid, dim3(g.m_block), lds, s, g, b, flags, RB);
+	} else {
+		if (grayscale) hipLaunchKernelGGL((k_map_pass<true, false>), grid, dim3(g.m_block), lds, s, g, b, flags, RB);
+		else hipLaunchKernelGGL((k_map_pass<false, false>), grid, dim3(g.m_block), lds, s, g, b, flags, RB);
+	}
 	return hipGetLastError();
 }
 
 static uint32_t map_brq_static_lds() {
-	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_map_brq_pass<true, true, 2>) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 2048u; }();
+	static const uint32_t v = [] { hipFuncAttributes a; return hipFuncGetAttributes(&a, (const void *)k_map_brq_pass<true, true, 2, false>) == hipSuccess ? (uint32_t)a.sharedSizeBytes : 2048u; }();
 	return v;
 }
 uint32_t map_brq_lds_bytes(const Geom &g) { return map_brq_static_lds() + (g.m_block / 64u) * 640u; }
 
 hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t qflags, int grayscale, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s,
                                const LaunchTuning *tune) {
-	const uint32_t RB = band_rows_for(g.rh, n, MAPQ_RB_MAX);
+	// (the grid-stride form and the three-set form never write the tile-major mask -- see below -- and keep the 58-row bands they had)
+	const uint32_t cap0 = tune ? tune->map_grid_cap : 0u;
+	const uint32_t RB0 = band_rows_for(g.rh, n, MAPQ_RB_MAX, false);
+	const bool no_tiles = b.tiled == nullptr || (tune && tune->map_deep) || (cap0 && cap0 < ((g.rh + RB0 - 1) / RB0) * n);
+	const uint32_t RB = no_tiles ? RB0 : band_rows_for(g.rh, n, MAPQ_RB_MAX);
 	const uint32_t nbands = (g.rh + RB - 1) / RB, items = nbands * n;
 	unsigned lds = (g.m_block / 64u) * 640u;                 // 64 x (pixel, verdict, id) per wave
 	if (tune && tune->map_lds_total > map_brq_lds_bytes(g)) lds = tune->map_lds_total - map_brq_static_lds();
@@ -961,8 +988,9 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess) return e;
 		if (dev >= 64 || !((attr_devices.load(std::memory_order_acquire) >> dev) & 1ull)) {
-			const void *fns[] = {(const void *)k_map_brq_pass<true, true, 2>, (const void *)k_map_brq_pass<false, true, 2>, (const void *)k_map_brq_pass<true, false, 2>, (const void *)k_map_brq_pass<false, false, 2>,
-			                     (const void *)k_map_brq_pass<true, false, 3>, (const void *)k_map_brq_pass<false, false, 3>};
+			const void *fns[] = {(const void *)k_map_brq_pass<true, true, 2, false>, (const void *)k_map_brq_pass<false, true, 2, false>, (const void *)k_map_brq_pass<true, false, 2, false>,
+			                     (const void *)k_map_brq_pass<false, false, 2, false>, (const void *)k_map_brq_pass<true, false, 2, true>, (const void *)k_map_brq_pass<false, false, 2, true>,
+			                     (const void *)k_map_brq_pass<true, false, 3, false>, (const void *)k_map_brq_pass<false, false, 3, false>};
 			for (const void *fn : fns) if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
 			if (e != hipSuccess) return e;
 			if (dev < 64) attr_devices.fetch_or(1ull << dev, std::memory_order_release);
@@ -975,14 +1003,20 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 	// (LaunchTuning::map_deep: SMHV_PIPE_THREE_LOAD_SETS, round 5's choice for frame-granular pipelines up to 1080p; since round 6
 	// two sets are ahead there too).  A launch alone takes the same time either way.
 	const bool deep = tune && tune->map_deep && !(cap && cap < items);
-#define SMH_LAUNCH_MAPQ(GRAYV, LOOPV, SETSV, GRID) \
-	hipLaunchKernelGGL((k_map_brq_pass<GRAYV, LOOPV, SETSV>), GRID, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items)
+	// The tile-major mask: only launches with one workgroup per item and two load sets, whose bands are whole tile rows
+	// (band_rows_for) -- the frame-granular pipelines and plain runs up to 1080p; the grid-stride form (batch-granular pipelines:
+	// k_lsd_tile walks the bit rows) and the three-set form (SMHV_PIPE_THREE_LOAD_SETS: round 5's streaming pass as it was) never.
+	const bool tiles = !no_tiles && (RB & 7u) == 0u && !(cap && cap < items) && !deep;
+#define SMH_LAUNCH_MAPQ(GRAYV, LOOPV, SETSV, TILESV, GRID) \
+	hipLaunchKernelGGL((k_map_brq_pass<GRAYV, LOOPV, SETSV, TILESV>), GRID, dim3(g.m_block), lds, s, g, b, flags, qflags, RB, fixed_start_y, use_anchor_start, nbands, items)
 	if (cap && cap < items) {
-		if (grayscale) SMH_LAUNCH_MAPQ(true, true, 2, dim3(cap)); else SMH_LAUNCH_MAPQ(false, true, 2, dim3(cap));
+		if (grayscale) SMH_LAUNCH_MAPQ(true, true, 2, false, dim3(cap)); else SMH_LAUNCH_MAPQ(false, true, 2, false, dim3(cap));
 	} else if (deep) {
-		if (grayscale) SMH_LAUNCH_MAPQ(true, false, 3, dim3(nbands, n)); else SMH_LAUNCH_MAPQ(false, false, 3, dim3(nbands, n));
+		if (grayscale) SMH_LAUNCH_MAPQ(true, false, 3, false, dim3(nbands, n)); else SMH_LAUNCH_MAPQ(false, false, 3, false, dim3(nbands, n));
+	} else if (tiles) {
+		if (grayscale) SMH_LAUNCH_MAPQ(true, false, 2, true, dim3(nbands, n)); else SMH_LAUNCH_MAPQ(false, false, 2, true, dim3(nbands, n));
 	} else {
-		if (grayscale) SMH_LAUNCH_MAPQ(true, false, 2, dim3(nbands, n)); else SMH_LAUNCH_MAPQ(false, false, 2, dim3(nbands, n));
+		if (grayscale) SMH_LAUNCH_MAPQ(true, false, 2, false, dim3(nbands, n)); else SMH_LAUNCH_MAPQ(false, false, 2, false, dim3(nbands, n));
 	}
 #undef SMH_LAUNCH_MAPQ
 	return hipGetLastError();
@@ -999,9 +1033,9 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 // four = 12); the bench line quotes the best of 4 / 8 / 12.
 // ------------------------------------------------------------------------------------------------
 template <int NR>
-__global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b) {
+__global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b, uint32_t RB) {
 	const uint32_t f = blockIdx.y, q = threadIdx.x;
-	const int r0 = (int)(blockIdx.x * MAPQ_RB_MAX), r1 = min(r0 + MAPQ_RB_MAX, (int)g.rh);
+	const int r0 = (int)(blockIdx.x * RB), r1 = min(r0 + (int)RB, (int)g.rh);
 	if (q >= g.m_quads) return;
 	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax) * 4 + (size_t)q * 16;
 	uint8_t *up = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
@@ -1033,11 +1067,12 @@ __global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b) {
 }
 
 hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, uint32_t rows_in_flight, hipStream_t s) {
-	const dim3 grid((g.rh + MAPQ_RB_MAX - 1) / MAPQ_RB_MAX, n), block(g.m_block);
+	const uint32_t RB = band_rows_for(g.rh, n, MAPQ_RB_MAX);   // (the pass's own band height for this launch)
+	const dim3 grid((g.rh + RB - 1) / RB, n), block(g.m_block);
 	switch (rows_in_flight) {
-	case 0: case 4: hipLaunchKernelGGL(k_pattern_copy<4>, grid, block, 0, s, g, b); break;
-	case 8: hipLaunchKernelGGL(k_pattern_copy<8>, grid, block, 0, s, g, b); break;
-	case 12: hipLaunchKernelGGL(k_pattern_copy<12>, grid, block, 0, s, g, b); break;
+	case 0: case 4: hipLaunchKernelGGL(k_pattern_copy<4>, grid, block, 0, s, g, b, RB); break;
+	case 8: hipLaunchKernelGGL(k_pattern_copy<8>, grid, block, 0, s, g, b, RB); break;
+	case 12: hipLaunchKernelGGL(k_pattern_copy<12>, grid, block, 0, s, g, b, RB); break;
 	default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError();

@@ -433,13 +433,22 @@ def test_tile_major_mask_of_the_streaming_passes(vision, size):
             fb.run(d.data_ptr(), n, stages=stages, anchors=anc, stream=s)
             for f in sorted(want_mask):
                 tiled, occ, bits, xoff = fb.tile_mask(f)
-                trows, wcols, _ = tiled.shape
-                assert trows == (rh + 7) // 8 and bits.shape == (rh, wcols)
+                wcols = bits.shape[1]
+                trows = (rh + 7) // 8
+                # whole tile rows per band where that is free or pays (band_rows_for, smh_stream.hip): few frames always (bands of 8 / 16 / 32
+                # rows), full-height bands when the ROI is at most 900 rows tall or 56-row bands need no more bands than the kernel's own
+                cap = 58 if stages == smh.STAGE_ALL else 62
+                expect_tiles = n == 1 or rh <= 900 or -(-rh // 56) == -(-rh // cap)
+                assert (tiled is not None) == expect_tiles, (size, n, stages, f)
+                assert bits.shape == (rh, wcols)
                 # the bit rows are the oracle's mask (bit x + xoff of row y = pixel x)
                 px = np.zeros((rh, wcols * 32), np.uint8)
                 px[:, xoff:xoff + rw] = want_mask[f] != 0
                 want_bits = np.packbits(px.reshape(rh, wcols, 32), axis=2, bitorder="little").view(np.uint32).reshape(rh, wcols)
                 assert np.array_equal(bits, want_bits), (size, n, stages, f)
+                if tiled is None:
+                    continue
+                assert tiled.shape == (trows, wcols, 8)
                 # occupancy == non-empty tiles of those rows; the tiles' words == the rows' words
                 padded = np.zeros((trows * 8, wcols), np.uint32)
                 padded[:rh] = bits
@@ -451,7 +460,7 @@ def test_tile_major_mask_of_the_streaming_passes(vision, size):
                 a, b_ = tiled[nonempty], by_tile[nonempty]
                 last = np.repeat(np.arange(trows)[:, None], wcols, axis=1)[nonempty] == trows - 1
                 assert np.array_equal(a[~last], b_[~last]) and np.array_equal(a[last][:, :tail], b_[last][:, :tail]), (size, n, stages, f)
-            if n > 1:
+            if n > 1 and fb.tile_mask(n - 1)[1] is not None:
                 assert not fb.tile_mask(n - 1)[1].any()                                   # no marker pixel: every occupancy byte written, all zero
         fb.close()
 

@@ -148,19 +148,19 @@ def main():
         if m:
             j = next(k for k in range(i, len(text)) if "s_endpgm" in text[k])
             found += 1
-            errors += check_kernel(m.group(1)[:50], text[i:j + 1])
+            errors += check_kernel(m.group(1)[:58], text[i:j + 1])
             i = j
         i += 1
     meta = "\n".join(text)
     for km in re.finditer(r"\.name:\s+(_ZN3smh14k_map_brq_pass\w+)\s*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s*(\d+)", meta):
-        loop = re.search(r"ILb[01]ELb1ELi\d+EEEv", km.group(1)) is not None   # <GRAY, LOOP = true, SETS>: the grid-stride variant
+        loop = re.search(r"ILb[01]ELb1ELi\d+ELb[01]EEEv", km.group(1)) is not None   # <GRAY, LOOP = true, SETS>: the grid-stride variant
         if int(km.group(2)) > (128 if loop else 0):
-            errors.append("%s uses %s bytes of scratch (allowed: %s)" % (km.group(1)[:50], km.group(2), "the prologue / epilogue spills of the grid-stride loop's state, <= 128"
+            errors.append("%s uses %s bytes of scratch (allowed: %s)" % (km.group(1)[:58], km.group(2), "the prologue / epilogue spills of the grid-stride loop's state, <= 128"
                           if loop else "none: the variant without the loop is the one whose HBM traffic is profiled"))
     if found == 0:
         raise RuntimeError("no k_map_brq_pass instantiation in the device assembly")
-    if found != 6:
-        errors.append("expected six instantiations of k_map_brq_pass (GRAY x {two sets, two sets + loop, three sets}), found %d" % found)
+    if found != 8:
+        errors.append("expected eight instantiations of k_map_brq_pass (GRAY x {two sets, two sets + tile-major mask, two sets + loop, three sets}), found %d" % found)
     for e in errors:
         print("FAIL:", e)
     print("k_map_brq_pass: %d instantiations checked, %d problems" % (found, len(errors)))
