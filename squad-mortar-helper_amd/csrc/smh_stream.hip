@@ -614,6 +614,13 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 	uint32_t *s_hits = s_dyn;
 	// One group = four rows r .. r+3 held in px.  Everything that depends on the row only (band membership, quadrant
 	// membership) is a uniform branch; lanes outside the ROI / the quadrant compute along and are masked at the end.
+	// Branch hints for the blocks of the streaming loop that few waves enter (a marker colour's pre-filter hit, the exact test, a
+	// white / edge pixel of the quadrant): where the compiler puts those blocks decides 1-2 % of the PIPELINE's rate -- the loop is
+	// 4 k instructions beside a search kernel of its own size on the same instruction cache -- and in both directions: one box,
+	// three interleaved rounds, with / without the hints: 256 x 1080p 547-551 against 539-541 k frames/s, 128 x 1440p 281 against
+	// 286-287 k.  So only the instantiation that the frame sizes up to 1080p launch (TILES) carries them; the others are round 5's
+	// code to the instruction.
+	auto rare = [](bool c) -> bool { if constexpr (TILES) return __builtin_expect(c, 0); else return c; };
 	auto group = [&](const u32x4 (&px)[GR], int r) {
 		uint32_t prehits = 0, wrows = 0, erows = 0;                // bit 4k + c: pixel column c of row r + k
 #pragma unroll
@@ -668,20 +675,20 @@ __device__ SMH_MAP_ITEM_INLINE void map_brq_item(MapKernelArgsPtr ka, uint32_t f
 					}
 				}
 			}
-			if (do_mask && __any(bright4(pv) != 0u)) {
+			if (rare(do_mask && __any(bright4(pv) != 0u))) {
 				uint32_t pre = 0;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) pre |= marker_prefilter(pv[c]) ? (1u << c) : 0u;
 				prehits |= (pre & vmask) << (4 * k);
 			}
 		}
-		if (wave_q && __any((wrows | erows) != 0u)) {                // the group's four rows into the column masks
+		if (rare(wave_q && __any((wrows | erows) != 0u))) {                // the group's four rows into the column masks
 			const int sh = r - base;
 #pragma unroll
 			for (int c = 0; c < 4; ++c) { or_w(c, (uint64_t)rows_of_col(wrows, c) << sh); or_e(c, (uint64_t)rows_of_col(erows, c) << sh); }
 		}
 		// ---- exact f32 HSV test for the pre-filter hits of this wave, one hit per lane (see k_map_pass) ----
-		if (do_mask && __any(prehits != 0u)) {
+		if (rare(do_mask && __any(prehits != 0u))) {
 			uint32_t *hpx = s_hits + gwave * 160u;
 			uint32_t *hres = hpx + 64;
 			unsigned short *hid = (unsigned short *)(hres + 64);
