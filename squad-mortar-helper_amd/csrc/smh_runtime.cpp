@@ -232,6 +232,7 @@ struct smhv_ctx {
 	// two buffers in turn, so that the map of frame k stays readable while frame k + 1 is processed
 	hipStream_t s_ui = nullptr;
 	hipEvent_t ev_map = nullptr, ev_ui[2] = {nullptr, nullptr};
+	hipEvent_t ev_ui_part[3] = {nullptr, nullptr, nullptr};     // the eager crop_to_map: the ui_map leaves the device in four row blocks (the last one's event is ev_ui)
 	uint8_t *h_ui[2] = {nullptr, nullptr};
 	size_t h_ui_cap[2] = {0, 0};
 	uint32_t ui_turn = 0;
@@ -393,6 +394,7 @@ extern "C" SMHV_API int smhv_init(int device, smhv_log_fn log, smhv_ctx **out) {
 	if (he == hipSuccess) he = hipStreamCreateWithFlags(&c->s_ui, hipStreamNonBlocking);
 	if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_map, hipEventDisableTiming);
 	for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&c->ev_ui[i], hipEventDisableTiming);
+	for (int i = 0; i < 3 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&c->ev_ui_part[i], hipEventDisableTiming);
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_res, sizeof(smhv_frame_result) * 4);
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_aux, sizeof(FrameAux));
 	if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_bars, sizeof(uint32_t) * SMHV_MAX_SCALES * 4 + sizeof(smhv_anchors));   // (+ the anchors of calc_meters_to_px_ratio)
@@ -435,6 +437,7 @@ extern "C" SMHV_API void smhv_shutdown(smhv_ctx *c) {
 	if (c->s_scales) (void)hipStreamDestroy(c->s_scales);
 	if (c->s_ui) (void)hipStreamDestroy(c->s_ui);
 	if (c->ev_map) (void)hipEventDestroy(c->ev_map);
+	for (int i = 0; i < 3; ++i) { if (c->ev_ui_part[i]) (void)hipEventDestroy(c->ev_ui_part[i]); c->ev_ui_part[i] = nullptr; }
 	for (int i = 0; i < 2; ++i) { if (c->ev_ui[i]) (void)hipEventDestroy(c->ev_ui[i]); if (c->h_ui[i]) (void)hipHostFree(c->h_ui[i]); c->ev_ui[i] = nullptr; c->h_ui[i] = nullptr; c->h_ui_cap[i] = 0; }
 	c->s_ui = nullptr; c->ev_map = nullptr;
 	c->d_frame = nullptr; c->d_frame_cap = 0; c->h_ocr = c->h_scales = nullptr; c->h_res = nullptr; c->h_aux = nullptr; c->h_bars = nullptr;
@@ -1809,12 +1812,28 @@ extern "C" SMHV_API int smhv_crop_to_map(smhv_ctx *c, int grayscale, int *map_op
 		c->h_ui_cap[t] = ui_bytes;
 	}
 	HIPCHK(hipStreamWaitEvent(c->s_ui, c->ev_map, 0));
-	HIPCHK(hipMemcpy2DAsync(c->h_ui[t], (size_t)g.rw * 4, b->d_ui + (size_t)g.m_xoff * 4, g.ui_pitch, (size_t)g.rw * 4, g.rh, hipMemcpyDeviceToHost, c->s_ui));
-	HIPCHK(hipEventRecord(c->ev_ui[t], c->s_ui));
+	if (!ui_rgba) {
+		HIPCHK(hipMemcpy2DAsync(c->h_ui[t], (size_t)g.rw * 4, b->d_ui + (size_t)g.m_xoff * 4, g.ui_pitch, (size_t)g.rw * 4, g.rh, hipMemcpyDeviceToHost, c->s_ui));
+		HIPCHK(hipEventRecord(c->ev_ui[t], c->s_ui));
+		c->ui_pending = true;
+		return SMHV_OK;
+	}
+	// The eager form -- what the trait's `crop_to_map -> Option<(RgbaImage, [u32; 4])>` amounts to (vision-common/src/lib.rs:47): the
+	// image in the caller's memory when the call returns.  It leaves the device in four row blocks, and the host copies block k
+	// out of the pinned buffer while block k + 1 is still crossing PCIe: the call's 3.2 MB host copy hides behind the transfer
+	// instead of following it.
+	const uint32_t parts = 4, rows_per = (g.rh + parts - 1) / parts;
+	const size_t row_bytes = (size_t)g.rw * 4;
+	for (uint32_t k = 0; k < parts; ++k) {
+		const uint32_t r0 = k * rows_per, r1 = std::min(g.rh, r0 + rows_per);
+		if (r1 > r0) HIPCHK(hipMemcpy2DAsync(c->h_ui[t] + (size_t)r0 * row_bytes, row_bytes, b->d_ui + (size_t)r0 * g.ui_pitch + (size_t)g.m_xoff * 4, g.ui_pitch, row_bytes, r1 - r0, hipMemcpyDeviceToHost, c->s_ui));
+		HIPCHK(hipEventRecord(k + 1 < parts ? c->ev_ui_part[k] : c->ev_ui[t], c->s_ui));
+	}
 	c->ui_pending = true;
-	if (ui_rgba) {                                  // the eager form: the image in the caller's memory when the call returns
-		HIPCHK(wait_event(c->ev_ui[t]));
-		memcpy(ui_rgba, c->h_ui[t], ui_bytes);
+	for (uint32_t k = 0; k < parts; ++k) {
+		const uint32_t r0 = k * rows_per, r1 = std::min(g.rh, r0 + rows_per);
+		HIPCHK(wait_event(k + 1 < parts ? c->ev_ui_part[k] : c->ev_ui[t]));
+		if (r1 > r0) memcpy(ui_rgba + (size_t)r0 * row_bytes, c->h_ui[t] + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes);
 	}
 	return SMHV_OK;
 }
