@@ -325,6 +325,7 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
                                const LaunchTuning *tune = nullptr);
 // the fused streaming pass's loads and stores without its arithmetic (calibration: smhv_debug_pattern_copy)
 hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, uint32_t rows_in_flight, hipStream_t s);
+void map_band_rows(uint32_t rh, uint32_t n, int fused, uint32_t *rows, int *tiles);
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s);
 // k_lsd is three kernels, one per mask residency mode, each over all frames (a workgroup whose frame needs another mode
 // exits at once).  When the whole ROI fits the LDS window (<= 1080p) every frame is a ROWS frame and only that kernel is

@@ -2541,6 +2541,17 @@ extern "C" SMHV_API int smhv_ingest_push_pixels(smhv_ingest *q, const uint8_t *p
 	return smhv_ingest_commit_pixels(q, layout);
 }
 
+extern "C" SMHV_API int smhv_debug_band_rows(uint32_t frame_w, uint32_t frame_h, uint32_t n, int fused, uint32_t *rows, uint32_t *bands, int *tiles) {
+	Geom g;
+	int rc = compute_geom(frame_w, frame_h, &g);
+	if (rc) return rc;
+	uint32_t rb = 0;
+	map_band_rows(g.rh, n ? n : 1u, fused, &rb, tiles);
+	if (rows) *rows = rb;
+	if (bands) *bands = (g.rh + rb - 1) / rb;
+	return SMHV_OK;
+}
+
 extern "C" SMHV_API int smhv_debug_ingest_feed(smhv_ingest *q, uint32_t n, uint32_t *counter) {
 	if (!q || !counter) return fail(SMHV_E_INVALID, "ingest_feed: null argument");
 	for (uint32_t i = 0; i < n; ++i) {

@@ -1085,6 +1085,14 @@ hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, uint
 	return hipGetLastError();
 }
 
+// (host logic, for the tests: rows per band the fused / the plain pass takes for a launch over n frames of an ROI rh rows tall, and
+// whether such a launch writes the tile-major mask)
+void map_band_rows(uint32_t rh, uint32_t n, int fused, uint32_t *rows, int *tiles) {
+	const uint32_t RB = band_rows_for(rh, n, fused ? MAPQ_RB_MAX : MAP_RB_MAX);
+	if (rows) *rows = RB;
+	if (tiles) *tiles = (RB & 7u) == 0u ? 1 : 0;
+}
+
 hipError_t launch_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, uint32_t fixed_start_y, int use_anchor_start, hipStream_t s) {
 	const dim3 grid((g.qh + BRQ_RB - 1) / BRQ_RB, n);
 	hipLaunchKernelGGL(k_brq_pass, grid, dim3(g.q_block), 0, s, g, b, flags, fixed_start_y, use_anchor_start);

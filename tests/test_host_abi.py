@@ -351,3 +351,30 @@ def test_vision_state_follows_the_reference_call_contract(built):
     assert res5.meters_to_px_ratio == 0.5 and len(res5.markers) == 1
     for s in (st, st2, st3):
         s.close()
+
+
+def test_band_heights_of_the_streaming_pass(built):
+    """band_rows_for (smh_stream.hip) through smhv_debug_band_rows, no device: whole tile rows -- and with them the tile-major mask --
+    where they cost the launch no band or the ROI is at most 900 rows tall (frames up to 1080p), the kernel's own 58 / 62 rows
+    elsewhere; fewer frames than fill the chip: shorter bands, whole tile rows again at the end of the halving."""
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import _lib
+    lib = _lib.load()
+
+    def q(w, h, n, fused):
+        rows, bands, tiles = C.c_uint32(), C.c_uint32(), C.c_int()
+        _lib.check(lib.smhv_debug_band_rows(w, h, n, fused, C.byref(rows), C.byref(bands), C.byref(tiles)))
+        return rows.value, bands.value, bool(tiles.value)
+    assert q(1920, 1080, 256, 1) == (56, 15, True)          # 822 rows: 15 bands of 56 or of 58
+    assert q(1920, 1080, 256, 0) == (56, 15, True)          # (62 would be 14 bands: the ROI is small enough for the search to sit on every CU)
+    assert q(2560, 1440, 128, 1) == (58, 19, False)         # 1096 rows: 56 would cost a twentieth band
+    assert q(2560, 1440, 128, 0) == (62, 18, False)
+    assert q(3840, 2160, 64, 1) == (58, 29, False)
+    assert q(1024, 768, 256, 1)[2] and q(1280, 1024, 256, 1)[2] and q(800, 600, 256, 1)[2]
+    for (w, h) in [(1920, 1080), (2560, 1440), (3840, 2160), (1024, 768), (5120, 1440)]:
+        for fused in (0, 1):
+            rows, bands, tiles = q(w, h, 1, fused)           # one frame: bands of 8 rows
+            assert rows == 8 and tiles and bands == -(-smh.map_bounds(w, h)[3] // 8)
+            for n in (2, 5, 17, 40, 300):
+                rows, bands, tiles = q(w, h, n, fused)
+                assert 8 <= rows <= (58 if fused else 62) and tiles == (rows % 8 == 0) and bands == -(-smh.map_bounds(w, h)[3] // rows)
