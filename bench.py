@@ -97,6 +97,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=128, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--timed-regions", type=int, default=1, help="cut the K timed steps into this many regions, each bracketed by barrier + synchronize (value = median; default 1 = the contract's one region)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-traffic-probe", action="store_true", help="skip the live HBM-traffic measurement of the streaming kernel (two short rocprofv3 --pmc child runs after the timed region); roofline.traffic then comes from the committed profiles/traffic.json")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-real-samples", action="store_true", help="skip the leg on the reference's own 1440p screenshots (real_samples)")
     ap.add_argument("--no-depth1", action="store_true", help="skip the one-batch-in-flight region (value_depth1)")
     ap.add_argument("--no-back-to-back", action="store_true",
@@ -819,6 +821,64 @@ def node_main(args, cfg, n, W, H, stages, rounds, custom):
     emit(out)
 
 
+def traffic_child(args, n, W, H, stages):
+    """What the traffic probe profiles: three plain passes over n resident frames (16 distinct, tiled), nothing else."""
+    import numpy as np
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import synth
+    k = min(16, n)
+    frames, infos = synth.make_batch(W, H, k, first_idx=0, n_lines=args.lines)
+    d = torch.from_numpy(frames).cuda()
+    d = d.repeat((n + k - 1) // k, 1, 1, 1)[:n].contiguous()
+    infos = [infos[i % k] for i in range(n)]
+    anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos]) if stages & 8 else None
+    vision = smh.HipVision.init(0)
+    fb = smh.FrameBatch(vision, W, H, n)
+    for _ in range(3):
+        fb.run(d.data_ptr(), n, stages=stages, grayscale=True, max_gap=15, anchors=anchors, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    fb.close()
+
+
+def traffic_probe(args, n, W, H, stages, kname, timeout=150):
+    """HBM bytes of the streaming kernel per launch, measured NOW on this box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    separate passes (nothing else combined with the counters but --kernel-trace: MI355X_MICROARCH.md, HBM / rocprofv3 section), each
+    around a child `python3 bench.py --traffic-child` that runs three plain passes of this workload; reads = 2 x FETCH_SIZE (the
+    guide's gfx950 correction for wide coalesced reads), units KB.  -> (bytes per launch, source text) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="smh_traffic_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
+                   "--config", str(args.config), "--frames-per-gpu", str(n), "--width", str(W), "--height", str(H), "--stages", str(stages), "--lines", str(args.lines)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout, text=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and kname in row.get("Kernel_Name", ""):
+                            vals.append(float(row["Counter_Value"]))
+            vals = [v for v in vals if v > 0.0]              # (a dispatch occasionally comes back with a counter of exactly 0: a dropped sample)
+            if not vals:
+                return None, "rocprofv3 --pmc %s gave no sample of %s (exit %d: %s)" % (counter, kname, r.returncode, (r.stderr or "")[-200:].replace("\n", " "))
+            got[counter] = sum(vals) / len(vals) * 1024.0
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+            return None, "traffic probe failed: %s" % e
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = 2.0 * got["FETCH_SIZE"], got["WRITE_SIZE"]
+    return rd + wr, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around three plain passes of the workload; "
+                     "reads = 2 x FETCH_SIZE (gfx950 correction) = %.1f MB, writes = %.1f MB per launch" % (rd / 1e6, wr / 1e6))
+
+
 def main():
     args = parse_args()
     if args.config is None:
@@ -844,6 +904,8 @@ def main():
     if args.distinct is None:
         args.distinct = 256 if args.config == 4 else 0
 
+    if args.traffic_child:
+        return traffic_child(args, n, W, H, stages)
     if args.rendezvous_only:                           # the launch / rendezvous path alone (CPU test of the self-launch)
         import torch
         import torch.distributed as dist
@@ -1141,6 +1203,13 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         kname = "k_map_brq_pass" if (stages & 0xC) and (stages & 0x3) else "k_map_pass"
+        if world == 1 and not args.no_traffic_probe:
+            live, why = traffic_probe(args, n, W, H, stages, kname)
+            if live is not None:
+                committed = traffic
+                traffic, tsrc = live, why + ("; the committed PMC run (profiles/traffic.json) has %.1f MB" % (committed / 1e6) if committed else "")
+            else:
+                tsrc = (tsrc or "none") + " -- live probe: " + why
         # `achieved` / `frac`: the kernel's algorithmic bytes per launch / its launch duration -- of a launch that runs ALONE when the
         # isolated pass was timed (hipEvents on the launch's stream, live, after the timed region), which is the figure that
         # says something about the kernel.  The launches INSIDE the timed region of a deep pipeline overlap each other and the
