@@ -221,6 +221,46 @@ def test_fuzz_lsd_slice(vision, seed, size, max_gap):
     fb.close()
 
 
+@pytest.mark.parametrize("size,seed", [((1920, 1080), 31), ((2440, 1376), 32), ((2344, 1320), 33), ((800, 600), 34), ((2560, 1440), 35), ((3440, 1440), 36), ((5120, 1440), 37)])
+def test_search_service_builds_its_tile_store_from_the_tile_major_mask(vision, size, seed):
+    """Random scenes through a frame-granular pipeline with the tile store built from the pass's tile-major mask (the default where
+    the launch writes it) and by the walk over the bit rows (SMHV_PIPE_WALK_BIT_ROWS): byte-identical records, equal to the oracle.
+    Sizes: 1080p (16-bit tile table, bit rows 2 bits left of pixel 0); 2440 x 1376 and 2344 x 1320 (above 1080p, 56-row bands cost no
+    band there: the compact index built from the occupancy bytes, bit rows 1 / 2 bits left of pixel 0); 800 x 600 (bit rows start on
+    pixel 0); 1440p (58-row bands: the launch writes no tile-major mask, FrameAux::tiles sends the search to the walk); the ultrawide
+    3440 x 1440 and 5120 x 1440 (ROIs 69 and 122 tile columns wide: the walk behind the compact index takes a tile row in chunks of
+    64 columns -- round 5's looked at the first 64 only and lost the lines to the right of pixel 2048: found by this round's fuzz)."""
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import _lib
+    from fuzz_scenes import scene
+    W, H = size
+    n, max_gap = 24, 15
+    rng = np.random.default_rng(seed)
+    frames = np.stack([scene(rng, W, H, 100 * seed + i, max_gap) for i in range(n)])
+    ref = o.process_batch(frames, min(os.cpu_count() or 1, n), stages=0x1, max_gap=max_gap)
+    d = torch.from_numpy(frames).cuda()
+    recs = {}
+    for name, flags in (("tiles", 0), ("walk", _lib.PIPE_WALK_BIT_ROWS)):
+        pipe = smh.Pipeline(vision, W, H, n, 4, search="frame", flags=flags)
+        # (markers + ui_map + ocr_preprocess: the fused pass, whose column masks hold 58 rows)
+        slots = [pipe.submit(d.data_ptr(), n, stages=0x7, max_gap=max_gap) for _ in range(6)]
+        pipe.wait()
+        got = [bytes(pipe.slots[s_].read_results(0, n)) for s_ in sorted(set(slots))]
+        assert all(g == got[0] for g in got), (size, name)
+        recs[name] = got[0]
+        dicts = smh.results_to_dicts(pipe.slots[slots[-1]].read_results(0, n))
+        for i in range(n):
+            assert dicts[i]["n_lines"] == ref[i].n_lines and np.array_equal(dicts[i]["lines"], _lines(ref[i])) and dicts[i]["rounds"] == ref[i].rounds, (size, name, i)
+        # which builder ran is what the launch wrote: the tile-major mask where bands are whole tile rows
+        _, occ, _, xoff = pipe.slots[slots[-1]].tile_mask(0)
+        x, y, rw, rh = smh.map_bounds(W, H)
+        assert (occ is not None) == (rh <= 900 or -(-rh // 56) == -(-rh // 58)), (size, rh)
+        pipe.close()
+    assert recs["tiles"] == recs["walk"], size
+    assert sum(r.rounds for r in ref) > 50
+
+
 def test_both_line_segment_kernels_agree_with_the_oracle(vision):
     """find_lines has three implementations: the task-based k_lsd_tile (sparse tile store of the mask, reorder buffer, waves
     claim 64-ray units), the workgroup-synchronous k_lsd (smhv_debug_lsd_classic) and the one-wave-per-frame sequential scan

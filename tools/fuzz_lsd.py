@@ -28,7 +28,9 @@ def main():
     for it in range(iters):
         sizes = [(1280, 1024), (1920, 1080), (1024, 768), (2560, 1440), (1600, 1024)]
         if os.environ.get("FUZZ_SERVICE"):
-            sizes += [(2560, 1440), (3840, 2160), (5120, 1440), (800, 600), (1366, 768)]   # (round 6: sixteen waves of the pass per row = four occupancy dwords per tile row; bit rows that start ON pixel 0 (m_xoff 0); above 1080p the service's tile stores sit behind the compact index; 4K: two groups of tile columns per row)
+            sizes += [(2560, 1440), (3840, 2160), (5120, 1440), (800, 600), (1366, 768), (2440, 1376), (2344, 1320)]   # (round 6: 2440 x 1376 / 2344 x 1320 = above 1080p with the tile-major mask -- the compact index from the occupancy bytes -- and bit rows 1 / 2 bits left of pixel 0; sixteen waves of the pass per row = four occupancy dwords per tile row; bit rows that start ON pixel 0 (m_xoff 0); above 1080p the service's tile stores sit behind the compact index; 4K: two groups of tile columns per row)
+        if os.environ.get("FUZZ_SIZE"):                           # e.g. FUZZ_SIZE=5120x1440: that frame size only
+            sizes = [tuple(int(v) for v in os.environ["FUZZ_SIZE"].split("x"))]
         W, H = sizes[int(rng.integers(0, len(sizes)))]
         max_gap = int(rng.choice([15, 15, 22, 9, 3, 30, 45, 49, 50, 1]))
         frames = np.stack([scene(rng, W, H, 1000 * it + i, max_gap) for i in range(n)])
@@ -40,7 +42,7 @@ def main():
         # FUZZ_SERVICE=1: through the frame-granular search service of a pipeline (one wave per frame + the workgroup help desk;
         # several submissions in flight so that waves are helping while others start) instead of the plain batch path
         service = bool(os.environ.get("FUZZ_SERVICE"))
-        pipe = smh.Pipeline(vision, W, H, n, 3, search="frame") if service else None
+        pipe = smh.Pipeline(vision, W, H, n, 3, search="frame", flags=int(os.environ.get("FUZZ_FLAGS", "0"))) if service else None
         for exact in (0, smh.STAGE_EXACT_STATS):
             if service:
                 slots = [pipe.submit(d.data_ptr(), n, stages=0x1 | exact, max_gap=max_gap) for _ in range(3)]
