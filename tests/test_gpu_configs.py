@@ -599,6 +599,58 @@ def test_fused_streaming_pass_on_threshold_frames(vision):
         fb.close()
 
 
+@pytest.mark.parametrize("size,n", [((1920, 1080), 36), ((2560, 1440), 28), ((1280, 1024), 40)])
+def test_fused_pass_full_height_bands_on_threshold_frames(vision, size, n):
+    """The same threshold frames with enough of them for FULL-HEIGHT bands (the test above runs three frames: bands of 8 rows): 56 rows
+    and the tile-major mask at 1080p and 1280 x 1024, 58 rows without it at 1440p (smhv_debug_band_rows says which) -- every image of
+    every frame against the oracle, and where the launch wrote the tile-major mask, its occupancy bytes and tiles against the bit rows."""
+    import ctypes as C
+    import torch
+    import squad_mortar_helper_amd as smh
+    from squad_mortar_helper_amd import _lib
+    from fuzz_scenes import random_frame
+    W, H = size
+    rows, bands, tiles = C.c_uint32(), C.c_uint32(), C.c_int()
+    _lib.check(_lib.load().smhv_debug_band_rows(W, H, n, 1, C.byref(rows), C.byref(bands), C.byref(tiles)))
+    assert rows.value in (56, 58) and bool(tiles.value) == (rows.value == 56)
+    rng = np.random.default_rng(W + n)
+    frames = np.stack([random_frame(rng, W, H) for _ in range(n)])
+    bx, by, bw, bh = smh.button_bounds(W, H)
+    frames[:, by:by + bh, bx:bx + bw, :3] = (49, 67, 217)                       # map open
+    start = [int(rng.integers(0, 60)) for _ in range(n)]
+    per = [(start[i], [(100, 10, start[i])]) for i in range(n)]
+    d = torch.from_numpy(frames).cuda()
+    fb = smh.FrameBatch(vision, W, H, n)
+    fb.run(d.data_ptr(), n, stages=0xF, grayscale=True, anchors=smh.make_anchors(per), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    x, y, rw, rh = smh.map_bounds(W, H)
+    for i in range(n):
+        ref = o.process_frame(frames[i], grayscale=True, stages=0xE, anchors=per[i][1], scales_start_y=per[i][0], want_images=True)
+        mask_ref = o.mask_marker_lines(np.ascontiguousarray(frames[i][y:y + rh, x:x + rw, 2::-1]))
+        assert np.array_equal(fb.read_image(smh._lib.IMAGE_UI_MAP, i), ref["ui_map"]), (size, i)
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_LSD_INPUT, i), mask_ref), (size, i)
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_OCR_INPUT, i), ref["ocr"]), (size, i)
+        assert np.array_equal(fb.read_image(smh._lib.VIEW_FIND_SCALES_INPUT, i)[per[i][0]:], ref["scales"][per[i][0]:]), (size, i)
+        tiled, occ, bits, xoff = fb.tile_mask(i)
+        assert (tiled is not None) == bool(tiles.value), (size, i)
+        wcols = bits.shape[1]
+        px = np.zeros((rh, wcols * 32), np.uint8)
+        px[:, xoff:xoff + rw] = mask_ref != 0
+        assert np.array_equal(bits, np.packbits(px.reshape(rh, wcols, 32), axis=2, bitorder="little").view(np.uint32).reshape(rh, wcols)), (size, i)
+        if tiled is not None:
+            trows = (rh + 7) // 8
+            padded = np.zeros((trows * 8, wcols), np.uint32)
+            padded[:rh] = bits
+            by_tile = padded.reshape(trows, 8, wcols).transpose(0, 2, 1)
+            nonempty = by_tile.any(axis=2)
+            assert np.array_equal(np.unpackbits(occ, axis=1, bitorder="little")[:, :wcols].astype(bool), nonempty), (size, i)
+            tail = rh - (trows - 1) * 8
+            a, b_ = tiled[nonempty], by_tile[nonempty]
+            last = np.repeat(np.arange(trows)[:, None], wcols, axis=1)[nonempty] == trows - 1
+            assert np.array_equal(a[~last], b_[~last]) and np.array_equal(a[last][:, :tail], b_[last][:, :tail]), (size, i)
+    fb.close()
+
+
 def test_pipeline_without_host_atomics_keeps_the_batch_granular_search(vision):
     """The search service's life cycle needs device-side 64-bit atomics on mapped host memory; smhv_pipeline_create probes for
     them.  With the probe's answer forced to "no" (smhv_debug_no_host_atomics): the default search of a deep pipeline is the
