@@ -20,7 +20,10 @@ def main():
     vision = smh.HipVision.init(0)
     bad = 0
     for it in range(iters):
-        W, H = [(1280, 1024), (1920, 1080), (1024, 768), (2560, 1440), (1600, 1024), (1366, 768), (1680, 1050)][int(rng.integers(0, 7))]
+        sizes = [(1280, 1024), (1920, 1080), (1024, 768), (2560, 1440), (1600, 1024), (1366, 768), (1680, 1050)]
+        if os.environ.get("FUZZ_SHAPES"):                       # round 6: shapes no test runs (ultrawide, 16:10, odd)
+            sizes += [(3440, 1440), (5120, 1440), (2560, 1080), (3840, 1600), (1920, 1200), (2560, 1600), (1440, 900), (1280, 720), (4096, 2160), (2440, 1376), (800, 600), (3840, 2160)]
+        W, H = sizes[int(rng.integers(0, len(sizes)))]
         frame = random_frame(rng, W, H)
         bx, by, bw, bh = smh.button_bounds(W, H)
         frac = rng.choice([0.60, 0.64, 0.65, 0.66, 0.7, 1.0])
