@@ -79,6 +79,9 @@ SMHV_API int smhv_debug_crc32_host_level(const void *data, uint64_t nbytes, int 
  * the fused map + quadrant pass of runs with the OCR / scales stages; 0: the plain map pass), the number of bands per frame, and
  * whether such a launch also writes the tile-major mask (bands of whole tile rows: smhv_batch_tile_mask).  The three-set form and
  * the grid-stride form of the fused pass keep 58-row bands whatever this says. */
+/* Rows per band of the streaming launches that write the tile-major mask (a multiple of 8, at most 56; 0 = the library's rule:
+ * smhv_debug_band_rows reports what a launch takes).  Process-wide; for measuring band heights against each other. */
+SMHV_API int smhv_debug_map_band_rows(uint32_t rows);
 SMHV_API int smhv_debug_band_rows(uint32_t frame_w, uint32_t frame_h, uint32_t n, int fused, uint32_t *rows, uint32_t *bands, int *tiles);
 /* benchmark driver: a NATIVE capture loop for the ingest queue (the reference's capture thread is native code, src/capture.rs) --
  * n times: smhv_ingest_acquire, stamp the 24-bit value (*counter)++ into pixel (0, 0) of the staging buffer (whose other

@@ -126,6 +126,7 @@ SIGNATURES = {
     "smhv_ingest_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "smhv_ingest_create_ex": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "smhv_crc32_host": (C.c_uint32, [C.c_void_p, C.c_uint64]),
+    "smhv_debug_map_band_rows": (C.c_int, [C.c_uint32]),
     "smhv_debug_band_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "smhv_debug_ingest_feed": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "smhv_debug_crc32_host_level": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]),

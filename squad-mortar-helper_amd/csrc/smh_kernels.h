@@ -156,8 +156,8 @@ struct Buffers {
 //          writes the bytes of its tile rows (zeros too), so nothing stale is ever read.
 // The builder reads the occupancy bytes of the bounding box's tile rows (one coalesced load) and then exactly the non-empty
 // tiles (32 contiguous bytes each, all in flight together): 2-3 round trips and 4-9 KB.  Bands have to be a multiple of 8 rows tall
-// for this (56 instead of 58: still 15 bands at 1080p, but 20 instead of 19 at 1440p): a launch takes them where they are free or
-// pay (band_rows_for, smh_stream.hip) and says so per frame in FrameAux::tiles; otherwise the search walks the bit rows as before.
+// for this (24 rows up to 1080p, where short bands are also the faster ones; 56 instead of 58 above, 20 bands instead of 19 at 1440p): a
+// launch takes them where they are free or pay (band_rows_for, smh_stream.hip) and says so per frame in FrameAux::tiles; otherwise the search walks the bit rows as before.
 __host__ __device__ inline uint32_t tiled_rows(const Geom &g) { return (g.rh + 7u) >> 3; }
 __host__ __device__ inline uint64_t tiled_stride_w(const Geom &g) { return (uint64_t)tiled_rows(g) * g.bits_pitch_w * 8u; }
 __host__ __device__ inline uint32_t occ_pitch(const Geom &g) { return ((g.m_block >> 6) + 3u) & ~3u; }

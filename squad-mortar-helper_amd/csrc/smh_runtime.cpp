@@ -1190,7 +1190,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 		// workgroups: 212 / 225 / 245 / 255 / 263 / 271 / 267 / 243 k frames/s on the synthetic scene, 225 / 247 / 260 / 260 / 256 / 244 /
 		// 226 / 211 k on the reference's screenshots in round 5.  Round 6 -- the tile store built from the pass's tile-major mask, a
 		// frame 20 % cheaper -- 192 / 160 / 144 / 128 / 112 / 96 workgroups: - / 269 / 275 / 282 / 293 / 262 k synthetic, 261 / 276 / 273 / 253 /
-		// 231 / - k on the screenshots; and with the walk over the bit rows (those frame sizes keep it: the 56-row bands of the tile-major mask
+		// 231 / - k on the screenshots; and with the walk over the bit rows (those frame sizes keep it: bands of whole tile rows for the tile-major mask
 		// would cost the pass a band, band_rows_for) 144 against 160 workgroups: 296-297 against 287-288 k synthetic, 272-274 against 276 k on the
 		// screenshots: nine sixteenths of the CUs)
 		const bool every_cu = p->svc_waves >= 4u && !p->svc_compact;
@@ -2539,6 +2539,13 @@ extern "C" SMHV_API int smhv_ingest_push_pixels(smhv_ingest *q, const uint8_t *p
 	if (rc) return rc;
 	memcpy(dst, pixels, q->frame_bytes / 4 * bpp);
 	return smhv_ingest_commit_pixels(q, layout);
+}
+
+namespace smh { extern std::atomic<uint32_t> g_map_band_rows; }   // smh_stream.hip
+extern "C" SMHV_API int smhv_debug_map_band_rows(uint32_t rows) {
+	if (rows & 7u) return fail(SMHV_E_INVALID, "debug_map_band_rows: a multiple of 8 (0: the library's rule)");
+	g_map_band_rows.store(rows, std::memory_order_relaxed);
+	return SMHV_OK;
 }
 
 extern "C" SMHV_API int smhv_debug_band_rows(uint32_t frame_w, uint32_t frame_h, uint32_t n, int fused, uint32_t *rows, uint32_t *bands, int *tiles) {

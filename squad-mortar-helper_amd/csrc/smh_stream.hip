@@ -438,20 +438,30 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 // find_scales_preprocess on the pixels it has already loaded for ui_map and the marker mask: the quadrant is not read a
 // second time (k_brq_pass re-read 2 x 126 MB per 256 frames) and one launch and the branch stream go away.
 // Column masks are indexed from row r0 - 3 (the OCR neighbourhood reaches 3 rows up; the marker dilation 1), so a band
-// holds at most 58 output rows: 3 + 58 + 3 = 64 bits.  band_rows_for takes 56 of them -- whole tile rows of the line search: the
-// pass then writes the mask tile-major as well (smh_kernels.h) -- where that costs no band (1080p: 15 bands either way) or the
-// frame is small enough for the search service to sit on every CU (ROI up to 900 rows: there the cheaper tile-store build buys the
-// pass a third workgroup per CU, +8 %); elsewhere 58 (1440p: 19 bands instead of 20 -- measured, same box, 128 x 1440p at depth 12:
-// 272-280 k frames/s with 58-row bands and the walk over the bit rows against 265-272 k with 56-row bands and the tile-major mask).
+// holds at most 58 output rows: 3 + 58 + 3 = 64 bits.  band_rows_for: whole tile rows of the line search -- the pass then writes
+// the mask tile-major as well (smh_kernels.h) -- for ROIs up to 900 rows (1080p), where the search service sits on every CU and the
+// cheaper tile-store build buys the pass a third workgroup per CU, and 24 of them: with four-wave workgroups (ROIs up to 1024 px
+// wide) a launch alone is 5-11 % shorter in 24-row bands than in 56-row ones in spite of reading 6 extra rows per 24 instead of per
+// 56 (one box, 256 frames, 56 / 48 / 40 / 32 / 24 / 16 rows: 1080p 0.466 / 0.470 / 0.450 / 0.444 / 0.441 / 0.478 ms, 1600 x 900 0.376 /
+// 0.363 / 0.361 / 0.353 / 0.346 / 0.369, 720p 0.263 / 0.263 / 0.250 / 0.244 / 0.233 / 0.241; 64 frames of 1080p 0.153 -> 0.142; the plain
+// pass k_map_pass 0.437 -> 0.410), and inside the frame-granular pipeline the band height is immaterial (548-554 k frames/s at every
+// height from 24 to 56: profiles/r06_sweep_band_rows.txt).  Taller ROIs: 56 where that costs no band, else 58 without the tile-major
+// mask (1440p, six-wave workgroups: 19 bands instead of 20; alone 58 = 32 rows = 0.420 ms, 24 rows 0.439; in the pipeline 58-row bands
+// and the walk over the bit rows 284-287 k frames/s, 56 rows 271-273 k, 32 rows 254-258 k, 24 rows 240-246 k).
 // ------------------------------------------------------------------------------------------------
 #define MAPQ_RB_MAX 58
 // rows per band of a launch over n frames of an ROI rh rows tall, for column masks that hold rb_cap rows.  A multiple of 8 means
 // "this launch writes the tile-major mask" (the kernels tell the search through FrameAux::tiles).
 // Fewer frames than fill the chip: shorter bands.
+std::atomic<uint32_t> g_map_band_rows{0};   // diagnostic (smhv_debug_map_band_rows): rows per band of the launches that write the tile-major mask; 0: the rule
 static inline uint32_t band_rows_for(uint32_t rh, uint32_t n, uint32_t rb_cap, bool tiles_wanted = true) {
-	const uint32_t rb8 = rb_cap & ~7u;
-	uint32_t RB = (tiles_wanted && ((rh + rb8 - 1) / rb8 == (rh + rb_cap - 1) / rb_cap || rh <= 900u)) ? rb8 : rb_cap;
-	while (RB > 8 && (uint64_t)((rh + RB - 1) / RB) * n < 512) RB = (RB & 7u) ? (RB + 1) / 2 : (RB > 32 ? 32 : RB / 2);
+	const uint32_t rb8 = rb_cap & ~7u, forced = g_map_band_rows.load(std::memory_order_relaxed);
+	uint32_t RB = rb_cap;
+	if (tiles_wanted && forced) RB = std::min(rb8, forced);
+	else if (tiles_wanted && rh <= 900u) RB = 24u;
+	else if (tiles_wanted && (rh + rb8 - 1) / rb8 == (rh + rb_cap - 1) / rb_cap) RB = rb8;
+	const uint64_t fill = RB == 24u ? 768u : 512u;            // (work items that fill the chip: measured with the band heights they go with)
+	while (RB > 8 && (uint64_t)((rh + RB - 1) / RB) * n < fill) RB = (RB & 7u) ? (RB + 1) / 2 : (RB > 32 ? 32 : RB > 16 ? 16 : 8);
 	return RB;
 }
 

@@ -599,20 +599,30 @@ def test_fused_streaming_pass_on_threshold_frames(vision):
         fb.close()
 
 
-@pytest.mark.parametrize("size,n", [((1920, 1080), 36), ((2560, 1440), 28), ((1280, 1024), 40)])
-def test_fused_pass_full_height_bands_on_threshold_frames(vision, size, n):
-    """The same threshold frames with enough of them for FULL-HEIGHT bands (the test above runs three frames: bands of 8 rows): 56 rows
-    and the tile-major mask at 1080p and 1280 x 1024, 58 rows without it at 1440p (smhv_debug_band_rows says which) -- every image of
-    every frame against the oracle, and where the launch wrote the tile-major mask, its occupancy bytes and tiles against the bit rows."""
+@pytest.mark.parametrize("size,n,forced", [((1920, 1080), 36, 0), ((1920, 1080), 36, 56), ((2560, 1440), 28, 0), ((2560, 1440), 28, 48), ((1280, 1024), 40, 0), ((1280, 1024), 40, 40)])
+def test_fused_pass_full_height_bands_on_threshold_frames(vision, size, n, forced):
+    """The same threshold frames with enough of them for FULL-HEIGHT bands (the test above runs three frames: bands of 8 rows): 24 rows
+    and the tile-major mask at 1080p and 1280 x 1024, 58 rows without it at 1440p (smhv_debug_band_rows says which), and the heights
+    the rule does not take by itself through smhv_debug_map_band_rows (56: seven tile rows per band) -- every image of every frame
+    against the oracle, and where the launch wrote the tile-major mask, its occupancy bytes and tiles against the bit rows."""
+    from squad_mortar_helper_amd import _lib
+    _lib.check(_lib.load().smhv_debug_map_band_rows(forced))
+    try:
+        _full_height_bands(vision, size[0], size[1], n, forced)
+    finally:
+        _lib.check(_lib.load().smhv_debug_map_band_rows(0))
+
+
+def _full_height_bands(vision, W, H, n, forced):
     import ctypes as C
     import torch
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import _lib
     from fuzz_scenes import random_frame
-    W, H = size
+    size = (W, H)
     rows, bands, tiles = C.c_uint32(), C.c_uint32(), C.c_int()
     _lib.check(_lib.load().smhv_debug_band_rows(W, H, n, 1, C.byref(rows), C.byref(bands), C.byref(tiles)))
-    assert rows.value in (56, 58) and bool(tiles.value) == (rows.value == 56)
+    assert rows.value == (forced or (58 if H == 1440 else 24)) and bool(tiles.value) == (rows.value % 8 == 0)
     rng = np.random.default_rng(W + n)
     frames = np.stack([random_frame(rng, W, H) for _ in range(n)])
     bx, by, bw, bh = smh.button_bounds(W, H)

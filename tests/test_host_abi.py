@@ -355,8 +355,9 @@ def test_vision_state_follows_the_reference_call_contract(built):
 
 def test_band_heights_of_the_streaming_pass(built):
     """band_rows_for (smh_stream.hip) through smhv_debug_band_rows, no device: whole tile rows -- and with them the tile-major mask --
-    where they cost the launch no band or the ROI is at most 900 rows tall (frames up to 1080p), the kernel's own 58 / 62 rows
-    elsewhere; fewer frames than fill the chip: shorter bands, whole tile rows again at the end of the halving."""
+    where the ROI is at most 900 rows tall (frames up to 1080p: 24-row bands) or they cost the launch no band (56), the kernel's own
+    58 / 62 rows elsewhere; fewer frames than fill the chip: shorter bands, whole tile rows again at the end of the halving;
+    smhv_debug_map_band_rows overrides the height of the launches that write the tile-major mask."""
     import squad_mortar_helper_amd as smh
     from squad_mortar_helper_amd import _lib
     lib = _lib.load()
@@ -365,8 +366,17 @@ def test_band_heights_of_the_streaming_pass(built):
         rows, bands, tiles = C.c_uint32(), C.c_uint32(), C.c_int()
         _lib.check(lib.smhv_debug_band_rows(w, h, n, fused, C.byref(rows), C.byref(bands), C.byref(tiles)))
         return rows.value, bands.value, bool(tiles.value)
-    assert q(1920, 1080, 256, 1) == (56, 15, True)          # 822 rows: 15 bands of 56 or of 58
-    assert q(1920, 1080, 256, 0) == (56, 15, True)          # (62 would be 14 bands: the ROI is small enough for the search to sit on every CU)
+    assert q(1920, 1080, 256, 1) == (24, 35, True)          # 822 rows
+    assert q(1920, 1080, 256, 0) == (24, 35, True)
+    assert q(1920, 1080, 16, 1) == (16, 52, True)           # 35 bands x 16 frames do not fill the chip's 768 workgroup slots
+    try:
+        _lib.check(lib.smhv_debug_map_band_rows(56))
+        assert q(1920, 1080, 256, 1) == (56, 15, True) and q(2560, 1440, 128, 1) == (56, 20, True)
+        _lib.check(lib.smhv_debug_map_band_rows(32))
+        assert q(1920, 1080, 256, 0) == (32, 26, True)
+        assert lib.smhv_debug_map_band_rows(12) != 0         # whole tile rows only
+    finally:
+        _lib.check(lib.smhv_debug_map_band_rows(0))
     assert q(2560, 1440, 128, 1) == (58, 19, False)         # 1096 rows: 56 would cost a twentieth band
     assert q(2560, 1440, 128, 0) == (62, 18, False)
     assert q(3840, 2160, 64, 1) == (58, 29, False)

@@ -32,6 +32,8 @@ fb.close()
 # experiment knobs (this tool's own; the library reads no environment): RATE_SEARCH=auto|batch|frame, RATE_STREAMS, RATE_IDLE_US,
 # RATE_WGS, RATE_FLAGS (1 no team help, 2 no streaming priority, 4 no prologue stream), RATE_POLICY, RATE_LATE
 _env = os.environ.get
+if _env("RATE_BAND_ROWS"):                              # (process-wide diagnostic: rows per band of the streaming pass)
+    smh._lib.check(smh._lib.load().smhv_debug_map_band_rows(int(_env("RATE_BAND_ROWS"))))
 if _env("RATE_TILE_CAP"):                               # (process-wide diagnostic: read when a pipeline is created)
     smh._lib.load().smhv_debug_lsd_tile_cap(int(_env("RATE_TILE_CAP")))
 pipe = smh.Pipeline(vision, W, H, N, depth, search=_env("RATE_SEARCH", "auto"), streams=int(_env("RATE_STREAMS", "0")), idle_close_us=int(_env("RATE_IDLE_US", "0")),
