@@ -75,14 +75,15 @@ SMHV_API int smhv_debug_marker_table(smhv_ctx *ctx, uint32_t *bits);
  * 1: PCLMULQDQ (128-bit lanes), 0: slicing-by-8 tables; a loop the machine lacks falls back to the next lower one.  Returns the
  * machine's level (what smhv_crc32_host and the ingest workers use); level < 0 (data may be NULL) only reports it. */
 SMHV_API int smhv_debug_crc32_host_level(const void *data, uint64_t nbytes, int level, uint32_t *crc);
-/* host logic only (no device needed): the band height the streaming pass takes for a launch over n frames of this frame size (fused != 0:
- * the fused map + quadrant pass of runs with the OCR / scales stages; 0: the plain map pass), the number of bands per frame, and
- * whether such a launch also writes the tile-major mask (bands of whole tile rows: smhv_batch_tile_mask).  The three-set form and
- * the grid-stride form of the fused pass keep 58-row bands whatever this says. */
+/* host logic only (no device needed): the band height the streaming pass takes for a launch over n frames of this frame size (fused = 1:
+ * the fused map + quadrant pass of runs with the OCR / scales stages; 2: the same inside a frame-granular pipeline, beside the search
+ * service; 0: the plain map pass), the number of bands per frame, and whether such a launch also writes the tile-major mask (bands of
+ * whole tile rows: smhv_batch_tile_mask).  The three-set form and the grid-stride form of the fused pass keep 58-row bands whatever
+ * this says. */
+SMHV_API int smhv_debug_band_rows(uint32_t frame_w, uint32_t frame_h, uint32_t n, int fused, uint32_t *rows, uint32_t *bands, int *tiles);
 /* Rows per band of the streaming launches that write the tile-major mask (a multiple of 8, at most 56; 0 = the library's rule:
  * smhv_debug_band_rows reports what a launch takes).  Process-wide; for measuring band heights against each other. */
 SMHV_API int smhv_debug_map_band_rows(uint32_t rows);
-SMHV_API int smhv_debug_band_rows(uint32_t frame_w, uint32_t frame_h, uint32_t n, int fused, uint32_t *rows, uint32_t *bands, int *tiles);
 /* benchmark driver: a NATIVE capture loop for the ingest queue (the reference's capture thread is native code, src/capture.rs) --
  * n times: smhv_ingest_acquire, stamp the 24-bit value (*counter)++ into pixel (0, 0) of the staging buffer (whose other
  * pixels keep what they last held; (0, 0) lies outside every region the path reads, so every frame hashes differently and

@@ -317,6 +317,8 @@ struct LaunchTuning {
 	uint32_t map_prio;        // != 0: the streaming waves run at wave priority 3 -- ahead of the search service's waves on their SIMD,
 	                          // which have slack (measured: 470 k -> 516 k frames/s at depth 12; beside the batch-granular search it cost 1-8 %)
 	uint32_t map_deep;        // != 0: three register sets of loads in flight per wave instead of two (launch_map_brq_pass)
+	uint32_t map_beside_service;   // != 0: the launch runs beside the search service (frame-granular pipelines): 56-row bands up to 1080p, where a
+	                          // launch that runs alone takes 24-row ones (band_rows_for)
 };
 // LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
 uint32_t map_brq_lds_bytes(const Geom &g);

@@ -1228,6 +1228,7 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 			// The streaming waves go first on their SIMD
 			p->batch[i]->tune.map_prio = (opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u;
 			p->batch[i]->tune.map_deep = (opt.flags & SMHV_PIPE_THREE_LOAD_SETS) ? 1u : 0u;   // (a service workgroup on every CU: launch_map_brq_pass)
+			p->batch[i]->tune.map_beside_service = 1u;
 		} else if (depth >= 3) {                                  // (an adaptive pipeline sets the tuning of a slot per submission)
 			if (opt.occupancy_policy != 2u) p->tuning = pipeline_tuning(p->batch[i]->g);
 			p->batch[i]->tune = p->tuning;
@@ -1331,7 +1332,7 @@ static int svc_submit(smhv_pipeline *p, uint32_t slot, const void *d_frames, uin
 	if (rc) return rc;
 	if (batch_check_errors(b, "pipeline_submit (the slot's previous submission, never waited for)") != SMHV_OK) logf(p->ctx, 2, "%s", t_last_error.c_str());
 	hipStream_t st = p->svc_stream[p->submitted % p->svc_streams];
-	if (p->adaptive) { b->tune = LaunchTuning{0u, 0u, 0u, (p->opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u, (p->opt.flags & SMHV_PIPE_THREE_LOAD_SETS) ? 1u : 0u}; b->probe = false; b->lsd_late_kc = 0u; }
+	if (p->adaptive) { b->tune = LaunchTuning{0u, 0u, 0u, (p->opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u, (p->opt.flags & SMHV_PIPE_THREE_LOAD_SETS) ? 1u : 0u, 1u}; b->probe = false; b->lsd_late_kc = 0u; }
 	// the sector table of this gap threshold is a launch parameter of the service: a submission with another one waits for
 	// the service to finish what it has and close (a host that alternates thresholds pays a drain per change)
 	Buffers probe{};
@@ -1513,7 +1514,7 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 			}
 			bb->probe_valid = false;
 		}
-		bb->tune = p->tune_on ? p->tuning : LaunchTuning{0u, 0u, 0u, 0u, 0u};
+		bb->tune = p->tune_on ? p->tuning : LaunchTuning{0u, 0u, 0u, 0u, 0u, 0u};
 		// ... and a search-bound pipeline lets the workgroups of k_lsd_tile that have finished their frame help the ones still at
 		// work after SMH_LATE_KC_SEARCH_BOUND thousand cycles (sample screenshots, batch 128: 96 -> 106 k frames/s at depth 4,
 		// 127 -> 138 k at depth 8; the synthetic pipeline, ratio 1.3, loses 3 % with them and keeps them off)

@@ -445,7 +445,8 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 // 56 (one box, 256 frames, 56 / 48 / 40 / 32 / 24 / 16 rows: 1080p 0.466 / 0.470 / 0.450 / 0.444 / 0.441 / 0.478 ms, 1600 x 900 0.376 /
 // 0.363 / 0.361 / 0.353 / 0.346 / 0.369, 720p 0.263 / 0.263 / 0.250 / 0.244 / 0.233 / 0.241; 64 frames of 1080p 0.153 -> 0.142; the plain
 // pass k_map_pass 0.437 -> 0.410), and inside the frame-granular pipeline the band height is immaterial (548-554 k frames/s at every
-// height from 24 to 56: profiles/r06_sweep_band_rows.txt).  Taller ROIs: 56 where that costs no band, else 58 without the tile-major
+// height from 24 to 56 in runs of 600 submissions; in runs of 8,000, three interleaved rounds, 24 rows 548-552 k, 32 rows 550-558 k, 56 rows
+// 556-558 k: profiles/r06_sweep_band_rows.txt -- so the launches of a frame-granular pipeline, beside_service, keep 56).  Taller ROIs: 56 where that costs no band, else 58 without the tile-major
 // mask (1440p, six-wave workgroups: 19 bands instead of 20; alone 58 = 32 rows = 0.420 ms, 24 rows 0.439; in the pipeline 58-row bands
 // and the walk over the bit rows 284-287 k frames/s, 56 rows 271-273 k, 32 rows 254-258 k, 24 rows 240-246 k).
 // ------------------------------------------------------------------------------------------------
@@ -454,11 +455,11 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 // "this launch writes the tile-major mask" (the kernels tell the search through FrameAux::tiles).
 // Fewer frames than fill the chip: shorter bands.
 std::atomic<uint32_t> g_map_band_rows{0};   // diagnostic (smhv_debug_map_band_rows): rows per band of the launches that write the tile-major mask; 0: the rule
-static inline uint32_t band_rows_for(uint32_t rh, uint32_t n, uint32_t rb_cap, bool tiles_wanted = true) {
+static inline uint32_t band_rows_for(uint32_t rh, uint32_t n, uint32_t rb_cap, bool tiles_wanted = true, bool beside_service = false) {
 	const uint32_t rb8 = rb_cap & ~7u, forced = g_map_band_rows.load(std::memory_order_relaxed);
 	uint32_t RB = rb_cap;
 	if (tiles_wanted && forced) RB = std::min(rb8, forced);
-	else if (tiles_wanted && rh <= 900u) RB = 24u;
+	else if (tiles_wanted && rh <= 900u) RB = beside_service ? rb8 : 24u;
 	else if (tiles_wanted && (rh + rb8 - 1) / rb8 == (rh + rb_cap - 1) / rb_cap) RB = rb8;
 	const uint64_t fill = RB == 24u ? 768u : 512u;            // (work items that fill the chip: measured with the band heights they go with)
 	while (RB > 8 && (uint64_t)((rh + RB - 1) / RB) * n < fill) RB = (RB & 7u) ? (RB + 1) / 2 : (RB > 32 ? 32 : RB > 16 ? 16 : 8);
@@ -995,7 +996,7 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 	const uint32_t cap0 = tune ? tune->map_grid_cap : 0u;
 	const uint32_t RB0 = band_rows_for(g.rh, n, MAPQ_RB_MAX, false);
 	const bool no_tiles = b.tiled == nullptr || (tune && tune->map_deep) || (cap0 && cap0 < ((g.rh + RB0 - 1) / RB0) * n);
-	const uint32_t RB = no_tiles ? RB0 : band_rows_for(g.rh, n, MAPQ_RB_MAX);
+	const uint32_t RB = no_tiles ? RB0 : band_rows_for(g.rh, n, MAPQ_RB_MAX, true, tune && tune->map_beside_service);
 	const uint32_t nbands = (g.rh + RB - 1) / RB, items = nbands * n;
 	unsigned lds = (g.m_block / 64u) * 640u;                 // 64 x (pixel, verdict, id) per wave
 	if (tune && tune->map_lds_total > map_brq_lds_bytes(g)) lds = tune->map_lds_total - map_brq_static_lds();
@@ -1098,7 +1099,7 @@ hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, uint
 // (host logic, for the tests: rows per band the fused / the plain pass takes for a launch over n frames of an ROI rh rows tall, and
 // whether such a launch writes the tile-major mask)
 void map_band_rows(uint32_t rh, uint32_t n, int fused, uint32_t *rows, int *tiles) {
-	const uint32_t RB = band_rows_for(rh, n, fused ? MAPQ_RB_MAX : MAP_RB_MAX);
+	const uint32_t RB = band_rows_for(rh, n, fused ? MAPQ_RB_MAX : MAP_RB_MAX, true, fused == 2);   // (2: the fused pass of a frame-granular pipeline)
 	if (rows) *rows = RB;
 	if (tiles) *tiles = (RB & 7u) == 0u ? 1 : 0;
 }

@@ -355,7 +355,8 @@ def test_vision_state_follows_the_reference_call_contract(built):
 
 def test_band_heights_of_the_streaming_pass(built):
     """band_rows_for (smh_stream.hip) through smhv_debug_band_rows, no device: whole tile rows -- and with them the tile-major mask --
-    where the ROI is at most 900 rows tall (frames up to 1080p: 24-row bands) or they cost the launch no band (56), the kernel's own
+    where the ROI is at most 900 rows tall (frames up to 1080p: 24-row bands for a launch alone, 56 beside the search service) or
+    they cost the launch no band (56), the kernel's own
     58 / 62 rows elsewhere; fewer frames than fill the chip: shorter bands, whole tile rows again at the end of the halving;
     smhv_debug_map_band_rows overrides the height of the launches that write the tile-major mask."""
     import squad_mortar_helper_amd as smh
@@ -369,6 +370,8 @@ def test_band_heights_of_the_streaming_pass(built):
     assert q(1920, 1080, 256, 1) == (24, 35, True)          # 822 rows
     assert q(1920, 1080, 256, 0) == (24, 35, True)
     assert q(1920, 1080, 16, 1) == (16, 52, True)           # 35 bands x 16 frames do not fill the chip's 768 workgroup slots
+    assert q(1920, 1080, 256, 2) == (56, 15, True)          # beside the search service (frame-granular pipelines): 56
+    assert q(2560, 1440, 128, 2) == (58, 19, False)
     try:
         _lib.check(lib.smhv_debug_map_band_rows(56))
         assert q(1920, 1080, 256, 1) == (56, 15, True) and q(2560, 1440, 128, 1) == (56, 20, True)

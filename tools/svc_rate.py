@@ -34,6 +34,8 @@ fb.close()
 _env = os.environ.get
 if _env("RATE_BAND_ROWS"):                              # (process-wide diagnostic: rows per band of the streaming pass)
     smh._lib.check(smh._lib.load().smhv_debug_map_band_rows(int(_env("RATE_BAND_ROWS"))))
+if _env("RATE_SKIP_LSD"):                               # (process-wide diagnostic: batch-granular submissions run without their line search)
+    smh._lib.check(smh._lib.load().smhv_debug_skip_line_search(1))
 if _env("RATE_TILE_CAP"):                               # (process-wide diagnostic: read when a pipeline is created)
     smh._lib.load().smhv_debug_lsd_tile_cap(int(_env("RATE_TILE_CAP")))
 pipe = smh.Pipeline(vision, W, H, N, depth, search=_env("RATE_SEARCH", "auto"), streams=int(_env("RATE_STREAMS", "0")), idle_close_us=int(_env("RATE_IDLE_US", "0")),
