@@ -853,6 +853,10 @@ def traffic_probe(args, n, W, H, stages, kname, timeout=150):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
+    # bench.py itself under a profiler (tools/profile_round.sh): a nested rocprofv3 would inherit the outer one's preloaded library, which
+    # initialises the GPU in the launcher before it starts the child -- not attempted
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "bench.py is itself running under rocprofv3: no nested counter run"
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="smh_traffic_", dir="/tmp")
