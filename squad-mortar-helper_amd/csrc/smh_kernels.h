@@ -352,6 +352,7 @@ hipError_t launch_scales_finalize(const Geom &g, const Buffers &b, uint32_t n, u
 // which: SMHV_VIEW_*; isolated: LSDPreprocess shows the marker-isolated crop (after isolate_map_markers)
 hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s);
 hipError_t launch_marker_table(uint32_t *d_bits, hipStream_t s);
+hipError_t launch_pack_rows(const void *d_src, uint32_t src_pitch_bytes, void *d_dst, uint32_t row_bytes, uint32_t rows, hipStream_t s);   // pitched rows -> a tight buffer (dword granularity)
 hipError_t launch_side_probe(uint32_t *d_out, uint32_t workgroups, uint32_t spin, hipStream_t s);   // a 21 KB-LDS / 280-VGPR kernel that does nothing (co-residency probe)
 hipError_t launch_build_sector_table(unsigned long long *d_tab, uint32_t T, hipStream_t s);
 hipError_t launch_build_ray_offsets(float *d_off, hipStream_t s);   // 3600 x (SMH_RAY_OFF_BATCHES + 1) float2

@@ -178,6 +178,25 @@ hipError_t launch_scales_finalize(const Geom &g, const Buffers &b, uint32_t n, u
 	return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_pack_rows: `rows` rows of `row_w` dwords each, `src_pitch_w` dwords apart, into a tight buffer -- the per-call path's ui_map on
+// its way to the host: a tight image leaves the device as ONE contiguous copy per row block (hipMemcpyAsync), which the runtime
+// always runs at the link's rate; the pitched copy it replaces (hipMemcpy2DAsync) took 0.2 ms for 3.2 MB in a fresh process and 0.6 ms
+// in one that had created and destroyed a pipeline (tools/trait_before_after_r06.py).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_rows(const uint32_t *__restrict__ src, uint32_t src_pitch_w, uint32_t *__restrict__ dst, uint32_t row_w, uint32_t rows) {
+	const uint32_t r = blockIdx.y;
+	const uint32_t *s = src + (size_t)r * src_pitch_w;
+	uint32_t *d = dst + (size_t)r * row_w;
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < row_w; x += gridDim.x * blockDim.x) d[x] = s[x];
+}
+hipError_t launch_pack_rows(const void *d_src, uint32_t src_pitch_bytes, void *d_dst, uint32_t row_bytes, uint32_t rows, hipStream_t s) {
+	if ((src_pitch_bytes | row_bytes) & 3u) return hipErrorInvalidValue;
+	const uint32_t row_w = row_bytes / 4u;
+	hipLaunchKernelGGL(k_pack_rows, dim3((row_w + 255u) / 256u, rows), dim3(256), 0, s, (const uint32_t *)d_src, src_pitch_bytes / 4u, (uint32_t *)d_dst, row_w, rows);
+	return hipGetLastError();
+}
+
 hipError_t launch_debug_view(const Geom &g, const Buffers &b, uint32_t frame, int which, int isolated, uint8_t *d_rgba, hipStream_t s) {
 	const bool brq = which == SMHV_VIEW_OCR_INPUT || which == SMHV_VIEW_FIND_SCALES_INPUT || which == SMHV_VIEW_CROPPED_BRQ;
 	const uint32_t npx = brq ? g.qw * g.qh : g.rw * g.rh;
