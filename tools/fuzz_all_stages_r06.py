@@ -10,13 +10,14 @@ from squad_mortar_helper_amd import synth
 from oracle import oracle as orc   # checker only
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+SEED = int(os.environ.get("FUZZ_SEED", "0"))             # other scenes: the synthetic frames' first index moves by 100000 x this
 SHAPES = [(1920, 1080), (2560, 1440), (3440, 1440), (5120, 1440), (2560, 1080), (3840, 1600), (1920, 1200), (2560, 1600), (1680, 1050), (1440, 900), (1280, 720),
           (1366, 768), (4096, 2160), (2440, 1376), (2344, 1320), (3840, 2160), (1024, 768), (800, 600)]
 TOL = 1e-4
 vision = smh.HipVision.init(0)
 bad = 0
 for (W, H) in SHAPES:
-    frames, infos = synth.make_batch(W, H, N, first_idx=4000 + W, n_lines=3)
+    frames, infos = synth.make_batch(W, H, N, first_idx=4000 + W + 100000 * SEED, n_lines=3)
     anchors = smh.make_anchors([(i["scales_start_y"], i["anchors"]) for i in infos])
     d = torch.from_numpy(frames).cuda()
     fb = smh.FrameBatch(vision, W, H, N)

@@ -10,11 +10,12 @@ import squad_mortar_helper_amd as smh
 from squad_mortar_helper_amd import synth
 
 SUBS = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-rng = np.random.default_rng(2026)
+SEED = int(os.environ.get("FUZZ_SEED", "0"))             # other scenes and another submission sequence
+rng = np.random.default_rng(2026 + SEED)
 vision = smh.HipVision.init(0)
 bad = 0
 for (W, H, N) in [(1920, 1080, 96), (2560, 1440, 64), (2440, 1376, 64), (1280, 1024, 96), (3440, 1440, 48)]:
-    frames, infos = synth.make_batch(W, H, N, first_idx=9000 + W, n_lines=2)
+    frames, infos = synth.make_batch(W, H, N, first_idx=9000 + W + 100000 * SEED, n_lines=2)
     all_anchors = [(i["scales_start_y"], i["anchors"]) for i in infos]
     d = torch.from_numpy(frames).cuda()
     fb = smh.FrameBatch(vision, W, H, N)
