@@ -533,11 +533,14 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
             except smh.VisionError as e:                       # (a cpuset that excludes those CPUs: the leg still runs, wherever the scheduler puts it)
                 print("bench.py: ingest producer not bound to the GPU's CPUs: %s" % e, file=sys.stderr)
         t0 = None
+        stamps = []
         for b in range(-2, slabs):                             # (two untimed slabs first: the pipeline behind the queues starts from idle)
             if b == 0:
                 pipe.wait()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
+            if b >= 0:
+                stamps.append(time.perf_counter())
             q = qs[b % 2]
             if pending[b % 2] is not None:
                 pipe.wait(pending[b % 2])                      # the previous run on this queue's slab has finished
@@ -555,6 +558,7 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
             pending[b % 2] = pipe.submit(ptr, cnt, stages=stages, grayscale=True, max_gap=15, anchors=anchors)
         pipe.wait()
         dt = time.perf_counter() - t0
+        run.slab_s = [b_ - a_ for a_, b_ in zip(stamps, stamps[1:])]   # host time from one slab's hand-over to the next's (diagnostic)
         return qs, slabs * n, dt
 
     cores = os.cpu_count() or 8
@@ -562,6 +566,7 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     affinity_before = os.sched_getaffinity(0)
     thr0 = cpu_throttled()
     qs, frames, dt = run(True, slots, frames_total)
+    slab_s = sorted(run.slab_s)
     thr1 = cpu_throttled()
     for q in qs:
         q.close()
@@ -630,6 +635,9 @@ def ingest_leg(smh, torch, vision, pipe, src, anchors, stages, frames_total, W, 
     return {"frames_per_s": frames / dt, "frames": frames, "mode": "roi_upload", "staging_slots": slots, "host_cores": cores,
             "producer": "native capture loop (smhv_debug_ingest_feed: acquire, stamp pixel (0,0), commit -- the reference's capture thread is native code, src/capture.rs)",
             "python_producer_frames_per_s": frames_py / dt_py,
+            "frames_per_s_by_slab": ({"median": n / slab_s[len(slab_s) // 2], "slowest": n / slab_s[-1], "fastest": n / slab_s[0], "slabs": len(slab_s),
+                                      "what": "the same timed loop slab by slab (%d frames each; host time between consecutive hand-overs): a run whose total is "
+                                              "well below its median slab had a few slow slabs, not a slow link" % n} if slab_s else None),
             "h2d_ceiling_GBps": {"packed_copies_three_streams": ceil_GBps, "one_256MB_copy": ceil_big_GBps,
                                  "what": "pinned host memory -> HBM on this box, measured here: copies of the queue's packed size round robin on three streams / one large copy"},
             "host_crc_GBps": frames * W * H * 4 / dt / 1e9, "host_crc_loop": {2: "VPCLMULQDQ (512-bit folding)", 1: "PCLMULQDQ", 0: "tables"}.get(crc_level, "?"),
