@@ -82,7 +82,9 @@ SMHV_API int smhv_debug_crc32_host_level(const void *data, uint64_t nbytes, int 
  * this says. */
 SMHV_API int smhv_debug_band_rows(uint32_t frame_w, uint32_t frame_h, uint32_t n, int fused, uint32_t *rows, uint32_t *bands, int *tiles);
 /* Rows per band of the streaming launches that write the tile-major mask (a multiple of 8, at most 56; 0 = the library's rule:
- * smhv_debug_band_rows reports what a launch takes).  Process-wide; for measuring band heights against each other. */
+ * smhv_debug_band_rows reports what a launch takes).  Bits 31 / 30 of the argument: the fused pass's work items in band-major order
+ * always / never (neither: the rule -- band-major where the launch runs alone, frame-major beside the search service).
+ * Process-wide; for measuring band heights and work-item orders against each other. */
 SMHV_API int smhv_debug_map_band_rows(uint32_t rows);
 /* benchmark driver: a NATIVE capture loop for the ingest queue (the reference's capture thread is native code, src/capture.rs) --
  * n times: smhv_ingest_acquire, stamp the 24-bit value (*counter)++ into pixel (0, 0) of the staging buffer (whose other

@@ -298,7 +298,7 @@ hipError_t svc_probe_host_atomics(SvcHost *h, SvcHost *d_h, bool *ok);   // pipe
 hipError_t launch_svc_publish(SvcCtl *ctl, unsigned long long *ring, SvcSlot *slots, uint32_t slot, const Buffers &b, uint32_t n, uint32_t seq, uint32_t ring_log2, hipStream_t s);
 hipError_t launch_lsd_service(const Geom &g, const SvcParams &p, uint32_t workgroups, uint32_t waves, uint32_t lds_bytes, hipStream_t s);
 
-enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u, MAP_PRIO = 0x100u };
+enum : uint32_t { MAP_UI = 1u, MAP_MASK = 2u, MAP_PRIO = 0x100u, MAP_BAND_MAJOR = 0x200u };   // MAP_BAND_MAJOR: the order of the work items (launch_map_brq_pass)
 enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
@@ -317,8 +317,9 @@ struct LaunchTuning {
 	uint32_t map_prio;        // != 0: the streaming waves run at wave priority 3 -- ahead of the search service's waves on their SIMD,
 	                          // which have slack (measured: 470 k -> 516 k frames/s at depth 12; beside the batch-granular search it cost 1-8 %)
 	uint32_t map_deep;        // != 0: three register sets of loads in flight per wave instead of two (launch_map_brq_pass)
-	uint32_t map_beside_service;   // != 0: the launch runs beside the search service (frame-granular pipelines): 56-row bands up to 1080p, where a
-	                          // launch that runs alone takes 24-row ones (band_rows_for)
+	uint32_t map_overlapped;  // != 0: the launch overlaps other kernels of its pipeline (the search service, or the searches and passes of a batch-granular
+	                          // pipeline of depth >= 3): 56-row bands up to 1080p and frame-major work items, where a launch that runs ALONE (plain
+	                          // runs, the per-call path, pipelines of depth 1 and 2) takes 24-row bands in band-major order (band_rows_for, k_map_brq_pass)
 };
 // LDS of one workgroup of the fused streaming pass without a reservation / of k_lsd_tile with `tile_cap` tiles (static + dynamic)
 uint32_t map_brq_lds_bytes(const Geom &g);

@@ -1232,10 +1232,11 @@ static int pipeline_create_impl(smhv_ctx *c, uint32_t W, uint32_t H, uint32_t ma
 			// The streaming waves go first on their SIMD
 			p->batch[i]->tune.map_prio = (opt.flags & SMHV_PIPE_NO_STREAM_PRIORITY) ? 0u : 1u;
 			p->batch[i]->tune.map_deep = (opt.flags & SMHV_PIPE_THREE_LOAD_SETS) ? 1u : 0u;   // (a service workgroup on every CU: launch_map_brq_pass)
-			p->batch[i]->tune.map_beside_service = 1u;
+			p->batch[i]->tune.map_overlapped = 1u;
 		} else if (depth >= 3) {                                  // (an adaptive pipeline sets the tuning of a slot per submission)
 			if (opt.occupancy_policy != 2u) p->tuning = pipeline_tuning(p->batch[i]->g);
 			p->batch[i]->tune = p->tuning;
+			p->batch[i]->tune.map_overlapped = 1u;
 			if (opt.late_helpers == 1u) p->batch[i]->lsd_late_kc = 20u;           // every frame asks at once
 			if (opt.occupancy_policy == 0u) {
 				p->adapt = true;
@@ -1519,6 +1520,7 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 			bb->probe_valid = false;
 		}
 		bb->tune = p->tune_on ? p->tuning : LaunchTuning{0u, 0u, 0u, 0u, 0u, 0u};
+		bb->tune.map_overlapped = 1u;
 		// ... and a search-bound pipeline lets the workgroups of k_lsd_tile that have finished their frame help the ones still at
 		// work after SMH_LATE_KC_SEARCH_BOUND thousand cycles (sample screenshots, batch 128: 96 -> 106 k frames/s at depth 4,
 		// 127 -> 138 k at depth 8; the synthetic pipeline, ratio 1.3, loses 3 % with them and keeps them off)
@@ -1529,6 +1531,7 @@ extern "C" SMHV_API int smhv_pipeline_submit(smhv_pipeline *p, const void *d_fra
 	}
 	if (p->adaptive && !p->adapt) {                           // (a fixed policy: what the slot's last frame-granular submission changed)
 		p->batch[slot]->tune = p->tuning;
+		p->batch[slot]->tune.map_overlapped = 1u;
 		p->batch[slot]->lsd_late_kc = p->opt.late_helpers == 1u ? 20u : 0u;
 	}
 	hipStream_t st, sl;
@@ -2556,8 +2559,10 @@ extern "C" SMHV_API int smhv_ingest_push_pixels(smhv_ingest *q, const uint8_t *p
 	return smhv_ingest_commit_pixels(q, layout);
 }
 
-namespace smh { extern std::atomic<uint32_t> g_map_band_rows; }   // smh_stream.hip
+namespace smh { extern std::atomic<uint32_t> g_map_band_rows, g_map_band_major; }   // smh_stream.hip
 extern "C" SMHV_API int smhv_debug_map_band_rows(uint32_t rows) {
+	g_map_band_major.store((rows >> 31) ? 1u : ((rows >> 30) & 1u) ? 2u : 0u, std::memory_order_relaxed);
+	rows &= 0x3FFFFFFFu;
 	if (rows & 7u) return fail(SMHV_E_INVALID, "debug_map_band_rows: a multiple of 8 (0: the library's rule)");
 	g_map_band_rows.store(rows, std::memory_order_relaxed);
 	return SMHV_OK;

@@ -454,6 +454,7 @@ __global__ void __launch_bounds__(1024) k_brq_pass(Geom g, Buffers b, uint32_t f
 // rows per band of a launch over n frames of an ROI rh rows tall, for column masks that hold rb_cap rows.  A multiple of 8 means
 // "this launch writes the tile-major mask" (the kernels tell the search through FrameAux::tiles).
 // Fewer frames than fill the chip: shorter bands.
+std::atomic<uint32_t> g_map_band_major{0};  // diagnostic (smhv_debug_map_band_rows, bits 31 / 30 of its argument): 1 = band-major order always, 2 = never; 0: the rule
 std::atomic<uint32_t> g_map_band_rows{0};   // diagnostic (smhv_debug_map_band_rows): rows per band of the launches that write the tile-major mask; 0: the rule
 static inline uint32_t band_rows_for(uint32_t rh, uint32_t n, uint32_t rb_cap, bool tiles_wanted = true, bool beside_service = false) {
 	const uint32_t rb8 = rb_cap & ~7u, forced = g_map_band_rows.load(std::memory_order_relaxed);
@@ -956,7 +957,19 @@ __global__ void __launch_bounds__(1024) k_map_brq_pass(Geom g, Buffers b, uint32
 			__syncthreads();                                   // the next item reuses the LDS exchange arrays
 		}
 	} else {
-		map_brq_item<GRAY, SETS, TILES>(ka, blockIdx.y, blockIdx.x);   // grid = (bands, frames)
+		// grid = (bands, frames); workgroups start in the order of their linear id.  MAP_BAND_MAJOR (a launch that runs alone): that order
+		// takes the same band of consecutive frames -- rows 8 MB apart -- instead of consecutive bands of one frame: the launch is 2.5-11 %
+		// shorter (one box, frame-major / band-major: 256 x 1080p 0.473 / 0.452 ms, 1024 x 1080p 1.645 / 1.469, 64 x 1080p 0.142 / 0.135,
+		// 1600 x 900 0.337 / 0.328, 720p 0.234 / 0.225, 128 x 1440p 0.418 / 0.407), while every XCD taking a contiguous run of (frame, band)
+		// items -- the halo rows of neighbouring bands in one L2 -- is 2-18 % LONGER (0.470 -> 0.559 ms in 24-row bands): what this access
+		// pattern wants is its requests spread over the memory system, not reuse.  Beside the search service the frame-major order stays
+		// (1080p level, 1440p 291 -> 281 k frames/s band-major: profiles/r06_sweep_band_major.txt).
+		uint32_t f = blockIdx.y, band = blockIdx.x;
+		if (flags & MAP_BAND_MAJOR) {
+			const uint32_t id = blockIdx.y * gridDim.x + blockIdx.x;
+			band = id / gridDim.y; f = id - band * gridDim.y;
+		}
+		map_brq_item<GRAY, SETS, TILES>(ka, f, band);
 	}
 }
 
@@ -996,7 +1009,7 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 	const uint32_t cap0 = tune ? tune->map_grid_cap : 0u;
 	const uint32_t RB0 = band_rows_for(g.rh, n, MAPQ_RB_MAX, false);
 	const bool no_tiles = b.tiled == nullptr || (tune && tune->map_deep) || (cap0 && cap0 < ((g.rh + RB0 - 1) / RB0) * n);
-	const uint32_t RB = no_tiles ? RB0 : band_rows_for(g.rh, n, MAPQ_RB_MAX, true, tune && tune->map_beside_service);
+	const uint32_t RB = no_tiles ? RB0 : band_rows_for(g.rh, n, MAPQ_RB_MAX, true, tune && tune->map_overlapped);
 	const uint32_t nbands = (g.rh + RB - 1) / RB, items = nbands * n;
 	unsigned lds = (g.m_block / 64u) * 640u;                 // 64 x (pixel, verdict, id) per wave
 	if (tune && tune->map_lds_total > map_brq_lds_bytes(g)) lds = tune->map_lds_total - map_brq_static_lds();
@@ -1015,6 +1028,10 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 		}
 	}
 	if (tune && tune->map_prio) flags |= MAP_PRIO;
+	{	// the order of the work items (k_map_brq_pass): band-major where the launch runs alone
+		const uint32_t forced = g_map_band_major.load(std::memory_order_relaxed);   // diagnostic: 1 = always, 2 = never
+		if (forced == 1u || (forced == 0u && !(tune && tune->map_overlapped))) flags |= MAP_BAND_MAJOR;
+	}
 	const uint32_t cap = tune ? tune->map_grid_cap : 0u;
 	// Loads in flight per wave: two register sets of four rows (one group ahead: 107 registers, three workgroups per CU beside a
 	// search-service workgroup), or three (two groups ahead: 123 registers, two workgroups) where the launch asks for it
