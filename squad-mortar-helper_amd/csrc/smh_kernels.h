@@ -303,7 +303,7 @@ enum : uint32_t { BRQ_OCR = 1u, BRQ_SCALES = 2u };
 
 hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_open, hipStream_t s);
 // tiles_wanted: the batch path (the mask also tile-major where the bands allow it: band_rows_for); the per-call path leaves it
-hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s, bool tiles_wanted = false);
+hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s, bool tiles_wanted = false, bool overlapped = false);
 // map pass + quadrant pass in one (the quadrant pixels are read once); flags: MAP_*, qflags: BRQ_*
 // Occupancy policy of a pipelined batch (smhv_pipeline_create).  A streaming workgroup beyond the two per
 // CU that saturate HBM only waits in the memory queues -- while holding wave slots and registers the other batches' line

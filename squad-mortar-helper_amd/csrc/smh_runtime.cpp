@@ -731,7 +731,7 @@ static int batch_run_impl(smhv_batch *b, const void *d_frames, uint32_t n, uint3
 	if (b->probe) HIPCHK(hipEventRecord(b->ev_probe[0], s));
 	STAGE_BEGIN(1, s);
 	if (mflags && qflags) HIPCHK(launch_map_brq_pass(g, bf, n, mflags, qflags, grayscale, 0, 1, s, &b->tune));
-	else if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s, true));
+	else if (mflags) HIPCHK(launch_map_pass(g, bf, n, mflags, grayscale, s, true, b->tune.map_overlapped != 0u));
 	STAGE_END(1, s);
 	STAGE_BEGIN(2, s);
 	if (qflags && !mflags) HIPCHK(launch_brq_pass(g, bf, n, qflags, 0, 1, s));

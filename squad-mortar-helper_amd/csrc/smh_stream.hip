@@ -981,9 +981,17 @@ hipError_t launch_button(const Geom &g, const Buffers &b, uint32_t n, int force_
 	return hipGetLastError();
 }
 
-hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s, bool tiles_wanted) {
+// the order of a streaming launch's work items: band-major where it runs alone (k_map_brq_pass), frame-major where it overlaps other kernels
+// of its pipeline; smhv_debug_map_band_rows can force either
+static uint32_t work_item_order(bool overlapped) {
+	const uint32_t forced = g_map_band_major.load(std::memory_order_relaxed);   // diagnostic: 1 = band-major always, 2 = never
+	return (forced == 1u || (forced == 0u && !overlapped)) ? (uint32_t)MAP_BAND_MAJOR : 0u;
+}
+
+// (the plain pass keeps its frame-major order: band-major measured level for it, 256 x 1080p alone 0.411 against 0.409 ms)
+hipError_t launch_map_pass(const Geom &g, const Buffers &b, uint32_t n, uint32_t flags, int grayscale, hipStream_t s, bool tiles_wanted, bool overlapped) {
 	// Few frames: shorter bands so a single frame still spreads over the chip.
-	const uint32_t RB = band_rows_for(g.rh, n, MAP_RB_MAX, tiles_wanted && b.tiled != nullptr);
+	const uint32_t RB = band_rows_for(g.rh, n, MAP_RB_MAX, tiles_wanted && b.tiled != nullptr, overlapped);
 	const dim3 grid((g.rh + RB - 1) / RB, n);
 	const unsigned lds = (g.m_block / 64u) * 640u;             // 64 x (pixel, verdict, id) per wave
 	const bool tiles = tiles_wanted && b.tiled != nullptr && (RB & 7u) == 0u;
@@ -1028,10 +1036,7 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 		}
 	}
 	if (tune && tune->map_prio) flags |= MAP_PRIO;
-	{	// the order of the work items (k_map_brq_pass): band-major where the launch runs alone
-		const uint32_t forced = g_map_band_major.load(std::memory_order_relaxed);   // diagnostic: 1 = always, 2 = never
-		if (forced == 1u || (forced == 0u && !(tune && tune->map_overlapped))) flags |= MAP_BAND_MAJOR;
-	}
+	flags |= work_item_order(tune && tune->map_overlapped);
 	const uint32_t cap = tune ? tune->map_grid_cap : 0u;
 	// Loads in flight per wave: two register sets of four rows (one group ahead: 107 registers, three workgroups per CU beside a
 	// search-service workgroup), or three (two groups ahead: 123 registers, two workgroups) where the launch asks for it
@@ -1068,9 +1073,14 @@ hipError_t launch_map_brq_pass(const Geom &g, const Buffers &b, uint32_t n, uint
 // four = 12); the bench line quotes the best of 4 / 8 / 12.
 // ------------------------------------------------------------------------------------------------
 template <int NR>
-__global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b, uint32_t RB) {
-	const uint32_t f = blockIdx.y, q = threadIdx.x;
-	const int r0 = (int)(blockIdx.x * RB), r1 = min(r0 + (int)RB, (int)g.rh);
+__global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b, uint32_t RB, uint32_t band_major) {
+	uint32_t f = blockIdx.y, band = blockIdx.x;                // (the pass's work-item order: k_map_brq_pass)
+	if (band_major) {
+		const uint32_t id = blockIdx.y * gridDim.x + blockIdx.x;
+		band = id / gridDim.y; f = id - band * gridDim.y;
+	}
+	const uint32_t q = threadIdx.x;
+	const int r0 = (int)(band * RB), r1 = min(r0 + (int)RB, (int)g.rh);
 	if (q >= g.m_quads) return;
 	const uint8_t *fp = b.frames + (size_t)f * g.frame_bytes + ((size_t)g.ry * g.W + g.m_ax) * 4 + (size_t)q * 16;
 	uint8_t *up = b.ui + (size_t)f * g.ui_stride + (size_t)q * 16;
@@ -1104,10 +1114,11 @@ __global__ void __launch_bounds__(1024) k_pattern_copy(Geom g, Buffers b, uint32
 hipError_t launch_pattern_copy(const Geom &g, const Buffers &b, uint32_t n, uint32_t rows_in_flight, hipStream_t s) {
 	const uint32_t RB = band_rows_for(g.rh, n, MAPQ_RB_MAX);   // (the pass's own band height for this launch)
 	const dim3 grid((g.rh + RB - 1) / RB, n), block(g.m_block);
+	const uint32_t bm = g_map_band_major.load(std::memory_order_relaxed) == 2u ? 0u : 1u;   // (the order of a pass that runs alone)
 	switch (rows_in_flight) {
-	case 0: case 4: hipLaunchKernelGGL(k_pattern_copy<4>, grid, block, 0, s, g, b, RB); break;
-	case 8: hipLaunchKernelGGL(k_pattern_copy<8>, grid, block, 0, s, g, b, RB); break;
-	case 12: hipLaunchKernelGGL(k_pattern_copy<12>, grid, block, 0, s, g, b, RB); break;
+	case 0: case 4: hipLaunchKernelGGL(k_pattern_copy<4>, grid, block, 0, s, g, b, RB, bm); break;
+	case 8: hipLaunchKernelGGL(k_pattern_copy<8>, grid, block, 0, s, g, b, RB, bm); break;
+	case 12: hipLaunchKernelGGL(k_pattern_copy<12>, grid, block, 0, s, g, b, RB, bm); break;
 	default: return hipErrorInvalidValue;
 	}
 	return hipGetLastError();
