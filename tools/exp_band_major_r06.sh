@@ -1,3 +1,8 @@
+#!/bin/bash
+# Round 6 experiment: the fused pass's work items in band-major order (smhv_debug_map_band_rows bit 31) at 1440p -- alone and inside the
+# frame-granular pipeline -- and in the 1080p pipeline with 1024 frames per submission.  build/lib_bm_all.so was a diagnostic build of the
+# library as it stood BEFORE the order switch went into every instantiation (it had it in the tile-writing one only): the committed library
+# has the switch everywhere, so SMH_VISION_HIP_LIB can simply be left unset now ('variant-lib' = the default library).
 L=$PWD/build/lib_bm_all.so
 SMH_VISION_HIP_LIB=$L BAND_ROWS="0 2147483648 0 2147483648" python tools/exp_band_rows_r06.py 128 2560 1440 20 2>&1 | grep "round 1" | sed "s/bands of 2147483648 rows/band-major             /" | cut -c1-150
 for r in 1 2 3; do

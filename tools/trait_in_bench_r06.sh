@@ -1,3 +1,5 @@
+#!/bin/bash
+# Round 6 experiment (see profiles/README.md and DESIGN.md section 5 for what it measured); run ON THE GPU BOX.
 p() { python -c "
 import json,sys
 d=json.load(open(sys.argv[1])); t=d['trait_path']; print(sys.argv[2], 'eager %.3f ms (crop_to_map %.3f, load %.3f)  lazy %.3f' % (t['eager_ms_per_frame'], t['eager_per_call_ms']['crop_to_map'], t['eager_per_call_ms']['load_frame'], t['ms_per_frame']))" $1 "$2"; }
